@@ -1,0 +1,364 @@
+"""Flat-array graph layout consumed by the HIP kernels (and by the oracle).
+
+The reference walks an `obgraph.Graph` through per-node accessor methods
+(/root/reference/graph_kmer_index/kmer_finder.py:50,62,259,279,350,384,138,143,374
+and critical_graph_paths.py:46,52-53,62 -- SURVEY.md section 8b).  The device
+path needs the same information as a handful of contiguous arrays that can be
+uploaded to HBM once:
+
+  node_size   int32 [n_nodes]      bases per node id (0 = empty "dummy" node or unused id)
+  seq_start   int64 [n_nodes+1]    exclusive prefix sum of node_size: global base index of (node, 0)
+  seq         uint8 [n_bases]      numeric bases a/n/m=0 c=1 g=2 t=3, nodes concatenated in id order
+  edge_start  int64 [n_nodes+1]    CSR successors, in `get_edges` order
+  edges       int32 [n_edges]
+  rev_start   int64 [n_nodes+1]    CSR predecessors (ascending source id, stable)
+  rev_edges   int32 [n_edges]
+  is_ref      uint8 [n_nodes]      is_linear_ref_node_or_linear_ref_dummy_node
+  allele_freq float64 [n_nodes]
+  exists      uint8 [n_nodes]      id is a real node of the graph
+
+`GraphArrays` also answers the obgraph accessor methods itself, so the same
+object can be handed to code written against obgraph (used by the golden-vector
+generator to drive the reference on synthetic graphs).
+"""
+import numpy as np
+
+_LETTER_TO_CODE = np.zeros(256, dtype=np.uint8)
+for _ch, _c in (("c", 1), ("g", 2), ("t", 3)):
+    _LETTER_TO_CODE[ord(_ch)] = _c
+    _LETTER_TO_CODE[ord(_ch.upper())] = _c
+
+
+def encode_letters(text):
+    """bytes/str -> uint8 codes (a,n,m and anything else -> 0; flat_kmers.py:134-145)."""
+    if isinstance(text, str):
+        text = text.encode("ascii")
+    return _LETTER_TO_CODE[np.frombuffer(text, dtype=np.uint8)]
+
+
+def _csr_from_lists(n_nodes, adjacency):
+    start = np.zeros(n_nodes + 1, dtype=np.int64)
+    for n, lst in adjacency.items():
+        start[n + 1] = len(lst)
+    np.cumsum(start, out=start)
+    flat = np.zeros(int(start[-1]), dtype=np.int32)
+    for n, lst in adjacency.items():
+        flat[start[n]:start[n] + len(lst)] = lst
+    return start, flat
+
+
+def _reverse_csr(n_nodes, edge_start, edges):
+    src = np.repeat(np.arange(n_nodes, dtype=np.int32), np.diff(edge_start))
+    order = np.argsort(edges, kind="stable")
+    rev_edges = src[order].astype(np.int32)
+    counts = np.bincount(edges, minlength=n_nodes)
+    rev_start = np.zeros(n_nodes + 1, dtype=np.int64)
+    np.cumsum(counts, out=rev_start[1:])
+    return rev_start, rev_edges
+
+
+class GraphArrays:
+    def __init__(self, node_size, seq, edge_start, edges, is_ref, allele_freq=None,
+                 exists=None, first_node=None, chromosome_start_nodes=None,
+                 node_to_ref_offset=None, rev_start=None, rev_edges=None):
+        self.node_size = np.ascontiguousarray(node_size, dtype=np.int32)
+        self.n_nodes = len(self.node_size)
+        self.seq_start = np.zeros(self.n_nodes + 1, dtype=np.int64)
+        np.cumsum(self.node_size, out=self.seq_start[1:])
+        self.seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        assert len(self.seq) == self.seq_start[-1]
+        self.edge_start = np.ascontiguousarray(edge_start, dtype=np.int64)
+        self.edges = np.ascontiguousarray(edges, dtype=np.int32)
+        assert len(self.edge_start) == self.n_nodes + 1
+        if rev_start is None:
+            rev_start, rev_edges = _reverse_csr(self.n_nodes, self.edge_start, self.edges)
+        self.rev_start = np.ascontiguousarray(rev_start, dtype=np.int64)
+        self.rev_edges = np.ascontiguousarray(rev_edges, dtype=np.int32)
+        self.is_ref = np.ascontiguousarray(is_ref, dtype=np.uint8)
+        if allele_freq is None:
+            allele_freq = np.ones(self.n_nodes, dtype=np.float64)
+        self.allele_freq = np.ascontiguousarray(allele_freq, dtype=np.float64)
+        if exists is None:
+            exists = np.ones(self.n_nodes, dtype=np.uint8)
+        self.exists = np.ascontiguousarray(exists, dtype=np.uint8)
+        if first_node is None:
+            indeg = np.diff(self.rev_start)
+            cand = np.nonzero((indeg == 0) & (self.exists != 0))[0]
+            first_node = int(cand[0])
+        self.first_node = int(first_node)
+        if chromosome_start_nodes is None:
+            chromosome_start_nodes = [self.first_node]
+        self._chromosome_start_nodes = [int(x) for x in chromosome_start_nodes]
+        self.node_to_ref_offset = node_to_ref_offset
+        self._device = None   # cache slot owned by graph_kmer_index_amd (device handle)
+
+    # ------------------------------------------------------------------ builders
+    @classmethod
+    def from_dicts(cls, node_sequences, edges, linear_ref_nodes, allele_frequencies=None):
+        """Same call shape as obgraph's `Graph.from_dicts` (tests/test_kmer_finder.py:12-16).
+
+        An empty node counts as linear-ref dummy iff none of its siblings is a
+        linear-ref node (assumption shared with the test stand-in)."""
+        n_nodes = max(int(n) for n in node_sequences) + 1
+        node_size = np.zeros(n_nodes, dtype=np.int32)
+        exists = np.zeros(n_nodes, dtype=np.uint8)
+        for n, s in node_sequences.items():
+            node_size[int(n)] = len(s)
+            exists[int(n)] = 1
+        seq_start = np.zeros(n_nodes + 1, dtype=np.int64)
+        np.cumsum(node_size, out=seq_start[1:])
+        seq = np.zeros(int(seq_start[-1]), dtype=np.uint8)
+        for n, s in node_sequences.items():
+            seq[seq_start[int(n)]:seq_start[int(n) + 1]] = encode_letters(s)
+        adjacency = {int(n): [int(x) for x in e] for n, e in edges.items()}
+        edge_start, flat_edges = _csr_from_lists(n_nodes, adjacency)
+        linear = set(int(n) for n in linear_ref_nodes)
+        rev = {n: [] for n in range(n_nodes)}
+        for n, succ in adjacency.items():
+            for m in succ:
+                rev[m].append(n)
+        is_ref = np.zeros(n_nodes, dtype=np.uint8)
+        for n in range(n_nodes):
+            if not exists[n]:
+                continue
+            if n in linear:
+                is_ref[n] = 1
+            elif node_size[n] == 0:
+                siblings = set()
+                for p in rev[n]:
+                    siblings.update(adjacency.get(p, []))
+                siblings.discard(n)
+                is_ref[n] = 0 if any(x in linear for x in siblings) else 1
+        af = np.ones(n_nodes, dtype=np.float64)
+        if allele_frequencies is not None:
+            for n, f in allele_frequencies.items():
+                af[int(n)] = f
+        linear_list = [int(n) for n in linear_ref_nodes]
+        ntro = np.zeros(n_nodes + 1, dtype=np.int64)
+        off = 0
+        for n in linear_list:
+            ntro[n] = off
+            off += int(node_size[n])
+        indeg0 = [n for n in range(n_nodes) if exists[n] and len(rev[n]) == 0]
+        first = min(indeg0)
+        chrom = [linear_list[0]] if linear_list else [first]
+        return cls(node_size, seq, edge_start, flat_edges, is_ref, af, exists, first, chrom, ntro)
+
+    @classmethod
+    def from_obgraph(cls, graph):
+        """Extract the flat arrays through the accessor methods the reference itself uses
+        (SURVEY.md 8b); obgraph's private array names are not relied upon."""
+        if isinstance(graph, cls):
+            return graph
+        n_nodes = int(graph.max_node_id()) + 1
+        sizes = np.asarray(graph.nodes)
+        node_size = np.zeros(n_nodes, dtype=np.int32)
+        m = min(n_nodes, len(sizes))
+        node_size[:m] = sizes[:m]
+        rev = graph.get_reverse_edges_hashtable()
+        adjacency, seqs = {}, []
+        exists = np.zeros(n_nodes, dtype=np.uint8)
+        is_ref = np.zeros(n_nodes, dtype=np.uint8)
+        for n in range(n_nodes):
+            e = [int(x) for x in graph.get_edges(n)]
+            if e:
+                adjacency[n] = e
+            if node_size[n] > 0:
+                seqs.append(np.asarray(graph.get_numeric_node_sequence(n), dtype=np.uint8))
+        for n in range(n_nodes):
+            try:
+                has_pred = len(rev[n]) > 0
+            except (KeyError, IndexError):
+                has_pred = False
+            if node_size[n] > 0 or n in adjacency or has_pred:
+                exists[n] = 1
+                is_ref[n] = 1 if graph.is_linear_ref_node_or_linear_ref_dummy_node(n) else 0
+        seq = np.concatenate(seqs) if seqs else np.zeros(0, dtype=np.uint8)
+        edge_start, flat_edges = _csr_from_lists(n_nodes, adjacency)
+        af = np.asarray(graph.get_node_allele_frequencies(np.arange(n_nodes)), dtype=np.float64)
+        chrom = list(graph.chromosome_start_nodes.values())
+        ntro = getattr(graph, "node_to_ref_offset", None)
+        return cls(node_size, seq, edge_start, flat_edges, is_ref, af, exists,
+                   int(graph.get_first_node()), chrom, ntro)
+
+    # ------------------------------------------- obgraph-compatible accessor surface
+    @property
+    def nodes(self):
+        return self.node_size
+
+    @property
+    def chromosome_start_nodes(self):
+        return {i + 1: n for i, n in enumerate(self._chromosome_start_nodes)}
+
+    def linear_ref_nodes(self):
+        return set(np.nonzero((self.is_ref != 0) & (self.node_size > 0))[0].tolist())
+
+    def get_first_node(self):
+        return self.first_node
+
+    def get_node_size(self, node):
+        return int(self.node_size[node])
+
+    def get_numeric_base_sequence(self, node, offset):
+        return int(self.seq[self.seq_start[node] + offset])
+
+    def get_numeric_node_sequence(self, node):
+        return self.seq[self.seq_start[node]:self.seq_start[node + 1]]
+
+    def get_edges(self, node):
+        return self.edges[self.edge_start[node]:self.edge_start[node + 1]].tolist()
+
+    def is_linear_ref_node_or_linear_ref_dummy_node(self, node):
+        return bool(self.is_ref[node])
+
+    def get_node_allele_frequencies(self, nodes):
+        return self.allele_freq[np.asarray(nodes, dtype=np.int64)]
+
+    def get_node_allele_frequency(self, node):
+        return float(self.allele_freq[node])
+
+    def get_reverse_edges_hashtable(self):
+        return _ReverseEdges(self)
+
+    def max_node_id(self):
+        return self.n_nodes - 1
+
+    def make_linear_ref_node_and_ref_dummy_node_index(self):
+        pass
+
+    def position_id_base(self):
+        """Per-node base of the default position id (exclusive cumulative node size)."""
+        return self.seq_start[:-1]
+
+
+class _ReverseEdges:
+    def __init__(self, g):
+        self._g = g
+
+    def __getitem__(self, node):
+        g = self._g
+        return g.rev_edges[g.rev_start[node]:g.rev_start[node + 1]].tolist()
+
+
+# ----------------------------------------------------------------------- synthetic graphs
+def _random_codes(n, seed_seq):
+    """n uniform codes in {0..3}; 32 codes per raw 64-bit draw."""
+    rng = np.random.Generator(np.random.PCG64(seed_seq))
+    raw = rng.bit_generator.random_raw((n + 31) // 32)
+    out = np.empty(len(raw) * 32, dtype=np.uint8)
+    b = raw.view(np.uint8).reshape(-1, 8)
+    o = out.reshape(-1, 4, 8)
+    for j in range(4):
+        np.bitwise_and(np.right_shift(b, 2 * j), 3, out=o[:, j, :])
+    return out[:n]
+
+
+def random_codes(n, seed, chunk=1 << 26):
+    """Chunk-seeded so that a prefix of a larger draw equals a smaller draw (bench sample)."""
+    out = np.empty(n, dtype=np.uint8)
+    for c, lo in enumerate(range(0, n, chunk)):
+        hi = min(n, lo + chunk)
+        out[lo:hi] = _random_codes(hi - lo, [seed, c])
+    return out
+
+
+def synthetic_linear_graph(n_bases, node_len=25000, seed=1234):
+    """BASELINE config 2: single-edge chain of linear-ref nodes."""
+    assert node_len <= 32767
+    n_nodes = (n_bases + node_len - 1) // node_len
+    node_size = np.full(n_nodes, node_len, dtype=np.int32)
+    node_size[-1] = n_bases - node_len * (n_nodes - 1)
+    seq = random_codes(n_bases, seed)
+    edge_start = np.minimum(np.arange(n_nodes + 1, dtype=np.int64), n_nodes - 1)
+    edges = np.arange(1, n_nodes, dtype=np.int32)
+    return GraphArrays(node_size, seq, edge_start, edges, np.ones(n_nodes, np.uint8),
+                       first_node=0, chromosome_start_nodes=[0],
+                       node_to_ref_offset=np.concatenate([[0], np.cumsum(node_size)])[:n_nodes + 1])
+
+
+def synthetic_snp_sites(n_ref_bases, n_sites, k, seed, min_gap=2, max_sites_per_window=5):
+    """Sorted SNP positions in [k, n_ref_bases-k): pairwise gap >= min_gap and at most
+    `max_sites_per_window` sites in any k-bp window."""
+    rng = np.random.default_rng([seed, 7])
+    want = n_sites
+    pos = np.unique(rng.integers(k, n_ref_bases - k, size=int(want * 1.02) + 16, dtype=np.int64))
+    keep = np.ones(len(pos), dtype=bool)
+    keep[1:] &= np.diff(pos) >= min_gap
+    pos = pos[keep]
+    m = max_sites_per_window
+    if len(pos) > m:
+        bad = np.zeros(len(pos), dtype=bool)
+        bad[m:] = (pos[m:] - pos[:-m]) < k
+        pos = pos[~bad]
+    if len(pos) > want:
+        sel = np.sort(rng.choice(len(pos), size=want, replace=False))
+        pos = pos[sel]
+        # thinning keeps both constraints valid
+    return pos
+
+
+def synthetic_snp_graph(n_ref_bases, n_sites, k=31, seed=1234, max_node_len=32767):
+    """BASELINE config 3/4: linear reference + SNP bubbles.
+
+    Node ids are topological: ref segment (split into chain nodes of > k bases when longer
+    than `max_node_len`), ref-allele node, alt-allele node, next ref segment ...  Successor
+    order is [ref_allele, alt_allele].  Ref nodes have allele frequency 1.0; the two alleles
+    of a site get f and 1-f with f ~ U(0.01, 0.99)."""
+    sites = synthetic_snp_sites(n_ref_bases, n_sites, k, seed)
+    S = len(sites)
+    # concatenated node sequence = reference with the alt base inserted right after each site
+    seq = random_codes(n_ref_bases + S, seed)
+    slot_ref = sites + np.arange(S, dtype=np.int64)          # index of the ref-allele base
+    rng = np.random.default_rng([seed, 11])
+    seq[slot_ref + 1] = (seq[slot_ref] + 1 + rng.integers(0, 3, size=S, dtype=np.uint8)) % 4
+    # ref segments: [0,s0) (s0,s1) ... (s_last, G)
+    seg_lo = np.concatenate([[0], sites + 1])
+    seg_hi = np.concatenate([sites, [n_ref_bases]])
+    seg_len = seg_hi - seg_lo
+    assert np.all(seg_len >= 1)
+    # split long segments into chain chunks, every chunk > k
+    n_chunks = np.maximum(1, -(-seg_len // max_node_len))
+    if np.any(n_chunks > 1):
+        assert np.all(seg_len[n_chunks > 1] // n_chunks[n_chunks > 1] > k + 1)
+    total_seg_nodes = int(n_chunks.sum())
+    n_nodes = total_seg_nodes + 2 * S
+    node_size = np.ones(n_nodes, dtype=np.int32)
+    is_ref = np.ones(n_nodes, dtype=np.uint8)
+    af = np.ones(n_nodes, dtype=np.float64)
+    # node id of first chunk of each segment
+    seg_first = np.zeros(S + 1, dtype=np.int64)
+    seg_first[1:] = np.cumsum(n_chunks[:-1] + 2)
+    # chunk sizes
+    chunk_seg = np.repeat(np.arange(S + 1), n_chunks)
+    chunk_idx = np.arange(total_seg_nodes) - np.repeat(np.cumsum(n_chunks) - n_chunks, n_chunks)
+    base = seg_len[chunk_seg] // n_chunks[chunk_seg]
+    rem = seg_len[chunk_seg] - base * n_chunks[chunk_seg]
+    csize = base + (chunk_idx < rem)
+    chunk_node = seg_first[chunk_seg] + chunk_idx
+    node_size[chunk_node] = csize
+    ref_allele = seg_first[:-1] + n_chunks[:-1]
+    alt_allele = ref_allele + 1
+    is_ref[alt_allele] = 0
+    f = rng.uniform(0.01, 0.99, size=S)
+    af[ref_allele] = f
+    af[alt_allele] = 1.0 - f
+    # edges: chunk -> next chunk (same segment) ; last chunk -> [ref, alt] ; alleles -> next seg first
+    out_deg = np.ones(n_nodes, dtype=np.int64)
+    last_chunk = seg_first + n_chunks - 1
+    out_deg[last_chunk[:-1]] = 2
+    out_deg[last_chunk[-1]] = 0
+    edge_start = np.zeros(n_nodes + 1, dtype=np.int64)
+    np.cumsum(out_deg, out=edge_start[1:])
+    edges = np.zeros(int(edge_start[-1]), dtype=np.int32)
+    inner = np.ones(total_seg_nodes, dtype=bool)
+    inner[np.cumsum(n_chunks) - 1] = False
+    edges[edge_start[chunk_node[inner]]] = chunk_node[inner] + 1
+    edges[edge_start[last_chunk[:-1]]] = ref_allele
+    edges[edge_start[last_chunk[:-1]] + 1] = alt_allele
+    edges[edge_start[ref_allele]] = seg_first[1:]
+    edges[edge_start[alt_allele]] = seg_first[1:]
+    ntro = np.zeros(n_nodes + 1, dtype=np.int64)
+    lin = np.nonzero(is_ref)[0]
+    ntro[lin] = np.concatenate([[0], np.cumsum(node_size[lin])[:-1]])
+    return GraphArrays(node_size, seq, edge_start, edges, is_ref, af,
+                       first_node=0, chromosome_start_nodes=[0], node_to_ref_offset=ntro)

@@ -1,0 +1,234 @@
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Run in the build container only (needs /root/reference; the test-only stand-ins under
+tests/standins/ replace the absent third-party packages obgraph / npstructures / Bio / pyfaidx):
+
+    python tests/golden/make_golden.py
+
+Fixtures are data only: graph literals / generator parameters and the reference's outputs.
+Nothing of the reference's source is stored.  The GPU box has no /root/reference; tests there
+read these files.
+"""
+import hashlib
+import json
+import logging
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [os.path.join(ROOT, "tests", "standins"), "/root/reference", ROOT, os.path.join(ROOT, "tests")]
+logging.disable(logging.CRITICAL)
+
+import numpy as np  # noqa: E402
+from graph_kmer_index.kmer_finder import DenseKmerFinder  # noqa: E402
+from graph_kmer_index.critical_graph_paths import CriticalGraphPaths  # noqa: E402
+from graph_kmer_index.flat_kmers import FlatKmers  # noqa: E402
+from graph_kmer_index.collision_free_kmer_index import CollisionFreeKmerIndex  # noqa: E402
+from graph_kmer_index.kmer_hashing import (kmer_hashes_to_reverse_complement_hash,  # noqa: E402
+                                           kmer_hashes_to_complement_hashes)
+from graph_kmer_index import sequence_to_kmer_hash, kmer_hash_to_sequence, ReadKmers  # noqa: E402
+from graph_kmer_index.kmer_hashing import power_array  # noqa: E402
+from obgraph import Graph  # noqa: E402
+
+from graph_kmer_index_amd.graph import GraphArrays, synthetic_linear_graph, synthetic_snp_graph  # noqa: E402
+from graphgen import random_bubble_graph, overlapping_bubble_graph  # noqa: E402
+from golden_cases import REFERENCE_TEST_GRAPHS, canonical_digest  # noqa: E402
+
+
+def run_finder(graph, k, **kw):
+    early = kw.pop("from_position", None)
+    cp = None
+    if early is None:
+        cp = CriticalGraphPaths.from_graph(graph, k)
+    f = DenseKmerFinder(graph, k, critical_graph_paths=cp, **kw)
+    if early is None:
+        f.find()
+    else:
+        f.find_only_kmers_starting_at_position(*early)
+    fl = f.get_flat_kmers()
+    crit = ([], []) if cp is None else (cp.nodes.tolist(), cp.offsets.tolist())
+    return fl, crit
+
+
+def toy_cases():
+    cases = []
+    rng = np.random.default_rng(20240501)
+
+    def add(name, seqs, edges, lin, k, af=None, **kw):
+        g = Graph.from_dicts(seqs, edges, lin, af)
+        kw2 = dict(kw)
+        if "only_store_nodes" in kw2:
+            kw2["only_store_nodes"] = set(kw2["only_store_nodes"])
+        try:
+            fl, crit = run_finder(g, k, **kw2)
+        except OverflowError:
+            cases.append(dict(name=name, seqs={str(a): b for a, b in seqs.items()},
+                              edges={str(a): b for a, b in edges.items()}, linear=lin, k=k,
+                              af=None if af is None else {str(a): b for a, b in af.items()},
+                              kw=kw, raises="E2"))
+            return
+        cases.append(dict(
+            name=name, seqs={str(a): b for a, b in seqs.items()}, edges={str(a): b for a, b in edges.items()},
+            linear=lin, k=k, af=None if af is None else {str(a): b for a, b in af.items()}, kw=kw,
+            crit_nodes=crit[0], crit_offsets=crit[1],
+            kmers=fl._hashes.tolist(), nodes=fl._nodes.tolist(), start_nodes=fl._start_nodes.tolist(),
+            start_offsets=fl._start_offsets.tolist(), allele_frequencies=fl._allele_frequencies.tolist()))
+
+    for name, (seqs, edges, lin, k, kw) in REFERENCE_TEST_GRAPHS.items():
+        add(name, seqs, edges, lin, k, **kw)
+    for i in range(40):
+        k = int(rng.integers(3, 8))
+        seqs, edges, lin, af = random_bubble_graph(rng, p_indel=float(rng.choice([0.0, 0.5])), with_af=True)
+        add("rand_bubble_%d" % i, seqs, edges, lin, k, af,
+            max_variant_nodes=int(rng.choice([0, 1, 2, 3, 4, 100])),
+            only_save_one_node_per_kmer=bool(rng.integers(0, 2)))
+    for i in range(15):
+        k = int(rng.integers(3, 8))
+        seqs, edges, lin, af = overlapping_bubble_graph(rng)
+        add("rand_overlap_%d" % i, seqs, edges, lin, k, af,
+            max_variant_nodes=int(rng.choice([1, 2, 4])), only_save_one_node_per_kmer=bool(rng.integers(0, 2)))
+    for i in range(30):
+        k = int(rng.integers(3, 8))
+        nv = int(rng.integers(1, 4))
+        seqs, edges, lin, af = random_bubble_graph(
+            rng, n_var=nv, min_ref=1, max_ref=3 * k + 8, p_indel=0.3,
+            chain_after={int(rng.integers(-1, nv)): int(rng.integers(1, k + 2))})
+        add("rand_chain_%d" % i, seqs, edges, lin, k, af,
+            max_variant_nodes=int(rng.choice([1, 4])), only_save_one_node_per_kmer=bool(rng.integers(0, 2)))
+    # chunked runs (command_line_interface.py:588-601): same graph, three critical-path ranges
+    for i in range(6):
+        k = int(rng.integers(3, 6))
+        seqs, edges, lin, af = random_bubble_graph(rng, n_var=7, min_ref=k, max_ref=3 * k, p_indel=0.3)
+        g = Graph.from_dicts(seqs, edges, lin)
+        n_crit = len(CriticalGraphPaths.from_graph(g, k))
+        cuts = [0, n_crit // 3, 2 * n_crit // 3, n_crit]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            add("rand_chunk_%d_%d_%d" % (i, a, b), seqs, edges, lin, k,
+                start_at_critical_path_number=a, stop_at_critical_path_number=b,
+                only_save_one_node_per_kmer=True, max_variant_nodes=5)
+    return cases
+
+
+def medium_cases():
+    """Generator-defined graphs at k=31; full columns for the linear one, digests for the SNP ones."""
+    out = {}
+    g = synthetic_linear_graph(20000, node_len=3000, seed=1234)
+    for one in (False, True):
+        fl, crit = run_finder(g, 31, only_save_one_node_per_kmer=one)
+        tag = "linear20k_one%d" % one
+        out[tag + "_kmers"] = fl._hashes
+        out[tag + "_nodes"] = fl._nodes
+        out[tag + "_start_nodes"] = fl._start_nodes
+        out[tag + "_start_offsets"] = fl._start_offsets
+        out[tag + "_af"] = fl._allele_frequencies
+    out["linear20k_crit_nodes"] = np.array(crit[0], dtype=np.uint32)
+    out["linear20k_crit_offsets"] = np.array(crit[1], dtype=np.uint16)
+    meta = {}
+    for name, (G, S, M, one) in {"snp100k_one1_M5": (100000, 400, 5, True),
+                                 "snp100k_one0_M4": (100000, 400, 4, False),
+                                 "snp30k_dense_one1_M2": (30000, 1500, 2, True),
+                                 "snp30k_dense_one0_M5": (30000, 1500, 5, False)}.items():
+        g = synthetic_snp_graph(G, S, k=31, seed=77)
+        fl, crit = run_finder(g, 31, only_save_one_node_per_kmer=one, max_variant_nodes=M)
+        cols = dict(kmers=fl._hashes, nodes=fl._nodes, start_nodes=fl._start_nodes,
+                    start_offsets=fl._start_offsets, allele_frequencies=fl._allele_frequencies)
+        meta[name] = dict(G=G, S=S, seed=77, k=31, M=M, one=one, n_records=int(len(fl._hashes)),
+                          digest=canonical_digest(cols), n_crit=len(crit[0]),
+                          graph_digest=hashlib.sha256(g.seq.tobytes() + g.node_size.tobytes()
+                                                      + g.edges.tobytes()).hexdigest())
+        out[name + "_head_kmers"] = fl._hashes[:3000]
+        out[name + "_head_nodes"] = fl._nodes[:3000]
+        out[name + "_head_start_nodes"] = fl._start_nodes[:3000]
+        out[name + "_head_start_offsets"] = fl._start_offsets[:3000]
+        out[name + "_head_af"] = fl._allele_frequencies[:3000]
+        out[name + "_crit_nodes"] = np.array(crit[0], dtype=np.uint32)
+        out[name + "_crit_offsets"] = np.array(crit[1], dtype=np.uint16)
+    return out, meta
+
+
+def hashing_cases():
+    rng = np.random.default_rng(99)
+    out = {}
+    for k in (3, 9, 16, 31):
+        h = rng.integers(0, 4 ** k, size=1000, dtype=np.uint64)
+        out["rc_in_k%d" % k] = h
+        out["rc_out_k%d" % k] = kmer_hashes_to_reverse_complement_hash(h.copy(), k).astype(np.uint64)
+        out["comp_out_k%d" % k] = kmer_hashes_to_complement_hashes(h.copy(), k).astype(np.uint64)
+    reads = ["".join("acgtACGTnN"[i] for i in rng.integers(0, 10, size=150)) for _ in range(20)]
+    reads += ["ACGT" * 8, "a" * 31, "T" * 40]
+    out["reads"] = np.array(reads)
+    for k in (5, 31):
+        pv = power_array(k)
+        out["read_kmers_k%d" % k] = np.concatenate(
+            [ReadKmers.get_kmers_from_read_dynamic(r, pv).astype(np.uint64) for r in reads])
+    seqs = ["ACTG", "T" * 31, "CAtgAACAtttggtAATCTACAtgAACAttt", "G", "atg", "Acacatacgactacg"]
+    out["kat_sequences"] = np.array(seqs)
+    out["kat_hashes"] = np.array([sequence_to_kmer_hash(s) for s in seqs], dtype=np.uint64)
+    assert all(kmer_hash_to_sequence(int(h), len(s)).lower() == s.lower() for s, h in zip(seqs, out["kat_hashes"]))
+    return out
+
+
+def index_cases():
+    out = {}
+    rng = np.random.default_rng(7)
+
+    def add(tag, hashes, nodes, ref_offsets, af, modulo, **kw):
+        flat = FlatKmers(hashes.astype(np.int64), nodes, ref_offsets, af)
+        idx = CollisionFreeKmerIndex.from_flat_kmers(flat, modulo=modulo, **kw)
+        out[tag + "_in_hashes"] = hashes.astype(np.int64)
+        out[tag + "_in_nodes"] = nodes
+        out[tag + "_in_ref_offsets"] = ref_offsets
+        out[tag + "_in_af"] = af
+        out[tag + "_modulo"] = np.int64(modulo)
+        for name in ("_hashes_to_index", "_n_kmers", "_nodes", "_ref_offsets", "_kmers", "_frequencies",
+                     "_allele_frequencies"):
+            out[tag + name] = np.asarray(getattr(idx, name))
+        # probes: every distinct kmer + misses, with two max_hits settings
+        queries = np.concatenate([np.unique(hashes), rng.integers(0, 4 ** 15, size=50)]).astype(np.int64)
+        out[tag + "_queries"] = queries
+        for mh in (10, 1):
+            hit_n, hit_nodes, hit_ro, hit_fr, hit_af = [], [], [], [], []
+            for q in queries:
+                r = idx.get(int(q), max_hits=mh)
+                if r[0] is None:
+                    hit_n.append(-1)
+                    continue
+                hit_n.append(len(r[0]))
+                hit_nodes.append(r[0]); hit_ro.append(r[1]); hit_fr.append(r[2]); hit_af.append(r[3])
+            cat = (lambda x, dt: np.concatenate(x).astype(dt) if x else np.zeros(0, dt))
+            out[tag + "_get%d_n" % mh] = np.array(hit_n, dtype=np.int64)
+            out[tag + "_get%d_nodes" % mh] = cat(hit_nodes, np.int64)
+            out[tag + "_get%d_ref_offsets" % mh] = cat(hit_ro, np.int64)
+            out[tag + "_get%d_frequencies" % mh] = cat(hit_fr, np.int64)
+            out[tag + "_get%d_af" % mh] = cat(hit_af, np.float64)
+
+    # fixture of tests/test_collision_free_kmer_index.py:6-15 (with int64 hashes, SURVEY.md 8c caveat 1)
+    add("kat", np.array([1, 1, 2, 2, 4, 5, 3]), np.array([5, 6, 7, 8, 10, 11, 100]),
+        np.array([1, 1, 2, 3, 10, 11, 100]), np.ones(7, dtype=np.float32), 4)
+    n = 4000
+    hashes = rng.integers(0, 600, size=n).astype(np.int64) * 7919
+    nodes = rng.integers(0, 5000, size=n).astype(np.uint32)
+    ref = rng.integers(0, 40, size=n).astype(np.uint64) + (hashes % 11).astype(np.uint64)
+    af = rng.uniform(0, 1, size=n).astype(np.float32)
+    add("rand", hashes, nodes, ref, af, 1009)
+    add("rand_skipfreq", hashes, nodes, ref, af, 1009, skip_frequencies=True)
+    add("rand_nosingle", hashes, nodes, ref, af, 257, skip_singletons=True)
+    return out
+
+
+def main():
+    cases = toy_cases()
+    with open(os.path.join(HERE, "finder_toy.json"), "w") as f:
+        json.dump(cases, f, separators=(",", ":"))
+    med, meta = medium_cases()
+    np.savez_compressed(os.path.join(HERE, "finder_medium.npz"), **med)
+    with open(os.path.join(HERE, "finder_medium_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    np.savez_compressed(os.path.join(HERE, "hashing.npz"), **hashing_cases())
+    np.savez_compressed(os.path.join(HERE, "index.npz"), **index_cases())
+    print("toy cases:", len(cases), "medium:", list(meta))
+
+
+if __name__ == "__main__":
+    main()

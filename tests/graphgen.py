@@ -1,0 +1,90 @@
+"""Random variation-graph generators for parity tests (test utility)."""
+import numpy as np
+
+_L = "ACGT"
+
+
+def _rand_seq(rng, n):
+    return "".join(_L[i] for i in rng.integers(0, 4, size=n))
+
+
+def random_bubble_graph(rng, n_var=None, min_ref=1, max_ref=14, p_indel=0.5,
+                        first_ref=None, last_ref=None, shuffle_succ=True, with_af=False,
+                        chain_after=None):
+    """Chain of bubbles.  Each bubble is a SNP (two 1-bp alleles), a deletion (ref allele of
+    1-3 bp on the linear ref, empty alt allele) or an insertion (empty ref allele = linear-ref
+    dummy, alt allele 1-3 bp).  Node ids increase along the graph.
+
+    chain_after: optional dict {bubble_index: chain_len} -> the ref segment after that bubble is
+    split into a first node of `chain_len` bases followed by the rest (single-edge chain).
+    Returns (node_sequences, edges, linear_ref_nodes, allele_frequencies)."""
+    if n_var is None:
+        n_var = int(rng.integers(2, 8))
+    seqs, edges, linear, af = {}, {}, [], {}
+    nid = 0
+
+    def add(seq, is_lin, freq=1.0):
+        nonlocal nid
+        seqs[nid] = seq
+        af[nid] = freq
+        if is_lin:
+            linear.append(nid)
+        nid += 1
+        return nid - 1
+
+    def ref_segment(length, chain_len=None):
+        s = _rand_seq(rng, length)
+        if chain_len is not None and 0 < chain_len < length:
+            a = add(s[:chain_len], True)
+            b = add(s[chain_len:], True)
+            edges[a] = [b]
+            return a, b
+        a = add(s, True)
+        return a, a
+
+    n0 = first_ref if first_ref is not None else int(rng.integers(min_ref, max_ref + 1))
+    head, tail = ref_segment(n0, (chain_after or {}).get(-1))
+    for b in range(n_var):
+        kind = rng.random()
+        f = float(rng.uniform(0.01, 0.99)) if with_af else 1.0
+        if kind >= p_indel:                       # SNP
+            r = _rand_seq(rng, 1)
+            a = _L[(_L.index(r) + 1 + int(rng.integers(0, 3))) % 4]
+            ref_a = add(r, True, f)
+            alt_a = add(a, False, 1.0 - f if with_af else 1.0)
+        elif kind < p_indel / 2:                  # deletion: alt allele empty
+            ref_a = add(_rand_seq(rng, int(rng.integers(1, 4))), True, f)
+            alt_a = add("", False, 1.0 - f if with_af else 1.0)
+        else:                                     # insertion: ref allele empty (ref dummy)
+            ref_a = add("", False, f)             # NOT listed in linear_ref_nodes
+            alt_a = add(_rand_seq(rng, int(rng.integers(1, 4))), False, 1.0 - f if with_af else 1.0)
+        succ = [ref_a, alt_a]
+        if shuffle_succ and rng.random() < 0.5:
+            succ = succ[::-1]
+        edges[tail] = succ
+        is_last = b == n_var - 1
+        n = (last_ref if (is_last and last_ref is not None)
+             else int(rng.integers(min_ref, max_ref + 1)))
+        head, new_tail = ref_segment(n, (chain_after or {}).get(b))
+        edges[ref_a] = [head]
+        edges[alt_a] = [head]
+        tail = new_tail
+    return seqs, edges, linear, (af if with_af else None)
+
+
+def overlapping_bubble_graph(rng, n_var=4, min_ref=2, max_ref=8):
+    """Bubbles plus a long alternative allele that skips over a whole bubble
+    (shape of tests/test_kmer_finder.py:51-62 `test_nested_paths`)."""
+    seqs, edges, linear, _ = random_bubble_graph(rng, n_var, min_ref, max_ref, p_indel=0.3)
+    # find ref segments (linear nodes with 2 successors) and add a skip allele across one bubble
+    branch = [n for n in linear if len(edges.get(n, [])) == 2]
+    if len(branch) >= 2:
+        i = int(rng.integers(0, len(branch) - 1))
+        src = branch[i]
+        # join node two bubbles ahead = successor of an allele of branch[i+1]
+        dst = edges[edges[branch[i + 1]][0]][0]
+        new = max(seqs) + 1
+        seqs[new] = _rand_seq(rng, int(rng.integers(1, 5)))
+        edges[src] = edges[src] + [new]
+        edges[new] = [dst]
+    return seqs, edges, linear, None

@@ -1,0 +1,89 @@
+"""Live cross-check: oracle and brute-force spec against the reference itself (build container only;
+skipped where /root/reference is absent).  Uses the test-only third-party stand-ins."""
+import logging
+import os
+import sys
+from collections import Counter
+import numpy as np
+import pytest
+
+from conftest import HAVE_REFERENCE, REFERENCE, ROOT
+
+pytestmark = pytest.mark.reference
+
+if HAVE_REFERENCE:
+    sys.path[:0] = [os.path.join(ROOT, "tests", "standins"), REFERENCE]
+    logging.disable(logging.CRITICAL)
+    from graph_kmer_index.kmer_finder import DenseKmerFinder
+    from graph_kmer_index.critical_graph_paths import CriticalGraphPaths
+    from obgraph import Graph
+
+from graph_kmer_index_amd.graph import GraphArrays
+from graphgen import random_bubble_graph, overlapping_bubble_graph
+from spec_bruteforce import spec_rows
+from oracle import oracle
+
+
+def _make(rng, mode, k):
+    if mode == "bubble":
+        return random_bubble_graph(rng, p_indel=float(rng.choice([0.0, 0.5])), with_af=True)
+    if mode == "overlap":
+        return overlapping_bubble_graph(rng)
+    nv = int(rng.integers(1, 4))
+    return random_bubble_graph(rng, n_var=nv, min_ref=1, max_ref=3 * k + 8, p_indel=0.3,
+                               chain_after={int(rng.integers(-1, nv)): int(rng.integers(1, k + 2))})
+
+
+@pytest.mark.parametrize("mode,n,seed", [("bubble", 150, 1), ("overlap", 100, 2), ("chain", 250, 3)])
+def test_oracle_and_spec_match_reference(mode, n, seed):
+    rng = np.random.default_rng(seed)
+    checked = 0
+    for _ in range(n):
+        k = int(rng.integers(3, 8))
+        M = int(rng.choice([0, 1, 2, 3, 4, 100]))
+        one = bool(rng.integers(0, 2))
+        seqs, edges, lin, af = _make(rng, mode, k)
+        g = GraphArrays.from_dicts(seqs, edges, lin, af)
+        rg = Graph.from_dicts(seqs, edges, lin, af)
+        try:
+            cp = CriticalGraphPaths.from_graph(rg, k)
+        except OverflowError:                      # reference crash E2 (SURVEY.md 8a')
+            with pytest.raises(oracle.OracleError):
+                oracle.critical_paths(g, k)
+            continue
+        ocn, oco = oracle.critical_paths(g, k)
+        assert np.array_equal(ocn, cp.nodes) and np.array_equal(oco, cp.offsets)
+        f = DenseKmerFinder(rg, k, critical_graph_paths=cp, max_variant_nodes=M, only_save_one_node_per_kmer=one)
+        f.find()
+        fl = f.get_flat_kmers()
+        o, flags = oracle.find(g, k, (cp.nodes, cp.offsets), one, M, return_flags=True)
+        # exact emission order, all five columns
+        assert np.array_equal(o["kmers"], fl._hashes) and np.array_equal(o["nodes"], fl._nodes)
+        assert np.array_equal(o["start_nodes"], fl._start_nodes)
+        assert np.array_equal(o["start_offsets"], fl._start_offsets)
+        assert np.array_equal(o["allele_frequencies"], fl._allele_frequencies)
+        if flags & oracle.ORC_FLAG_UNDEFINED_BULK:
+            continue                               # reference emits meaningless hashes here
+        crit = {int(a): int(b) for a, b in zip(cp.nodes, cp.offsets)}
+        ref_rows = Counter(zip(fl._hashes.tolist(), fl._start_nodes.tolist(), fl._start_offsets.tolist(),
+                               fl._nodes.tolist(), fl._allele_frequencies.tolist()))
+        assert spec_rows(g, k, M, one, crit) == ref_rows
+        checked += 1
+    assert checked > n // 2
+
+
+def test_chunked_find_equals_unchunked():
+    # command_line_interface.py:588-601 chunking over critical-path ranges
+    rng = np.random.default_rng(11)
+    for _ in range(30):
+        k = int(rng.integers(3, 6))
+        seqs, edges, lin, af = random_bubble_graph(rng, n_var=7, min_ref=k, max_ref=3 * k, p_indel=0.3)
+        g = GraphArrays.from_dicts(seqs, edges, lin)
+        cn, co = oracle.critical_paths(g, k)
+        full = oracle.find(g, k, (cn, co), True, 5)
+        n = len(cn)
+        cuts = [0, n // 3, 2 * n // 3, n]
+        parts = [oracle.find(g, k, (cn, co), True, 5, start_at_critical_path_number=a,
+                             stop_at_critical_path_number=b) for a, b in zip(cuts[:-1], cuts[1:])]
+        for key in ("kmers", "nodes", "start_nodes", "start_offsets"):
+            assert np.array_equal(np.concatenate([p[key] for p in parts]), full[key])
