@@ -1,0 +1,158 @@
+"""ctypes binding of libgki_hip.so (C ABI in include/gki.h).
+
+There is no CPU fallback: if the shared library is missing or no MI355X is visible, the
+operations raise.  `python -c "import __graft_entry__ as g; g.build()"` (or
+`make -C graph_kmer_index_amd/csrc`) builds the library in-tree.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgki_hip.so")
+
+
+class GkiError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libgki_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+class FindParams(C.Structure):
+    _fields_ = [("k", C.c_int32), ("max_variant_nodes", C.c_int32), ("one_node_per_kmer", C.c_int32),
+                ("reserved", C.c_int32), ("node_begin", C.c_int64), ("off_begin", C.c_int64),
+                ("node_end", C.c_int64), ("off_end", C.c_int64), ("h_lossy_crit", C.c_void_p)]
+
+
+class IndexView(C.Structure):
+    _fields_ = [("d_hashes_to_index", C.c_void_p), ("d_n_kmers", C.c_void_p), ("d_kmers", C.c_void_p),
+                ("d_nodes", C.c_void_p), ("d_ref_offsets", C.c_void_p), ("d_frequencies", C.c_void_p),
+                ("d_af32", C.c_void_p), ("modulo", C.c_uint64), ("n", C.c_int64)]
+
+
+# every symbol include/gki.h declares: name -> (restype, argtypes)
+_P, _I64, _I32, _U64 = C.c_void_p, C.c_int64, C.c_int, C.c_uint64
+SYMBOLS = {
+    "gki_last_error": (C.c_char_p, []),
+    "gki_device_count": (_I32, [C.POINTER(C.c_int)]),
+    "gki_set_device": (_I32, [_I32]),
+    "gki_malloc": (_I32, [C.POINTER(_P), _I64]),
+    "gki_free": (_I32, [_P]),
+    "gki_memcpy_h2d": (_I32, [_P, _P, _I64]),
+    "gki_memcpy_d2h": (_I32, [_P, _P, _I64]),
+    "gki_memset": (_I32, [_P, _I32, _I64]),
+    "gki_device_synchronize": (_I32, []),
+    "gki_mem_info": (_I32, [C.POINTER(_I64), C.POINTER(_I64)]),
+    "gki_hash_sequence": (_I32, [_P, _I64, _I32, _P]),
+    "gki_hash_reads": (_I32, [_P, _P, _I64, _I32, _I32, _P, _P, _I64, C.POINTER(_I64)]),
+    "gki_reverse_complement": (_I32, [_P, _I64, _I32, _P]),
+    "gki_complement": (_I32, [_P, _I64, _I32, _P]),
+    "gki_graph_create": (_I32, [C.POINTER(_P), _I64, _P, _P, _I64, _P, _P, _P, _P, _I64, _P, _P, _P]),
+    "gki_graph_create_dseq": (_I32, [C.POINTER(_P), _I64, _P, _P, _I64, _P, _P, _P, _P, _I64, _P, _P, _P]),
+    "gki_graph_prepare": (_I32, [_P]),
+    "gki_graph_destroy": (_I32, [_P]),
+    "gki_graph_n_bases": (_I64, [_P]),
+    "gki_critical_paths": (_I32, [_I64, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, C.POINTER(_I64)]),
+    "gki_finder_create": (_I32, [_P, C.POINTER(_P)]),
+    "gki_finder_destroy": (_I32, [_P]),
+    "gki_finder_count": (_I32, [_P, C.POINTER(FindParams), C.POINTER(_I64)]),
+    "gki_finder_emit_flat": (_I32, [_P, _P, _P, _P, _P]),
+    "gki_finder_emit_v2": (_I32, [_P, _P, _P, _P, _P, _P]),
+    "gki_finder_synchronize": (_I32, [_P]),
+    "gki_finder_kernel_ms": (_I32, [_P, _I32, C.POINTER(C.c_float)]),
+    "gki_finder_interior_records": (_I64, [_P]),
+    "gki_index_build": (_I32, [_P, _P, _P, _P, _I64, _U64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gki_index_lookup_count": (_I32, [C.POINTER(IndexView), _P, _I64, _I64, _P, C.POINTER(_I64)]),
+    "gki_index_lookup_emit": (_I32, [C.POINTER(IndexView), _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libgki_hip.so and bind every exported symbol.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libgki_hip.so is not built (%s). Run `make -C graph_kmer_index_amd/csrc`; "
+                          "graph_kmer_index_amd has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    missing = [name for name in SYMBOLS if not hasattr(lib, name)]
+    if missing:
+        raise ImportError("libgki_hip.so is stale: missing %s (rebuild with make -C graph_kmer_index_amd/csrc)" % missing)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        raise GkiError(code, load().gki_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load().gki_device_count(C.byref(n))
+    return 0 if rc != 0 else n.value
+
+
+def require_device():
+    if device_count() < 1:
+        raise GkiError(3, "no HIP device visible: graph_kmer_index_amd needs an MI355X (no CPU fallback)")
+
+
+def hptr(a):
+    """Host pointer of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceArray:
+    """A typed 1-D buffer in HBM owned by this object (freed on garbage collection)."""
+
+    def __init__(self, n, dtype):
+        self.dtype = np.dtype(dtype)
+        self.n = int(n)
+        p = C.c_void_p()
+        check(load().gki_malloc(C.byref(p), self.n * self.dtype.itemsize))
+        self.ptr = p
+
+    @classmethod
+    def from_host(cls, a):
+        a = np.ascontiguousarray(a)
+        d = cls(a.size, a.dtype)
+        check(load().gki_memcpy_h2d(d.ptr, hptr(a), a.nbytes))
+        return d
+
+    def to_host(self, n=None):
+        n = self.n if n is None else int(n)
+        out = np.empty(n, dtype=self.dtype)
+        check(load().gki_memcpy_d2h(hptr(out), self.ptr, out.nbytes))
+        return out
+
+    def zero(self):
+        check(load().gki_memset(self.ptr, 0, self.n * self.dtype.itemsize))
+
+    @property
+    def nbytes(self):
+        return self.n * self.dtype.itemsize
+
+    def free(self):
+        if self.ptr is not None and self.ptr.value:
+            load().gki_free(self.ptr)
+            self.ptr = None
+
+    def __len__(self):
+        return self.n
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,279 @@
+"""CollisionFreeKmerIndex with the reference's attributes, constructor and methods
+(collision_free_kmer_index.py:163-490); `from_flat_kmers` and the batched getters run on MI355X.
+
+The attribute arrays stay NumPy-readable (`to_file`/`from_file` use the reference's .npz keys, and
+kmer_mapper reads `_hashes_to_index/_n_kmers/_nodes/_kmers/_modulo` directly, :210-216); a device
+copy for batched lookups is created lazily and cached.
+"""
+import ctypes as C
+import gc
+import logging
+import numpy as np
+
+from . import _lib
+from .flat_kmers import FlatKmers, DeviceFlatKmers
+from .kmer_hashing import kmer_hash_to_reverse_complement_hash
+
+
+class DeviceIndex:
+    """The seven index arrays resident in HBM."""
+
+    def __init__(self, n, modulo, hashes_to_index, n_kmers, kmers, nodes, ref_offsets, af, frequencies):
+        self.n, self.modulo = int(n), int(modulo)
+        self.permutation = None
+        self.hashes_to_index, self.n_kmers, self.kmers, self.nodes = hashes_to_index, n_kmers, kmers, nodes
+        self.ref_offsets, self.allele_frequencies, self.frequencies = ref_offsets, af, frequencies
+
+    def view(self):
+        return _lib.IndexView(self.hashes_to_index.ptr, self.n_kmers.ptr, self.kmers.ptr, self.nodes.ptr,
+                              self.ref_offsets.ptr, self.frequencies.ptr, self.allele_frequencies.ptr,
+                              self.modulo, self.n)
+
+    @classmethod
+    def build(cls, dflat, modulo=452930477, skip_frequencies=False, want_permutation=False):
+        """gki_index_build on device-resident FlatKmers columns."""
+        _lib.require_device()
+        n = dflat.n
+        na = max(n, 1)
+        out = cls(n, modulo, _lib.DeviceArray(modulo, np.int32), _lib.DeviceArray(modulo, np.uint32),
+                  _lib.DeviceArray(na, np.uint64), _lib.DeviceArray(na, np.uint32), _lib.DeviceArray(na, np.uint64),
+                  _lib.DeviceArray(na, np.float32), _lib.DeviceArray(na, np.uint16))
+        perm = _lib.DeviceArray(na, np.uint32) if want_permutation else None
+        out.permutation = perm
+        _lib.check(_lib.load().gki_index_build(
+            dflat.hashes.ptr, dflat.nodes.ptr, dflat.ref_offsets.ptr, dflat.allele_frequencies.ptr, n, int(modulo),
+            int(bool(skip_frequencies)), out.hashes_to_index.ptr, out.n_kmers.ptr, out.kmers.ptr, out.nodes.ptr,
+            out.ref_offsets.ptr, out.allele_frequencies.ptr, out.frequencies.ptr, None if perm is None else perm.ptr))
+        return out
+
+    def lookup_positions(self, queries, max_hits=10):
+        """Batched CollisionFreeKmerIndex.get: (hit_start int64[q+1], position int64[hits] into the payload
+        arrays, query index int64[hits]) as NumPy arrays."""
+        lib = _lib.load()
+        q = np.ascontiguousarray(np.asarray(queries)).astype(np.uint64)
+        nq = len(q)
+        dq = _lib.DeviceArray.from_host(q if nq else np.zeros(1, np.uint64))
+        hs = _lib.DeviceArray(nq + 1, np.int64)
+        view = self.view()
+        n_hits = C.c_int64(0)
+        mh = int(min(max_hits, 2 ** 62))
+        _lib.check(lib.gki_index_lookup_count(C.byref(view), dq.ptr, nq, mh, hs.ptr, C.byref(n_hits)))
+        m = n_hits.value
+        pos, qi = _lib.DeviceArray(max(m, 1), np.int64), _lib.DeviceArray(max(m, 1), np.int64)
+        if m:
+            _lib.check(lib.gki_index_lookup_emit(C.byref(view), dq.ptr, nq, mh, hs.ptr, None, None, qi.ptr, None, None,
+                                                 pos.ptr))
+        out = (hs.to_host(), pos.to_host(m), qi.to_host(m))
+        for b in (dq, hs, pos, qi):
+            b.free()
+        return out
+
+    def free(self):
+        for a in (self.hashes_to_index, self.n_kmers, self.kmers, self.nodes, self.ref_offsets,
+                  self.allele_frequencies, self.frequencies):
+            a.free()
+
+
+class CollisionFreeKmerIndex:
+    properties = {"_hashes_to_index", "_n_kmers", "_nodes", "_ref_offsets", "_kmers", "_modulo", "_frequencies",
+                  "_allele_frequencies"}
+
+    def __init__(self, _hashes_to_index=None, _n_kmers=None, _nodes=None, _ref_offsets=None, _kmers=None,
+                 _modulo=452930477, _frequencies=None, _allele_frequencies=None):
+        self._hashes_to_index = _hashes_to_index
+        self._n_kmers = _n_kmers
+        self._nodes = _nodes
+        self._ref_offsets = _ref_offsets
+        self._kmers = _kmers
+        self._modulo = int(_modulo)
+        self._frequencies = 0 if _frequencies is None else _frequencies
+        self._allele_frequencies = _allele_frequencies
+        self._device = None
+
+    # ------------------------------------------------------------------ build
+    @classmethod
+    def from_flat_kmers(cls, flat_kmers, modulo=452930477, skip_frequencies=False, skip_singletons=False):
+        """collision_free_kmer_index.py:423-467.  Records of a bucket keep their input order (the
+        reference's np.argsort leaves that order unspecified)."""
+        if skip_singletons:
+            flat_kmers = flat_kmers.get_new_without_singletons()
+        host_cols = None
+        if not isinstance(flat_kmers, DeviceFlatKmers):
+            host_cols = [np.asarray(flat_kmers._hashes), np.asarray(flat_kmers._nodes),
+                         np.asarray(flat_kmers._ref_offsets), np.asarray(flat_kmers._allele_frequencies)]
+            dflat = DeviceFlatKmers.from_flat_kmers(flat_kmers)
+        else:
+            dflat = flat_kmers
+        dev = DeviceIndex.build(dflat, modulo, skip_frequencies, want_permutation=host_cols is not None)
+        n = dflat.n
+        freq = dev.frequencies.to_host(n)
+        if skip_singletons:
+            freq = freq + np.uint16(1)                                                     # :463-465
+        dev_cols = [dev.kmers, dev.nodes, dev.ref_offsets, dev.allele_frequencies]
+        if host_cols is None:
+            cols = [c.to_host(n) for c in dev_cols]
+        else:
+            # the reference permutes the caller's arrays whatever their dtype (:436-440): columns whose dtype is the
+            # device's (up to signedness) come back from HBM, others are permuted here with the device's `sorting`
+            dflat.free()
+            perm = None
+            cols = []
+            for h, d in zip(host_cols, dev_cols):
+                if h.dtype.kind in "iu" and d.dtype.kind in "iu" and h.dtype.itemsize == d.dtype.itemsize \
+                        or h.dtype == d.dtype:
+                    cols.append(d.to_host(n).view(h.dtype))
+                else:
+                    if perm is None:
+                        perm = dev.permutation.to_host(n).astype(np.int64)
+                    cols.append(h[perm])
+            dev.permutation.free()
+            dev.permutation = None
+        obj = cls(dev.hashes_to_index.to_host(), dev.n_kmers.to_host(), cols[1], cols[2], cols[0], modulo, freq, cols[3])
+        if skip_singletons:
+            dev.free()            # device frequencies differ from the host ones by the +1
+        else:
+            obj._device = dev
+        return obj
+
+    def _device_index(self):
+        if self._device is None:
+            _lib.require_device()
+            n = len(self._kmers)
+            freq = self._frequencies
+            if not isinstance(freq, np.ndarray) or len(freq) != n:
+                freq = np.zeros(n, dtype=np.uint16)
+            af = self._allele_frequencies if self._allele_frequencies is not None else np.zeros(n, np.float32)
+            h = _lib.DeviceArray.from_host
+            self._device = DeviceIndex(
+                n, self._modulo, h(np.asarray(self._hashes_to_index).astype(np.int32)),
+                h(np.asarray(self._n_kmers).astype(np.uint32)), h(np.asarray(self._kmers).astype(np.uint64)),
+                h(np.asarray(self._nodes).astype(np.uint32)), h(np.asarray(self._ref_offsets).astype(np.uint64)),
+                h(np.asarray(af).astype(np.float32)), h(np.asarray(freq).astype(np.uint16)))
+        return self._device
+
+    def _invalidate_device(self):
+        if self._device is not None:
+            self._device.free()
+            self._device = None
+
+    # ------------------------------------------------------------------ housekeeping (reference :191-244)
+    def clear(self):
+        self._hashes_to_index = self._n_kmers = self._nodes = self._kmers = self._modulo = None
+        self._invalidate_device()
+        gc.collect()
+
+    def copy(self):
+        return CollisionFreeKmerIndex(self._hashes_to_index.copy(), self._n_kmers.copy(), self._nodes.copy(),
+                                      self._ref_offsets.copy(), self._kmers.copy(), self._modulo,
+                                      self._frequencies.copy(), self._allele_frequencies.copy())
+
+    def get_kmers(self):
+        return self._kmers
+
+    def set_allele_frequencies(self, frequencies):
+        pass
+
+    def max_node_id(self):
+        return np.max(self._nodes)
+
+    def convert_to_int32(self):
+        self._hashes_to_index = self._hashes_to_index.astype(np.int32)
+        self._nodes = self._nodes.astype(np.int32)
+        self._n_kmers = self._n_kmers.astype(np.int32)
+        self._modulo = np.uint64(self._modulo)
+
+    def remove_ref_offsets(self):
+        self._ref_offsets = np.array([0])
+        self._invalidate_device()
+
+    def remove_frequencies(self):
+        self._frequencies = np.array([0])
+        self._invalidate_device()
+
+    def has_kmers(self, kmers):
+        """kmer_mapper.in_graph_index equivalent (:214-216): membership of every query."""
+        hs = self._device_index().lookup_positions(kmers, max_hits=2 ** 62)[0]
+        return np.diff(hs) > 0
+
+    def map_kmers(self, kmers, n_nodes):
+        """kmer_mapper.map_kmers_to_graph_index equivalent (:210-212): node hit counts."""
+        pos = self._device_index().lookup_positions(kmers, max_hits=2 ** 62)[1]
+        return np.bincount(np.asarray(self._nodes)[pos].astype(np.int64), minlength=n_nodes)
+
+    # ------------------------------------------------------------------ probes
+    def get(self, kmer, max_hits=10):
+        """collision_free_kmer_index.py:303-315, served by the batched device probe with one query; the hit
+        positions index this object's own arrays, so every dtype comes back as stored."""
+        _, pos, _ = self._device_index().lookup_positions(np.array([int(kmer)], dtype=np.uint64), max_hits)
+        if len(pos) == 0:
+            return None, None, None, None
+        return self._nodes[pos], self._ref_offsets[pos], self._frequencies[pos], self._allele_frequencies[pos]
+
+    def __contains__(self, item):
+        return self.get(int(item), 100000000000)[0] is not None
+
+    def get_nodes(self, kmer, max_hits=10):
+        return self.get(kmer, max_hits)[0]
+
+    def get_grouped_nodes(self, kmer, max_hits=10):
+        hits = self.get(kmer, max_hits)
+        if hits[0] is None:
+            return None
+        sorting = np.argsort(hits[1])
+        ref_offsets, nodes = hits[1][sorting], hits[0][sorting]
+        _, idx = np.unique(ref_offsets, return_index=True)
+        idx = list(idx) + [len(ref_offsets)]
+        return [nodes[a:b] for a, b in zip(idx[:-1], idx[1:])]
+
+    def get_frequency(self, kmer, include_reverse_complement=True, k=31):
+        nodes, _, frequencies, _ = self.get(kmer, max_hits=1000000000000000)
+        f = 0 if nodes is None else int(frequencies[0])
+        if include_reverse_complement:
+            rev = int(kmer_hash_to_reverse_complement_hash(kmer, k))
+            nodes, _, frequencies, _ = self.get(rev, max_hits=1000000000000000)
+            if nodes is not None:
+                f += int(frequencies[0])
+        return f
+
+    def get_nodes_and_ref_offsets_from_multiple_kmers(self, kmers, max_hits=10):
+        """:354-376 -- one batched device probe instead of a Python loop of get()."""
+        _, pos, query = self._device_index().lookup_positions(kmers, max_hits)
+        if len(pos) == 0:
+            return np.array([]), np.array([]), np.array([]), np.array([])
+        return self._nodes[pos], self._ref_offsets[pos], query.astype(np.float64), self._frequencies[pos]
+
+    def get_nodes_from_multiple_kmers(self, kmers, max_hits=10):
+        """:378-391."""
+        _, pos, _ = self._device_index().lookup_positions(kmers, max_hits)
+        if len(pos) == 0:
+            return np.array([])
+        return self._nodes[pos]
+
+    # ------------------------------------------------------------------ I/O (:393-420)
+    def to_file(self, file_name):
+        np.savez(file_name, hashes_to_index=self._hashes_to_index, n_kmers=self._n_kmers, nodes=self._nodes,
+                 ref_offsets=self._ref_offsets, kmers=self._kmers, modulo=self._modulo, frequencies=self._frequencies,
+                 allele_frequencies=self._allele_frequencies)
+
+    @classmethod
+    def from_file(cls, file_name):
+        try:
+            data = np.load(file_name + ".npz")
+        except FileNotFoundError:
+            data = np.load(file_name)
+        af = data["allele_frequencies"] if "allele_frequencies" in data else np.zeros(len(data["ref_offsets"]))
+        return cls(data["hashes_to_index"], data["n_kmers"], data["nodes"], data["ref_offsets"], data["kmers"],
+                   data["modulo"], data["frequencies"], af)
+
+    def set_frequencies(self, skip=False):
+        """:267-293 -- rebuilds the frequency column on device from the current payload."""
+        n = len(self._kmers)
+        self._frequencies = np.zeros(n, dtype=np.uint16)
+        if skip:
+            return
+        flat = FlatKmers(np.asarray(self._kmers), np.asarray(self._nodes), np.asarray(self._ref_offsets),
+                         np.asarray(self._allele_frequencies))
+        rebuilt = CollisionFreeKmerIndex.from_flat_kmers(flat, self._modulo)
+        # a stable re-sort of already bucket-sorted records is the identity permutation
+        self._frequencies = rebuilt._frequencies
+        logging.info("Frequencies set")

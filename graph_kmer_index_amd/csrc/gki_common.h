@@ -1,0 +1,92 @@
+// Shared device/host helpers of libgki_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/gki.h"
+
+#define GKI_WAVE 64
+
+extern thread_local char gki_err_buf[512];
+int gki_set_error(int code, const char *fmt, ...);
+
+#define HIP_TRY(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return gki_set_error(GKI_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call,     \
+                                 hipGetErrorString(e_));                                       \
+    } while (0)
+
+#define GKI_TRY(call)                  \
+    do {                               \
+        int r_ = (call);               \
+        if (r_ != GKI_OK) return r_;   \
+    } while (0)
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Grid for a grid-stride streaming kernel: enough blocks to fill 256 CUs x 8 blocks, no more.
+static inline int stream_grid(int64_t work_items, int block) {
+    int64_t g = ceil_div(work_items, block);
+    if (g > 256 * 8) g = 256 * 8;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------------------------- 2-bit sequence
+// seq2: bases packed 32 per uint64, base i of the graph at bits [2*(i%32), 2*(i%32)+2) of word i/32.
+// With the reference's hash (first base least significant, kmer_hashing.py:4-9) the hash of the
+// t bases starting at global position P is simply a 2t-bit field of that bit stream.
+__device__ __forceinline__ uint64_t gki_extract(const uint64_t *__restrict__ seq2, int64_t P, int t) {
+    int64_t w = P >> 5;
+    int sh = (int)(P & 31) * 2;
+    uint64_t lo = seq2[w];
+    uint64_t hi = seq2[w + 1];
+    uint64_t v = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    return v & ((1ull << (2 * t)) - 1ull);   // t <= 31
+}
+
+// ---------------------------------------------------------------------------------- device graph view
+struct DevGraph {
+    int64_t n_nodes, n_bases, n_words64;     // n_words64 = ceil(n_bases / 64): one bitmap word per 64 bases
+    const int32_t *node_size;
+    const int64_t *seq_start;                // [n_nodes+1]
+    const uint8_t *seq;                      // uint8 bases (kept for re-prepare)
+    const uint64_t *seq2;                    // 2-bit packed, padded
+    const int64_t *rev_start;
+    const int32_t *rev_edges;
+    const int64_t *edge_start;
+    const int32_t *edges;
+    const uint8_t *is_ref;
+    const double *allele_freq;
+    const int64_t *pos_base;                 // position id of (node, 0)
+    const uint64_t *start_mask;              // bit p%64 of word p/64 set iff a non-empty node starts at base p
+    const uint32_t *start_rank;              // number of node starts in words before this one
+    const int32_t *nonempty;                 // ids of non-empty nodes, ascending (= sequence order)
+    int64_t n_nonempty;
+};
+
+struct gki_graph {
+    DevGraph d;
+    hipStream_t stream;
+    int device;
+    void *owned[24];
+    int n_owned;
+    bool owns_seq;
+    hipEvent_t ev_prep0, ev_prep1;
+};
+
+// ---------------------------------------------------------------------------------- exclusive scan
+// out[0..n] (n+1 entries), out[n] = total.  Three launches: block sums, scan of block sums, rescan.
+int gki_scan_u32_to_i64(const uint32_t *d_in, int64_t n, int64_t *d_out, void *d_tmp, int64_t tmp_bytes,
+                        hipStream_t s);
+int gki_scan_i32_to_i64(const int32_t *d_in, int64_t n, int64_t *d_out, void *d_tmp, int64_t tmp_bytes,
+                        hipStream_t s);
+int gki_scan_u32_to_u32(const uint32_t *d_in, int64_t n, uint32_t *d_out, void *d_tmp, int64_t tmp_bytes,
+                        hipStream_t s);
+int64_t gki_scan_tmp_bytes(int64_t n);
+
+// uint8 bases -> 2-bit stream (out sized ceil(n/16) uint32), asynchronous on `s` (gki_graph.hip).
+int gki_launch_pack(const uint8_t *d_seq, int64_t n_bases, uint32_t *d_out, hipStream_t s);

@@ -1,0 +1,241 @@
+// Device graph: obgraph's node-sequence / edge arrays resident in HBM, 2-bit packed, plus the
+// node-start bitmap + rank that turns "which node owns base p" into a popcount.
+#include "gki_common.h"
+#include <vector>
+#include <limits.h>
+
+namespace {
+
+// 16 bases (uint8 each, values 0..3) -> 32 bits, first base in the least significant 2 bits.
+__device__ __forceinline__ uint32_t pack4(uint32_t x) {
+    x = (x | (x >> 6)) & 0x000F000Fu;
+    return (x | (x >> 12)) & 0xFFu;
+}
+
+__global__ __launch_bounds__(256) void k_pack_2bit(const uint8_t *__restrict__ seq, int64_t n_bases,
+                                                   uint32_t *__restrict__ seq2_u32, int64_t n_u32) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_u32; i += stride) {
+        int64_t b = i * 16;
+        uint32_t r;
+        if (b + 16 <= n_bases) {
+            uint4 v = *reinterpret_cast<const uint4 *>(seq + b);     // 16 B per lane, coalesced
+            r = pack4(v.x & 0x03030303u) | (pack4(v.y & 0x03030303u) << 8) |
+                (pack4(v.z & 0x03030303u) << 16) | (pack4(v.w & 0x03030303u) << 24);
+        } else {
+            r = 0;
+            for (int j = 0; j < 16; j++)
+                if (b + j < n_bases) r |= (uint32_t)(seq[b + j] & 3) << (2 * j);
+        }
+        seq2_u32[i] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_start_mask(const int32_t *__restrict__ nonempty, int64_t n_nonempty,
+                                                    const int64_t *__restrict__ seq_start,
+                                                    unsigned long long *__restrict__ mask) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_nonempty; j += stride) {
+        int64_t p = seq_start[nonempty[j]];
+        atomicOr(&mask[p >> 6], 1ull << (p & 63));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_popcount(const uint64_t *__restrict__ mask, int64_t n, uint32_t *__restrict__ cnt) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) cnt[i] = (uint32_t)__popcll(mask[i]);
+}
+
+}  // namespace
+
+// uint8 bases -> 2-bit stream (out sized ceil(n/16) uint32), asynchronous on `s`.
+int gki_launch_pack(const uint8_t *d_seq, int64_t n_bases, uint32_t *d_out, hipStream_t s) {
+    int64_t n_u32 = ceil_div(n_bases, 16);
+    if (n_u32 <= 0) return GKI_OK;
+    hipLaunchKernelGGL(k_pack_2bit, dim3(stream_grid(n_u32, 256)), dim3(256), 0, s, d_seq, n_bases, d_out, n_u32);
+    HIP_TRY(hipGetLastError());
+    return GKI_OK;
+}
+
+namespace {
+template <typename T>
+int upload(gki_graph *g, const T *h, int64_t n, const T **d_out) {
+    void *d = nullptr;
+    int64_t bytes = (int64_t)sizeof(T) * (n > 0 ? n : 1);
+    HIP_TRY(hipMalloc(&d, (size_t)bytes));
+    g->owned[g->n_owned++] = d;
+    if (n > 0) HIP_TRY(hipMemcpy(d, h, (size_t)(sizeof(T) * n), hipMemcpyHostToDevice));
+    *d_out = (const T *)d;
+    return GKI_OK;
+}
+
+int graph_create_common(gki_graph **out, int64_t n_nodes, const int32_t *h_node_size, const uint8_t *h_seq,
+                        const void *d_seq, bool seq_on_device, int64_t n_bases, const int64_t *h_edge_start, const int32_t *h_edges,
+                        const int64_t *h_rev_start, const int32_t *h_rev_edges, int64_t n_edges,
+                        const uint8_t *h_is_ref, const double *h_allele_freq, const int64_t *h_position_base) {
+    *out = nullptr;
+    if (n_nodes <= 0 || n_bases < 0 || n_edges < 0) return gki_set_error(GKI_ERR_BAD_ARG, "graph_create: bad sizes");
+    if (n_edges >= INT32_MAX) return gki_set_error(GKI_ERR_BAD_ARG, "graph_create: more than 2^31-1 edges");
+    gki_graph *g = new gki_graph();
+    memset(g, 0, sizeof(*g));
+    HIP_TRY(hipGetDevice(&g->device));
+    HIP_TRY(hipStreamCreate(&g->stream));
+    HIP_TRY(hipEventCreate(&g->ev_prep0));
+    HIP_TRY(hipEventCreate(&g->ev_prep1));
+    DevGraph &d = g->d;
+    d.n_nodes = n_nodes; d.n_bases = n_bases; d.n_words64 = ceil_div(n_bases, 64);
+
+    std::vector<int64_t> seq_start((size_t)n_nodes + 1);
+    std::vector<int32_t> nonempty;
+    nonempty.reserve((size_t)n_nodes);
+    seq_start[0] = 0;
+    for (int64_t n = 0; n < n_nodes; n++) {
+        if (h_node_size[n] < 0) { delete g; return gki_set_error(GKI_ERR_BAD_ARG, "negative node size"); }
+        seq_start[n + 1] = seq_start[n] + h_node_size[n];
+        if (h_node_size[n] > 0) nonempty.push_back((int32_t)n);
+    }
+    if (seq_start[n_nodes] != n_bases) { delete g; return gki_set_error(GKI_ERR_BAD_ARG, "sum(node_size) != n_bases"); }
+    d.n_nonempty = (int64_t)nonempty.size();
+
+    GKI_TRY(upload(g, h_node_size, n_nodes, &d.node_size));
+    GKI_TRY(upload(g, seq_start.data(), n_nodes + 1, &d.seq_start));
+    GKI_TRY(upload(g, h_edge_start, n_nodes + 1, &d.edge_start));
+    GKI_TRY(upload(g, h_edges, n_edges, &d.edges));
+    GKI_TRY(upload(g, h_rev_start, n_nodes + 1, &d.rev_start));
+    GKI_TRY(upload(g, h_rev_edges, n_edges, &d.rev_edges));
+    GKI_TRY(upload(g, h_is_ref, n_nodes, &d.is_ref));
+    GKI_TRY(upload(g, h_allele_freq, n_nodes, &d.allele_freq));
+    GKI_TRY(upload(g, h_position_base ? h_position_base : seq_start.data(), n_nodes, &d.pos_base));
+    GKI_TRY(upload(g, nonempty.data(), d.n_nonempty, &d.nonempty));
+    if (seq_on_device) {
+        d.seq = (const uint8_t *)d_seq;
+        g->owns_seq = false;
+    } else {
+        GKI_TRY(upload(g, h_seq, n_bases, &d.seq));
+        g->owns_seq = true;
+    }
+    // 2-bit sequence: ceil(n/32) words + 2 words of zero padding (gki_extract reads word w+1)
+    int64_t n_u64 = ceil_div(n_bases, 32) + 2;
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, (size_t)n_u64 * 8)); g->owned[g->n_owned++] = p; d.seq2 = (const uint64_t *)p;
+    HIP_TRY(hipMalloc(&p, (size_t)(d.n_words64 + 1) * 8)); g->owned[g->n_owned++] = p; d.start_mask = (const uint64_t *)p;
+    HIP_TRY(hipMalloc(&p, (size_t)(d.n_words64 + 2) * 4)); g->owned[g->n_owned++] = p; d.start_rank = (const uint32_t *)p;
+    *out = g;
+    return gki_graph_prepare(g);
+}
+}  // namespace
+
+extern "C" {
+
+int gki_graph_prepare(gki_graph *g) {
+    DevGraph &d = g->d;
+    hipStream_t s = g->stream;
+    int64_t n_u64 = ceil_div(d.n_bases, 32) + 2;
+    HIP_TRY(hipEventRecord(g->ev_prep0, s));
+    HIP_TRY(hipMemsetAsync((void *)d.seq2, 0, (size_t)n_u64 * 8, s));
+    GKI_TRY(gki_launch_pack(d.seq, d.n_bases, (uint32_t *)d.seq2, s));
+    HIP_TRY(hipMemsetAsync((void *)d.start_mask, 0, (size_t)(d.n_words64 + 1) * 8, s));
+    if (d.n_nonempty > 0) {
+        hipLaunchKernelGGL(k_start_mask, dim3(stream_grid(d.n_nonempty, 256)), dim3(256), 0, s, d.nonempty,
+                           d.n_nonempty, d.seq_start, (unsigned long long *)d.start_mask);
+        HIP_TRY(hipGetLastError());
+    }
+    if (d.n_words64 > 0) {
+        // rank = exclusive scan of per-word popcounts (counts staged in a scratch buffer)
+        void *cnt = nullptr, *tmp = nullptr;
+        int64_t tmp_bytes = gki_scan_tmp_bytes(d.n_words64);
+        HIP_TRY(hipMalloc(&cnt, (size_t)d.n_words64 * 4));
+        HIP_TRY(hipMalloc(&tmp, (size_t)tmp_bytes));
+        hipLaunchKernelGGL(k_popcount, dim3(stream_grid(d.n_words64, 256)), dim3(256), 0, s, d.start_mask,
+                           d.n_words64, (uint32_t *)cnt);
+        HIP_TRY(hipGetLastError());
+        int r = gki_scan_u32_to_u32((const uint32_t *)cnt, d.n_words64, (uint32_t *)d.start_rank, tmp, tmp_bytes, s);
+        HIP_TRY(hipEventRecord(g->ev_prep1, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipFree(cnt));
+        HIP_TRY(hipFree(tmp));
+        if (r != GKI_OK) return r;
+    } else {
+        HIP_TRY(hipEventRecord(g->ev_prep1, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return GKI_OK;
+}
+
+int gki_graph_create(gki_graph **out, int64_t n_nodes, const int32_t *h_node_size, const uint8_t *h_seq,
+                     int64_t n_bases, const int64_t *h_edge_start, const int32_t *h_edges,
+                     const int64_t *h_rev_start, const int32_t *h_rev_edges, int64_t n_edges,
+                     const uint8_t *h_is_ref, const double *h_allele_freq, const int64_t *h_position_base) {
+    return graph_create_common(out, n_nodes, h_node_size, h_seq, nullptr, false, n_bases, h_edge_start, h_edges, h_rev_start,
+                               h_rev_edges, n_edges, h_is_ref, h_allele_freq, h_position_base);
+}
+
+int gki_graph_create_dseq(gki_graph **out, int64_t n_nodes, const int32_t *h_node_size, const void *d_seq,
+                          int64_t n_bases, const int64_t *h_edge_start, const int32_t *h_edges,
+                          const int64_t *h_rev_start, const int32_t *h_rev_edges, int64_t n_edges,
+                          const uint8_t *h_is_ref, const double *h_allele_freq, const int64_t *h_position_base) {
+    if (!d_seq && n_bases > 0) return gki_set_error(GKI_ERR_BAD_ARG, "d_seq is NULL");
+    return graph_create_common(out, n_nodes, h_node_size, nullptr, d_seq, true, n_bases,
+                               h_edge_start, h_edges, h_rev_start, h_rev_edges, n_edges, h_is_ref, h_allele_freq,
+                               h_position_base);
+}
+
+int gki_graph_destroy(gki_graph *g) {
+    if (!g) return GKI_OK;
+    for (int i = 0; i < g->n_owned; i++) (void)hipFree(g->owned[i]);
+    (void)hipEventDestroy(g->ev_prep0);
+    (void)hipEventDestroy(g->ev_prep1);
+    (void)hipStreamDestroy(g->stream);
+    delete g;
+    return GKI_OK;
+}
+
+int64_t gki_graph_n_bases(const gki_graph *g) { return g->d.n_bases; }
+
+// critical_graph_paths.py:42-104, host walk along the linear reference.
+int gki_critical_paths(int64_t n_nodes, const int32_t *node_size, const int64_t *edge_start, const int32_t *edges,
+                       const int64_t *rev_start, const uint8_t *is_ref, const int32_t *chrom_start, int n_chrom,
+                       int k, uint32_t *out_nodes, uint16_t *out_offsets, int64_t *n_out) {
+    int64_t found = 0;
+    *n_out = 0;
+    for (int c = 0; c < n_chrom; c++) {
+        int64_t cur = chrom_start[c];
+        int64_t depth = 0, since_join = 0, steps = 0;
+        while (true) {
+            if (cur < 0 || cur >= n_nodes || ++steps > n_nodes + 1)
+                return gki_set_error(GKI_ERR_BAD_ARG, "critical paths: walk left the graph or found a cycle");
+            const int64_t indeg = rev_start[cur + 1] - rev_start[cur];
+            const bool was_open = depth > 1;
+            depth -= indeg;
+            if (was_open && depth == 0) since_join = 0;
+            const int64_t size = node_size[cur];
+            if (depth == 0 && size != 0 && since_join <= k && since_join + size >= k) {
+                const int64_t off = (int64_t)k - since_join - 1;
+                if (off < 0)
+                    return gki_set_error(GKI_ERR_BAD_ARG, "critical paths: node %lld is reached after exactly k bases "
+                                         "of single-edge chain; the reference raises here (uint16 offset -1)", (long long)cur);
+                out_nodes[found] = (uint32_t)cur;
+                out_offsets[found] = (uint16_t)off;
+                found++;
+            }
+            const int64_t e0 = edge_start[cur], e1 = edge_start[cur + 1];
+            depth += e1 - e0;
+            if (e1 == e0) break;
+            if (e1 - e0 == 1) {
+                since_join += size;
+                cur = edges[e0];
+            } else {
+                int64_t next = -1, n_ref = 0;
+                for (int64_t e = e0; e < e1; e++) if (is_ref[edges[e]]) { next = edges[e]; n_ref++; }
+                if (n_ref != 1)
+                    return gki_set_error(GKI_ERR_BAD_ARG, "critical paths: node %lld has %lld linear-ref successors "
+                                         "(the reference requires exactly one)", (long long)cur, (long long)n_ref);
+                cur = next;
+            }
+        }
+    }
+    *n_out = found;
+    return GKI_OK;
+}
+
+}  // extern "C"

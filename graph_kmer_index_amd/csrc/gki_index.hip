@@ -1,0 +1,461 @@
+// CollisionFreeKmerIndex on MI355X: bucket = kmer % modulo, records stably sorted by bucket,
+// bucket directory (first position + length), per-kmer frequencies, batched probe.
+//
+// Build = 4 kernels families:
+//   k_bucket_keys      bucket of every record (u64 % modulo) + identity permutation
+//   radix passes       stable LSD radix sort of (bucket, index) pairs, 8 bits per pass, only the
+//                      bits modulo-1 occupies; per pass: tile histograms -> scan -> ranked scatter with an
+//                      in-LDS reorder so every digit's run leaves the CU as one contiguous store
+//   k_gather_payload   the four payload columns permuted once by the sorted index
+//   k_directory / k_frequencies_*   bucket heads, lengths, distinct-ref_offset counts
+// Inside a bucket records keep their input order (stable sort), which is also what the oracle's
+// stable restatement produces, so the build is comparable element by element.
+#include "gki_common.h"
+
+namespace {
+
+constexpr int RB = 256;             // threads per block in the radix kernels
+constexpr int RI = 16;              // items per thread
+constexpr int RTILE = RB * RI;      // 4096 items per tile
+constexpr int RBINS = 256;
+
+__global__ __launch_bounds__(256) void k_bucket_keys(const uint64_t *__restrict__ kmers, int64_t n, uint64_t modulo,
+                                                     uint32_t *__restrict__ keys, uint32_t *__restrict__ idx) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        keys[i] = (uint32_t)(kmers[i] % modulo);       // collision_free_kmer_index.py:433
+        idx[i] = (uint32_t)i;
+    }
+}
+
+// histogram of one 8-bit digit per tile, stored bin-major: hist[bin * n_tiles + tile]
+__global__ __launch_bounds__(RB) void k_radix_hist(const uint32_t *__restrict__ keys, int64_t n, int shift,
+                                                   uint32_t *__restrict__ hist, int64_t n_tiles) {
+    __shared__ uint32_t h[RBINS];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RTILE;
+#pragma unroll
+    for (int r = 0; r < RI; r++) {
+        int64_t i = base + r * RB + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 0xFF], 1u);
+    }
+    __syncthreads();
+    hist[(int64_t)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// Stable scatter of one tile.  Element order inside a tile is (wave, round, lane): wave w owns the
+// contiguous slice [w*1024, (w+1)*1024) of the tile, round r its r-th group of 64.
+__global__ __launch_bounds__(RB) void k_radix_scatter(const uint32_t *__restrict__ keys_in,
+                                                      const uint32_t *__restrict__ vals_in, int64_t n, int shift,
+                                                      const uint32_t *__restrict__ offs /* scanned hist */,
+                                                      int64_t n_tiles, uint32_t *__restrict__ keys_out,
+                                                      uint32_t *__restrict__ vals_out) {
+    __shared__ uint32_t wave_cnt[4][RBINS];     // per wave, per digit: running count, then exclusive offset
+    __shared__ uint32_t digit_start[RBINS];     // start of each digit's run in the locally sorted tile
+    __shared__ uint32_t s_keys[RTILE];
+    __shared__ uint32_t s_vals[RTILE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4 * RBINS; i += RB) (&wave_cnt[0][0])[i] = 0;
+    __syncthreads();
+    const int64_t tile_base = (int64_t)blockIdx.x * RTILE;
+    const int64_t wave_base = tile_base + (int64_t)wave * (RTILE / 4);
+    uint32_t key[RI], val[RI], rank[RI];
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < RI; r++) {
+        const int64_t i = wave_base + r * 64 + lane;
+        const bool valid = i < n;
+        key[r] = valid ? keys_in[i] : 0xFFFFFFFFu;
+        val[r] = valid ? vals_in[i] : 0u;
+        const uint32_t d = valid ? ((key[r] >> shift) & 0xFF) : 0x100u;     // 0x100: matches no real digit
+        // lanes of this wave with the same digit (8 ballots) -> rank among them, group size
+        uint64_t same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint64_t bit = __ballot((d >> b) & 1u);
+            same &= ((d >> b) & 1u) ? bit : ~bit;
+        }
+        const uint32_t before = (uint32_t)__popcll(same & lt_mask);
+        uint32_t prev = 0;
+        if (valid) {
+            prev = wave_cnt[wave][d];                     // all lanes of the group read the same value ...
+        }
+        rank[r] = prev + before;
+        // ... then the group's first lane publishes the new count (rounds are sequential per wave)
+        if (valid && before == 0) wave_cnt[wave][d] = prev + (uint32_t)__popcll(same);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // per digit: exclusive offsets over waves, and the digit's start in the locally sorted tile
+    {
+        const int d = threadIdx.x;       // RB == RBINS
+        uint32_t c0 = wave_cnt[0][d], c1 = wave_cnt[1][d], c2 = wave_cnt[2][d], c3 = wave_cnt[3][d];
+        wave_cnt[0][d] = 0; wave_cnt[1][d] = c0; wave_cnt[2][d] = c0 + c1; wave_cnt[3][d] = c0 + c1 + c2;
+        const uint32_t tot = c0 + c1 + c2 + c3;
+        // exclusive scan of tot over the 256 digits (4 waves of 64)
+        uint32_t inc = tot;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            uint32_t o = __shfl_up(inc, s, 64);
+            if (lane >= s) inc += o;
+        }
+        __shared__ uint32_t wsum[4];
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        digit_start[d] = woff + inc - tot;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RI; r++) {
+        const int64_t i = wave_base + r * 64 + lane;
+        if (i < n) {
+            const uint32_t d = (key[r] >> shift) & 0xFF;
+            const uint32_t pos = digit_start[d] + wave_cnt[wave][d] + rank[r];
+            s_keys[pos] = key[r];
+            s_vals[pos] = val[r];
+        }
+    }
+    __syncthreads();
+    const int64_t n_here = (n - tile_base) < RTILE ? (n - tile_base) : RTILE;
+#pragma unroll
+    for (int r = 0; r < RI; r++) {
+        const int p = r * RB + threadIdx.x;
+        if (p < n_here) {
+            const uint32_t k = s_keys[p];
+            const uint32_t d = (k >> shift) & 0xFF;
+            const int64_t dst = (int64_t)offs[(int64_t)d * n_tiles + blockIdx.x] + (p - digit_start[d]);
+            keys_out[dst] = k;
+            vals_out[dst] = s_vals[p];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gather_payload(const uint32_t *__restrict__ idx, int64_t n,
+                                                        const uint64_t *__restrict__ kmers, const uint32_t *__restrict__ nodes,
+                                                        const uint64_t *__restrict__ refs, const float *__restrict__ af,
+                                                        uint64_t *__restrict__ o_kmers, uint32_t *__restrict__ o_nodes,
+                                                        uint64_t *__restrict__ o_refs, float *__restrict__ o_af) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t j = idx[i];
+        o_kmers[i] = kmers[j];
+        o_nodes[i] = nodes[j];
+        o_refs[i] = refs[j];
+        o_af[i] = af[j];
+    }
+}
+
+// bucket heads -> directory (collision_free_kmer_index.py:444-457).  A head lane walks to the end of
+// its run; runs are short except for highly repeated k-mers.
+__global__ __launch_bounds__(256) void k_directory(const uint32_t *__restrict__ keys, int64_t n,
+                                                   int32_t *__restrict__ hashes_to_index, uint32_t *__restrict__ n_kmers) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t b = keys[i];
+        if (i > 0 && keys[i - 1] == b) continue;
+        int64_t e = i + 1;
+        while (e < n && keys[e] == b) e++;
+        hashes_to_index[b] = (int32_t)i;
+        n_kmers[b] = (uint32_t)(e - i);
+    }
+}
+
+constexpr int SMALL_BUCKET = 24;
+
+// set_frequencies (collision_free_kmer_index.py:267-293): for every record, the number of distinct
+// ref_offsets among the records of its bucket that carry the same k-mer.  Buckets of up to
+// SMALL_BUCKET records: one lane per record.  Larger buckets are queued for k_frequencies_large.
+__global__ __launch_bounds__(256) void k_frequencies_small(const uint32_t *__restrict__ keys, int64_t n,
+                                                           const int32_t *__restrict__ hashes_to_index,
+                                                           const uint32_t *__restrict__ n_kmers,
+                                                           const uint64_t *__restrict__ kmers, const uint64_t *__restrict__ refs,
+                                                           uint16_t *__restrict__ freq, uint32_t *__restrict__ large_list,
+                                                           unsigned int *__restrict__ n_large) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t b = keys[i];
+        const int64_t s = hashes_to_index[b];
+        const int64_t m = n_kmers[b];
+        if (m > SMALL_BUCKET) {
+            if (i == s) large_list[atomicAdd(n_large, 1u)] = b;
+            continue;
+        }
+        const uint64_t km = kmers[i];
+        int count = 0;
+        for (int64_t j = s; j < s + m; j++) {
+            if (kmers[j] != km) continue;
+            const uint64_t r = refs[j];
+            bool dup = false;
+            for (int64_t c = s; c < j; c++) dup |= (kmers[c] == km && refs[c] == r);
+            count += dup ? 0 : 1;
+        }
+        freq[i] = (uint16_t)count;            // uint16 as in :270
+    }
+}
+
+struct Pair { uint64_t kmer, ref; };
+__device__ __forceinline__ bool pair_less(const Pair &a, const Pair &b) {
+    return a.kmer < b.kmer || (a.kmer == b.kmer && a.ref < b.ref);
+}
+
+// One block per large bucket: bitonic sort of its (kmer, ref_offset) pairs in a global scratch
+// slice (padded to a power of two with max sentinels), then distinct counting per k-mer.
+__global__ __launch_bounds__(256) void k_frequencies_large(const uint32_t *__restrict__ large_list, unsigned int n_large,
+                                                           const int32_t *__restrict__ hashes_to_index,
+                                                           const uint32_t *__restrict__ n_kmers,
+                                                           const uint64_t *__restrict__ kmers, const uint64_t *__restrict__ refs,
+                                                           const int64_t *__restrict__ scratch_start, Pair *__restrict__ scratch,
+                                                           uint16_t *__restrict__ freq) {
+    for (unsigned int li = blockIdx.x; li < n_large; li += gridDim.x) {
+        const uint32_t b = large_list[li];
+        const int64_t s = hashes_to_index[b];
+        const int64_t m = n_kmers[b];
+        Pair *p = scratch + scratch_start[li];
+        int64_t cap = 1;
+        while (cap < m) cap <<= 1;
+        for (int64_t i = threadIdx.x; i < cap; i += blockDim.x) {
+            Pair v;
+            if (i < m) { v.kmer = kmers[s + i]; v.ref = refs[s + i]; } else { v.kmer = ~0ull; v.ref = ~0ull; }
+            p[i] = v;
+        }
+        __syncthreads();
+        for (int64_t size = 2; size <= cap; size <<= 1) {
+            for (int64_t str = size >> 1; str > 0; str >>= 1) {
+                for (int64_t t = threadIdx.x; t < (cap >> 1); t += blockDim.x) {
+                    const int64_t lo = ((t / str) * (str << 1)) + (t % str);
+                    const int64_t hi = lo + str;
+                    const bool up = ((lo & size) == 0);
+                    Pair a = p[lo], c = p[hi];
+                    if (pair_less(c, a) == up) { p[lo] = c; p[hi] = a; }
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
+        }
+        // every record: distinct refs among pairs with its kmer = (first position of kmer .. last), counting ref changes
+        for (int64_t i = threadIdx.x; i < m; i += blockDim.x) {
+            const uint64_t km = kmers[s + i];
+            int64_t lo = 0, hi = m;                       // first pair with kmer >= km
+            while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (p[mid].kmer < km) lo = mid + 1; else hi = mid; }
+            int64_t count = 0;
+            uint64_t prev = 0;
+            for (int64_t j = lo; j < m && p[j].kmer == km; j++) {
+                if (j == lo || p[j].ref != prev) count++;
+                prev = p[j].ref;
+            }
+            freq[s + i] = (uint16_t)count;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_large_sizes(const uint32_t *__restrict__ large_list, unsigned int n_large,
+                                                     const uint32_t *__restrict__ n_kmers, uint32_t *__restrict__ sizes) {
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_large; i += gridDim.x * blockDim.x) {
+        uint32_t m = n_kmers[large_list[i]], cap = 1;
+        while (cap < m) cap <<= 1;
+        sizes[i] = cap;
+    }
+}
+
+// ------------------------------------------------------------------------------------ probe
+struct IndexDev {
+    const int32_t *h2i; const uint32_t *nk; const uint64_t *kmers; const uint32_t *nodes; const uint64_t *refs;
+    const uint16_t *freq; const float *af; uint64_t modulo;
+};
+
+// CollisionFreeKmerIndex.get (collision_free_kmer_index.py:303-315) for one query per lane.
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_lookup(IndexDev ix, const uint64_t *__restrict__ queries, int64_t q, int64_t max_hits,
+                                                uint32_t *__restrict__ cnt, const int64_t *__restrict__ hit_start,
+                                                uint32_t *__restrict__ o_nodes, uint64_t *__restrict__ o_refs,
+                                                int64_t *__restrict__ o_query, uint16_t *__restrict__ o_freq,
+                                                float *__restrict__ o_af, int64_t *__restrict__ o_pos) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += stride) {
+        const uint64_t km = queries[i];
+        const uint64_t b = km % ix.modulo;                            // :304
+        const int64_t s = ix.h2i[b];                                  // :305
+        const int64_t m = ix.nk[b];                                   // :306
+        if (!EMIT) {
+            uint32_t c = 0;
+            bool first = true, too_frequent = false;
+            for (int64_t j = s; j < s + m; j++) {
+                if (ix.kmers[j] != km) continue;                      // :309
+                if (first) { too_frequent = ix.freq && (int64_t)ix.freq[j] > max_hits; first = false; }   // :312
+                c++;
+            }
+            cnt[i] = too_frequent ? 0u : c;
+        } else {
+            int64_t o = hit_start[i];
+            if (hit_start[i + 1] == o) continue;
+            for (int64_t j = s; j < s + m; j++) {
+                if (ix.kmers[j] != km) continue;
+                if (o_nodes) o_nodes[o] = ix.nodes[j];                // :315
+                if (o_refs) o_refs[o] = ix.refs[j];
+                if (o_query) o_query[o] = i;                          // read_offsets = query index (:365)
+                if (o_freq) o_freq[o] = ix.freq ? ix.freq[j] : (uint16_t)0;
+                if (o_af) o_af[o] = ix.af[j];
+                if (o_pos) o_pos[o] = j;
+                o++;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gki_index_build(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
+                    uint64_t modulo, int skip_frequencies, void *d_hashes_to_index, void *d_n_kmers, void *d_out_kmers,
+                    void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32, void *d_out_frequencies,
+                    void *d_out_permutation) {
+    if (modulo == 0 || modulo > 0xFFFFFFFFull) return gki_set_error(GKI_ERR_BAD_ARG, "modulo must be in 1..2^32-1");
+    if (n >= (1ll << 31))
+        return gki_set_error(GKI_ERR_OVERFLOW, "%lld records: the reference's directory is int32 "
+                             "(collision_free_kmer_index.py:453); shard the build", (long long)n);
+    hipStream_t s = 0;
+    HIP_TRY(hipMemsetAsync(d_hashes_to_index, 0, (size_t)modulo * 4, s));          // :453
+    HIP_TRY(hipMemsetAsync(d_n_kmers, 0, (size_t)modulo * 4, s));                  // :456
+    if (n <= 0) { HIP_TRY(hipStreamSynchronize(s)); return GKI_OK; }
+    HIP_TRY(hipMemsetAsync(d_out_frequencies, 0, (size_t)n * 2, s));               // :270
+    const int64_t n_tiles = ceil_div(n, RTILE);
+    uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *hist = nullptr, *offs = nullptr;
+    void *tmp = nullptr;
+    const int64_t hist_n = (int64_t)RBINS * n_tiles;
+    const int64_t tmp_bytes = gki_scan_tmp_bytes(hist_n);
+    int rc = GKI_OK;
+#define CLEANUP_RETURN(code) do { rc = (code); goto done; } while (0)
+#define HIP_G(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = gki_set_error(GKI_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); goto done; } } while (0)
+    {
+        for (int i = 0; i < 2; i++) {
+            HIP_G(hipMalloc((void **)&keys[i], (size_t)n * 4));
+            HIP_G(hipMalloc((void **)&vals[i], (size_t)n * 4));
+        }
+        HIP_G(hipMalloc((void **)&hist, (size_t)hist_n * 4));
+        HIP_G(hipMalloc((void **)&offs, (size_t)(hist_n + 1) * 4));
+        HIP_G(hipMalloc(&tmp, (size_t)tmp_bytes));
+        hipLaunchKernelGGL(k_bucket_keys, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const uint64_t *)d_kmers, n, modulo,
+                           keys[0], vals[0]);
+        HIP_G(hipGetLastError());
+        int bits = 0;
+        while (bits < 32 && ((modulo - 1) >> bits) != 0) bits++;
+        int cur = 0;
+        for (int shift = 0; shift < bits; shift += 8) {
+            hipLaunchKernelGGL(k_radix_hist, dim3((unsigned)n_tiles), dim3(RB), 0, s, keys[cur], n, shift, hist, n_tiles);
+            HIP_G(hipGetLastError());
+            int r = gki_scan_u32_to_u32(hist, hist_n, offs, tmp, tmp_bytes, s);
+            if (r != GKI_OK) CLEANUP_RETURN(r);
+            hipLaunchKernelGGL(k_radix_scatter, dim3((unsigned)n_tiles), dim3(RB), 0, s, keys[cur], vals[cur], n, shift, offs,
+                               n_tiles, keys[1 - cur], vals[1 - cur]);
+            HIP_G(hipGetLastError());
+            cur = 1 - cur;
+        }
+        hipLaunchKernelGGL(k_gather_payload, dim3(stream_grid(n, 256)), dim3(256), 0, s, vals[cur], n, (const uint64_t *)d_kmers,
+                           (const uint32_t *)d_nodes, (const uint64_t *)d_ref_offsets, (const float *)d_af32,
+                           (uint64_t *)d_out_kmers, (uint32_t *)d_out_nodes, (uint64_t *)d_out_ref_offsets, (float *)d_out_af32);
+        HIP_G(hipGetLastError());
+        if (d_out_permutation) HIP_G(hipMemcpyAsync(d_out_permutation, vals[cur], (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_directory, dim3(stream_grid(n, 256)), dim3(256), 0, s, keys[cur], n, (int32_t *)d_hashes_to_index,
+                           (uint32_t *)d_n_kmers);
+        HIP_G(hipGetLastError());
+        if (!skip_frequencies) {
+            // large-bucket work list: at most n / SMALL_BUCKET entries; reuse the spare key/val buffers
+            uint32_t *large_list = keys[1 - cur];
+            unsigned int *n_large_d = (unsigned int *)hist;
+            HIP_G(hipMemsetAsync(n_large_d, 0, 4, s));
+            hipLaunchKernelGGL(k_frequencies_small, dim3(stream_grid(n, 256)), dim3(256), 0, s, keys[cur], n,
+                               (const int32_t *)d_hashes_to_index, (const uint32_t *)d_n_kmers, (const uint64_t *)d_out_kmers,
+                               (const uint64_t *)d_out_ref_offsets, (uint16_t *)d_out_frequencies, large_list, n_large_d);
+            HIP_G(hipGetLastError());
+            unsigned int n_large = 0;
+            HIP_G(hipMemcpyAsync(&n_large, n_large_d, 4, hipMemcpyDeviceToHost, s));
+            HIP_G(hipStreamSynchronize(s));
+            if (n_large > 0) {
+                uint32_t *sizes = vals[1 - cur];
+                int64_t *starts = nullptr;
+                Pair *scratch = nullptr;
+                hipLaunchKernelGGL(k_large_sizes, dim3(stream_grid(n_large, 256)), dim3(256), 0, s, large_list, n_large,
+                                   (const uint32_t *)d_n_kmers, sizes);
+                HIP_G(hipGetLastError());
+                HIP_G(hipMalloc((void **)&starts, ((size_t)n_large + 1) * 8));
+                void *tmp2 = nullptr;
+                int64_t tmp2_bytes = gki_scan_tmp_bytes(n_large);
+                hipError_t e2 = hipMalloc(&tmp2, (size_t)tmp2_bytes);
+                int r = e2 == hipSuccess ? gki_scan_u32_to_i64(sizes, n_large, starts, tmp2, tmp2_bytes, s) : GKI_ERR_HIP;
+                int64_t total = 0;
+                if (r == GKI_OK && hipMemcpy(&total, starts + n_large, 8, hipMemcpyDeviceToHost) != hipSuccess) r = GKI_ERR_HIP;
+                if (r == GKI_OK && hipMalloc((void **)&scratch, (size_t)total * sizeof(Pair)) != hipSuccess) r = GKI_ERR_HIP;
+                if (r == GKI_OK) {
+                    unsigned grid = n_large < 2048 ? n_large : 2048;
+                    hipLaunchKernelGGL(k_frequencies_large, dim3(grid), dim3(256), 0, s, large_list, n_large,
+                                       (const int32_t *)d_hashes_to_index, (const uint32_t *)d_n_kmers,
+                                       (const uint64_t *)d_out_kmers, (const uint64_t *)d_out_ref_offsets, starts, scratch,
+                                       (uint16_t *)d_out_frequencies);
+                    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) r = GKI_ERR_HIP;
+                }
+                (void)hipFree(starts); (void)hipFree(tmp2); (void)hipFree(scratch);
+                if (r != GKI_OK) CLEANUP_RETURN(gki_set_error(r, "large-bucket frequency pass failed"));
+            }
+        }
+        HIP_G(hipStreamSynchronize(s));
+    }
+done:
+    for (int i = 0; i < 2; i++) { (void)hipFree(keys[i]); (void)hipFree(vals[i]); }
+    (void)hipFree(hist); (void)hipFree(offs); (void)hipFree(tmp);
+#undef HIP_G
+#undef CLEANUP_RETURN
+    return rc;
+}
+
+static IndexDev view_of(const gki_index_view *ix) {
+    IndexDev d;
+    d.h2i = (const int32_t *)ix->d_hashes_to_index; d.nk = (const uint32_t *)ix->d_n_kmers;
+    d.kmers = (const uint64_t *)ix->d_kmers; d.nodes = (const uint32_t *)ix->d_nodes;
+    d.refs = (const uint64_t *)ix->d_ref_offsets; d.freq = (const uint16_t *)ix->d_frequencies;
+    d.af = (const float *)ix->d_af32; d.modulo = ix->modulo;
+    return d;
+}
+
+int gki_index_lookup_count(const gki_index_view *ix, const void *d_queries, int64_t q, int64_t max_hits, void *d_hit_start,
+                           int64_t *n_hits) {
+    *n_hits = 0;
+    if (ix->modulo == 0) return gki_set_error(GKI_ERR_BAD_ARG, "modulo is 0");
+    if (q <= 0) { HIP_TRY(hipMemset(d_hit_start, 0, 8)); return GKI_OK; }
+    uint32_t *cnt = nullptr;
+    void *tmp = nullptr;
+    int64_t tmp_bytes = gki_scan_tmp_bytes(q);
+    HIP_TRY(hipMalloc((void **)&cnt, (size_t)q * 4));
+    HIP_TRY(hipMalloc(&tmp, (size_t)tmp_bytes));
+    hipLaunchKernelGGL(k_lookup<false>, dim3(stream_grid(q, 256)), dim3(256), 0, 0, view_of(ix), (const uint64_t *)d_queries, q,
+                       max_hits, cnt, (const int64_t *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr, (int64_t *)nullptr,
+                       (uint16_t *)nullptr, (float *)nullptr, (int64_t *)nullptr);
+    int rc = hipGetLastError() == hipSuccess ? GKI_OK : gki_set_error(GKI_ERR_HIP, "k_lookup launch failed");
+    if (rc == GKI_OK) rc = gki_scan_u32_to_i64(cnt, q, (int64_t *)d_hit_start, tmp, tmp_bytes, 0);
+    int64_t total = 0;
+    hipError_t e = hipMemcpy(&total, (const int64_t *)d_hit_start + q, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(cnt); (void)hipFree(tmp);
+    if (rc != GKI_OK) return rc;
+    HIP_TRY(e);
+    *n_hits = total;
+    return GKI_OK;
+}
+
+int gki_index_lookup_emit(const gki_index_view *ix, const void *d_queries, int64_t q, int64_t max_hits, const void *d_hit_start,
+                          void *d_hit_nodes, void *d_hit_ref_offsets, void *d_hit_query, void *d_hit_frequencies,
+                          void *d_hit_af32, void *d_hit_position) {
+    if (q <= 0) return GKI_OK;
+    hipLaunchKernelGGL(k_lookup<true>, dim3(stream_grid(q, 256)), dim3(256), 0, 0, view_of(ix), (const uint64_t *)d_queries, q,
+                       max_hits, (uint32_t *)nullptr, (const int64_t *)d_hit_start, (uint32_t *)d_hit_nodes,
+                       (uint64_t *)d_hit_ref_offsets, (int64_t *)d_hit_query, (uint16_t *)d_hit_frequencies, (float *)d_hit_af32,
+                       (int64_t *)d_hit_position);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(0));
+    return GKI_OK;
+}
+
+}  // extern "C"

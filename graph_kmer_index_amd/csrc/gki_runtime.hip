@@ -1,0 +1,171 @@
+// Runtime plumbing of libgki_hip.so: errors, memory, and the exclusive-scan primitive.
+#include "gki_common.h"
+#include <stdarg.h>
+
+thread_local char gki_err_buf[512] = "";
+
+int gki_set_error(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(gki_err_buf, sizeof(gki_err_buf), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" {
+
+const char *gki_last_error(void) { return gki_err_buf; }
+
+int gki_device_count(int *count) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *count = 0; return gki_set_error(GKI_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = c;
+    return GKI_OK;
+}
+
+int gki_set_device(int device) { HIP_TRY(hipSetDevice(device)); return GKI_OK; }
+
+int gki_malloc(void **d_ptr, int64_t bytes) {
+    *d_ptr = nullptr;
+    if (bytes < 0) return gki_set_error(GKI_ERR_BAD_ARG, "gki_malloc: negative size");
+    if (bytes == 0) bytes = 16;
+    HIP_TRY(hipMalloc(d_ptr, (size_t)bytes));
+    return GKI_OK;
+}
+
+int gki_free(void *d_ptr) { if (d_ptr) HIP_TRY(hipFree(d_ptr)); return GKI_OK; }
+
+int gki_memcpy_h2d(void *d_dst, const void *h_src, int64_t bytes) {
+    if (bytes > 0) HIP_TRY(hipMemcpy(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice));
+    return GKI_OK;
+}
+
+int gki_memcpy_d2h(void *h_dst, const void *d_src, int64_t bytes) {
+    if (bytes > 0) HIP_TRY(hipMemcpy(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return GKI_OK;
+}
+
+int gki_memset(void *d_dst, int value, int64_t bytes) {
+    if (bytes > 0) HIP_TRY(hipMemset(d_dst, value, (size_t)bytes));
+    return GKI_OK;
+}
+
+int gki_device_synchronize(void) { HIP_TRY(hipDeviceSynchronize()); return GKI_OK; }
+
+int gki_mem_info(int64_t *free_bytes, int64_t *total_bytes) {
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    *free_bytes = (int64_t)f; *total_bytes = (int64_t)t;
+    return GKI_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------ scan
+namespace {
+constexpr int SB = 256;        // threads per block
+constexpr int SI = 8;          // items per thread
+constexpr int STILE = SB * SI; // 2048 items per block
+
+template <typename TAcc>
+__device__ __forceinline__ TAcc block_exclusive(TAcc v, TAcc *total, TAcc *lds /* [SB/64 + 1] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    TAcc inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        TAcc o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    TAcc wave_off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SB / 64; w++) {
+        TAcc s = lds[w];
+        if (w < wave) wave_off += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return wave_off + inc - v;
+}
+
+template <typename TIn, typename TAcc>
+__global__ __launch_bounds__(SB) void k_block_sums(const TIn *__restrict__ in, int64_t n, TAcc *__restrict__ sums) {
+    __shared__ TAcc lds[SB / 64 + 1];
+    int64_t base = (int64_t)blockIdx.x * STILE + (int64_t)threadIdx.x * SI;
+    TAcc s = 0;
+#pragma unroll
+    for (int i = 0; i < SI; i++) if (base + i < n) s += (TAcc)in[base + i];
+    TAcc tot;
+    block_exclusive<TAcc>(s, &tot, lds);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+// exclusive scan with per-block offset; writes out[i] for i < n and out[n] = grand total.
+template <typename TIn, typename TAcc, typename TOut>
+__global__ __launch_bounds__(SB) void k_block_scan(const TIn *__restrict__ in, int64_t n,
+                                                   const TAcc *__restrict__ block_off, TOut *__restrict__ out) {
+    __shared__ TAcc lds[SB / 64 + 1];
+    int64_t base = (int64_t)blockIdx.x * STILE + (int64_t)threadIdx.x * SI;
+    TAcc v[SI];
+    TAcc s = 0;
+#pragma unroll
+    for (int i = 0; i < SI; i++) { v[i] = (base + i < n) ? (TAcc)in[base + i] : (TAcc)0; s += v[i]; }
+    TAcc tot;
+    TAcc ex = block_exclusive<TAcc>(s, &tot, lds);
+    ex += block_off ? block_off[blockIdx.x] : (TAcc)0;
+#pragma unroll
+    for (int i = 0; i < SI; i++) {
+        if (base + i < n) out[base + i] = (TOut)ex;
+        ex += v[i];
+        if (base + i == n - 1) out[n] = (TOut)ex;
+    }
+}
+
+template <typename TIn, typename TAcc, typename TOut>
+int scan_impl(const TIn *d_in, int64_t n, TOut *d_out, void *d_tmp, int64_t tmp_bytes, hipStream_t s) {
+    if (n <= 0) {
+        if (n == 0) HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(TOut), s));
+        return GKI_OK;
+    }
+    int64_t nb = ceil_div(n, STILE);
+    if (nb == 1) {
+        hipLaunchKernelGGL((k_block_scan<TIn, TAcc, TOut>), dim3(1), dim3(SB), 0, s, d_in, n, (const TAcc *)nullptr, d_out);
+        HIP_TRY(hipGetLastError());
+        return GKI_OK;
+    }
+    // tmp: sums[nb] then scanned[nb+1], then the next level's tmp
+    int64_t need = (int64_t)sizeof(TAcc) * (2 * nb + 1);
+    if (tmp_bytes < need) return gki_set_error(GKI_ERR_BAD_ARG, "scan: tmp too small (%lld < %lld)", (long long)tmp_bytes, (long long)need);
+    TAcc *sums = (TAcc *)d_tmp;
+    TAcc *scanned = sums + nb;
+    hipLaunchKernelGGL((k_block_sums<TIn, TAcc>), dim3((unsigned)nb), dim3(SB), 0, s, d_in, n, sums);
+    HIP_TRY(hipGetLastError());
+    GKI_TRY((scan_impl<TAcc, TAcc, TAcc>(sums, nb, scanned, (char *)d_tmp + need, tmp_bytes - need, s)));
+    hipLaunchKernelGGL((k_block_scan<TIn, TAcc, TOut>), dim3((unsigned)nb), dim3(SB), 0, s, d_in, n, (const TAcc *)scanned, d_out);
+    HIP_TRY(hipGetLastError());
+    return GKI_OK;
+}
+}  // namespace
+
+int64_t gki_scan_tmp_bytes(int64_t n) {
+    int64_t total = 0;
+    while (n > STILE) {
+        int64_t nb = ceil_div(n, STILE);
+        total += 8 * (2 * nb + 1);
+        n = nb;
+    }
+    return total + 64;
+}
+
+int gki_scan_u32_to_i64(const uint32_t *d_in, int64_t n, int64_t *d_out, void *d_tmp, int64_t tmp_bytes, hipStream_t s) {
+    return scan_impl<uint32_t, int64_t, int64_t>(d_in, n, d_out, d_tmp, tmp_bytes, s);
+}
+int gki_scan_i32_to_i64(const int32_t *d_in, int64_t n, int64_t *d_out, void *d_tmp, int64_t tmp_bytes, hipStream_t s) {
+    return scan_impl<int32_t, int64_t, int64_t>(d_in, n, d_out, d_tmp, tmp_bytes, s);
+}
+int gki_scan_u32_to_u32(const uint32_t *d_in, int64_t n, uint32_t *d_out, void *d_tmp, int64_t tmp_bytes, hipStream_t s) {
+    return scan_impl<uint32_t, int64_t, uint32_t>(d_in, n, d_out, d_tmp, tmp_bytes, s);
+}

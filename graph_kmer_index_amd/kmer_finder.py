@@ -1,0 +1,272 @@
+"""DenseKmerFinder with the reference's constructor and methods (kmer_finder.py:37-244), running
+on MI355X through libgki_hip.so.
+
+What `find()` computes is the reference's record multiset: for every base
+position and every backward k-base window with at most `max_variant_nodes` non-linear-ref nodes,
+one record per distinct window node.  Record ORDER differs from the reference's depth-first order
+on branching graphs (it is by end position); on linear graphs it is identical.
+
+Graphs outside the class where that statement was verified against the reference raise instead of
+silently diverging:
+  * a node none of whose predecessors is a linear-ref(-dummy) node      -> NotImplementedError
+  * a chromosome other than the first starting with a node shorter than k -> NotImplementedError
+  * a critical point (N, c) with 3 <= c < k-1 on a node longer than 2k+3: the reference itself
+    emits meaningless hashes there (SURVEY.md 8a' E1 + bulk path)        -> ValueError
+"""
+import ctypes as C
+import logging
+import numpy as np
+
+from . import _lib
+from .critical_graph_paths import CriticalGraphPaths
+from .device_graph import DeviceGraph
+from .flat_kmers import FlatKmers, FlatKmers2, DeviceFlatKmers
+from .graph import GraphArrays
+
+
+def update_hash(current_base, current_hash, first_base, k, only_add=False):
+    """kmer_finder.py:15-34 (kept for API parity; the kernels read hashes straight out of the 2-bit
+    sequence instead of rolling them)."""
+    current_hash, current_base, first_base = int(current_hash), int(current_base), int(first_base)
+    if not isinstance(only_add, bool):
+        return current_hash + 4 ** only_add * current_base
+    return (current_hash - first_base) // 4 + current_base * 4 ** (k - 1)
+
+
+def check_supported_graph(g, k):
+    indeg = np.diff(g.rev_start)
+    has_pred = indeg > 0
+    if len(g.rev_edges):
+        ref_pred = np.add.reduceat(g.is_ref[g.rev_edges].astype(np.int64),
+                                   np.minimum(g.rev_start[:-1], len(g.rev_edges) - 1))
+        ref_pred[~has_pred] = 0
+        bad = np.nonzero(has_pred & (ref_pred == 0))[0]
+        if len(bad):
+            raise NotImplementedError(
+                "node %d has predecessors but none of them is a linear-ref(-dummy) node; the order-free "
+                "form of the variant limit (kmer_finder.py:391-403) is only established for graphs where "
+                "every node has a linear-ref predecessor" % int(bad[0]))
+    starts = list(g.chromosome_start_nodes.values())
+    for s in starts:
+        if s != g.first_node and g.node_size[s] < k:
+            raise NotImplementedError("chromosome start node %d is shorter than k" % s)
+
+
+def lossy_table(g, k, crit_nodes, crit_offsets):
+    """uint16[n_nodes] of critical offsets c with 0 < c < k-1 (SURVEY.md 8a' E1), or None."""
+    c = np.asarray(crit_offsets).astype(np.int64)
+    n = np.asarray(crit_nodes).astype(np.int64)
+    sel = (c > 0) & (c < k - 1)
+    if not np.any(sel):
+        return None
+    undefined = sel & (c >= 3) & (g.node_size[n] > 2 * k + 3)
+    if np.any(undefined):
+        raise ValueError(
+            "critical point (%d, %d): a single-edge chain of %d bases precedes a node longer than 2k+3; the "
+            "reference emits meaningless hashes for this graph (kmer_finder.py:272-273 enters the bulk path with "
+            "fewer than k bases), so there is nothing to be bit-exact with"
+            % (int(n[undefined][0]), int(c[undefined][0]), k - 1 - int(c[undefined][0])))
+    table = np.full(g.n_nodes, 0xFFFF, dtype=np.uint16)
+    table[n[sel]] = c[sel]
+    return table
+
+
+class DenseKmerFinder:
+    """Finds all possible kmers in graph (kmer_finder.py:37-47 signature)."""
+
+    def __init__(self, graph, k, critical_graph_paths=None, position_id=None, only_save_one_node_per_kmer=False,
+                 max_variant_nodes=4, only_store_variant_nodes=False, start_at_critical_path_number=None,
+                 stop_at_critical_path_number=None, whitelist=None, only_store_nodes=None, only_follow_nodes=None):
+        self._graph = graph
+        self._arrays = GraphArrays.from_obgraph(graph)
+        self._k = int(k)
+        if not 1 <= self._k <= 31:
+            raise ValueError("k must be in 1..31")
+        self._only_save_one_node_per_kmer = bool(only_save_one_node_per_kmer)
+        self._max_variant_nodes = int(max_variant_nodes)
+        if only_store_variant_nodes:
+            raise NotImplementedError("only_store_variant_nodes is not usable in the reference either "
+                                      "(kmer_finder.py:75-76 asserts on an undefined name)")
+        self._critical_graph_paths = critical_graph_paths
+        self._position_id = position_id
+        self._start_at_critical_path_number = start_at_critical_path_number
+        self._stop_at_critical_path_number = stop_at_critical_path_number
+        self._whitelist = whitelist
+        self._only_store_nodes = only_store_nodes
+        if only_follow_nodes is not None:
+            raise NotImplementedError("only_follow_nodes (forced traversal, kmer_finder.py:386-388) is not "
+                                      "implemented on the device path")
+        self._cols = None          # host columns after find()
+        self._device = None
+        self._finder = None
+        self.last_timings = {}
+
+    # ------------------------------------------------------------------ device plumbing
+    def _device_graph(self):
+        if self._device is None:
+            pid = self._position_id
+            if pid is None:
+                self._device = DeviceGraph.of(self._arrays)
+            else:
+                g = self._arrays
+                base = np.asarray(pid.get(np.arange(g.n_nodes), np.zeros(g.n_nodes, dtype=np.int64))).astype(np.int64)
+                self._device = DeviceGraph(g, position_base=base)
+        return self._device
+
+    def _finder_handle(self):
+        if self._finder is None:
+            h = C.c_void_p()
+            _lib.check(_lib.load().gki_finder_create(self._device_graph().handle, C.byref(h)))
+            self._finder = h
+        return self._finder
+
+    def close(self):
+        if self._finder is not None:
+            _lib.load().gki_finder_destroy(self._finder)
+            self._finder = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _params(self):
+        g, k = self._arrays, self._k
+        check_supported_graph(g, k)
+        if self._critical_graph_paths is None:
+            logging.info("Making critical graph paths since it's not specified.")
+            self._critical_graph_paths = CriticalGraphPaths.from_graph(g, k)
+        cp = self._critical_graph_paths
+        crit_nodes = np.asarray(cp.nodes).astype(np.int64)
+        crit_offsets = np.asarray(cp.offsets).astype(np.int64)
+        lossy = lossy_table(g, k, crit_nodes, crit_offsets)
+        start_at, stop_at = self._start_at_critical_path_number, self._stop_at_critical_path_number
+        node_begin, off_begin, node_end, off_end = 0, 0, g.n_nodes, 0
+        n_crit = len(crit_nodes)
+        chunked = False
+        if start_at is not None and start_at > 0:                     # kmer_finder.py:204-205
+            chunked = True
+            if start_at >= n_crit:
+                node_begin, off_begin = g.n_nodes, 0                 # nothing left to start from
+            else:
+                node_begin, off_begin = int(crit_nodes[start_at]), int(crit_offsets[start_at])
+        if stop_at is not None and stop_at < n_crit:                  # :193-194
+            if not (start_at is not None and start_at > stop_at):     # stop node already behind us: never met (:220)
+                chunked = True
+                node_end, off_end = int(crit_nodes[stop_at]), int(crit_offsets[stop_at])
+        if chunked and len(g.edges):
+            src = np.repeat(np.arange(g.n_nodes), np.diff(g.edge_start))
+            if np.any(g.edges <= src):
+                raise NotImplementedError("chunked find() needs node ids that increase along every edge")
+        p = _lib.FindParams(k, self._max_variant_nodes, int(self._only_save_one_node_per_kmer), 0,
+                            node_begin, off_begin, node_end, off_end, _lib.hptr(lossy))
+        p._keep = lossy
+        if node_begin >= g.n_nodes:
+            return None
+        return p
+
+    def _count(self):
+        p = self._params()
+        if p is None:
+            return 0
+        n = C.c_int64(0)
+        _lib.check(_lib.load().gki_finder_count(self._finder_handle(), C.byref(p), C.byref(n)))
+        return n.value
+
+    # ------------------------------------------------------------------ reference API
+    def find(self):
+        """kmer_finder.py:179-244."""
+        lib = _lib.load()
+        n = self._count()
+        dt = [np.int64, np.int32, np.int16, np.int32, np.float64]
+        if n == 0:
+            cols = [np.zeros(0, dtype=d) for d in dt]
+        else:
+            bufs = [_lib.DeviceArray(n, d) for d in dt]
+            _lib.check(lib.gki_finder_emit_v2(self._finder_handle(), *[b.ptr for b in bufs]))
+            _lib.check(lib.gki_finder_synchronize(self._finder_handle()))
+            cols = [b.to_host() for b in bufs]
+            for b in bufs:
+                b.free()
+        kmers, start_nodes, start_offsets, nodes, af = cols
+        keep = None
+        if self._whitelist is not None:                                # kmer_finder.py:130-132, 362-365
+            wl = np.fromiter((int(x) for x in self._whitelist), dtype=np.int64)
+            keep = np.isin(kmers, wl)
+        if self._only_store_nodes is not None:                         # :153 (the bulk path :370-374 ignores it)
+            g, k = self._arrays, self._k
+            osn = np.fromiter((int(x) for x in self._only_store_nodes), dtype=np.int64)
+            size = g.node_size[start_nodes]
+            bulk = (nodes == start_nodes) & (start_offsets >= k + 2) & (start_offsets <= size - 2) & (size > 2 * k + 3)
+            sel = np.isin(nodes, osn) | bulk
+            keep = sel if keep is None else keep & sel
+        if keep is not None:
+            kmers, start_nodes, start_offsets, nodes, af = (c[keep] for c in (kmers, start_nodes, start_offsets, nodes, af))
+        self._cols = dict(kmers=kmers, start_nodes=start_nodes, start_offsets=start_offsets, nodes=nodes, af=af)
+
+    def find_flat_on_device(self, out=None):
+        """find() + get_flat_kmers(v="1") + FlatKmers.from_multiple_flat_kmers dtypes, columns left in
+        HBM (the CLI `index` path, command_line_interface.py:559-614).  Returns DeviceFlatKmers."""
+        if self._whitelist is not None or self._only_store_nodes is not None:
+            raise NotImplementedError("whitelist / only_store_nodes filters are applied by find() on the host")
+        n = self._count()
+        if out is None or out.hashes.n < n:
+            out = DeviceFlatKmers.allocate(n)
+        out.n = n
+        if n:
+            _lib.check(_lib.load().gki_finder_emit_flat(self._finder_handle(), out.hashes.ptr, out.nodes.ptr,
+                                                        out.ref_offsets.ptr, out.allele_frequencies.ptr))
+        return out
+
+    def synchronize(self):
+        _lib.check(_lib.load().gki_finder_synchronize(self._finder_handle()))
+
+    def kernel_ms(self, which):
+        ms = C.c_float(0)
+        _lib.check(_lib.load().gki_finder_kernel_ms(self._finder_handle(), which, C.byref(ms)))
+        return ms.value
+
+    def interior_records(self):
+        return _lib.load().gki_finder_interior_records(self._finder_handle())
+
+    def find_only_kmers_starting_at_position(self, node, offset):
+        raise NotImplementedError("find_only_kmers_starting_at_position (kmer_finder.py:170-177) is the per-variant "
+                                  "entry point of UniqueVariantKmersFinder; not on the device path yet")
+
+    def _require_found(self):
+        if self._cols is None:
+            raise RuntimeError("call find() first")
+        return self._cols
+
+    def get_found_kmers_and_nodes(self):
+        c = self._require_found()
+        return c["kmers"], c["nodes"]
+
+    def get_flat_kmers(self, v="2"):
+        c = self._require_found()
+        if v == "0" or v == "1":
+            if v == "1":
+                if self._position_id is not None:
+                    ref_offsets = self._position_id.get(c["start_nodes"], c["start_offsets"])       # :117
+                else:
+                    ref_offsets = self._arrays.position_id_base()[c["start_nodes"]] + c["start_offsets"]
+            else:
+                ref_offsets = np.asarray(self._graph.node_to_ref_offset)[c["start_nodes"]] + c["start_offsets"]  # :119
+            return FlatKmers(c["kmers"], c["nodes"], ref_offsets, c["af"])
+        return FlatKmers2(c["kmers"], c["start_nodes"], c["start_offsets"], c["nodes"], c["af"])
+
+    @property
+    def kmers_found(self):
+        """First 500 windows as (None, set(nodes), start_node, kmer) -- debugging aid of the reference
+        (kmer_finder.py:148-168), here in end-position order."""
+        c = self._require_found()
+        out, i, n = [], 0, len(c["kmers"])
+        while i < n and len(out) < 500:
+            j = i + 1
+            while (j < n and c["kmers"][j] == c["kmers"][i] and c["start_nodes"][j] == c["start_nodes"][i]
+                   and c["start_offsets"][j] == c["start_offsets"][i] and c["nodes"][j] > c["nodes"][j - 1]):
+                j += 1
+            out.append((None, set(int(x) for x in c["nodes"][i:j]), int(c["start_nodes"][i]), int(c["kmers"][i])))
+            i = j
+        return out

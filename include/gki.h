@@ -1,0 +1,186 @@
+/*
+ * gki.h -- C ABI of libgki_hip.so, the MI355X (gfx950) implementation of graph_kmer_index's
+ * k-mer enumeration + hashing + index hot path.
+ *
+ * The reference (ivargr/graph_kmer_index v0.0.29) has no FFI seam for this path: it is plain
+ * Python/NumPy.  The entry points below are therefore what a ctypes
+ * binding inside the reference would call; each one names the reference function it replaces
+ * (paths relative to /root/reference/graph_kmer_index/).  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / numpy types.
+ *   - every function returns 0 on success or a GKI_ERR_* code; gki_last_error() returns a
+ *     thread-local description of the most recent failure.
+ *   - "d_" pointers are device (HBM) addresses obtained from gki_malloc(); "h_" pointers are host
+ *     memory owned by the caller.  Variable-size results use count -> allocate -> emit.
+ *   - one HIP stream per handle; calls on distinct handles may run concurrently, calls on one
+ *     handle are serialised by the caller.
+ */
+#ifndef GKI_H
+#define GKI_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GKI_OK 0
+#define GKI_ERR_HIP 1            /* a HIP runtime call failed (message has the HIP error string) */
+#define GKI_ERR_BAD_ARG 2
+#define GKI_ERR_NO_DEVICE 3
+#define GKI_ERR_WINDOW_TOO_DEEP 4 /* a k-window crosses more than GKI_MAX_WINDOW_NODES nodes */
+#define GKI_ERR_STATE 5          /* call order violated (e.g. emit before count) */
+#define GKI_ERR_OVERFLOW 6       /* a count does not fit the reference's dtype (e.g. int32 directory) */
+
+#define GKI_MAX_WINDOW_NODES 48
+#define GKI_MAX_K 31             /* kmer_hashing.py:25 `assert k <= 31` */
+
+/* ---------------------------------------------------------------- runtime */
+const char *gki_last_error(void);
+int gki_device_count(int *count);
+int gki_set_device(int device);
+int gki_malloc(void **d_ptr, int64_t bytes);
+int gki_free(void *d_ptr);
+int gki_memcpy_h2d(void *d_dst, const void *h_src, int64_t bytes);
+int gki_memcpy_d2h(void *h_dst, const void *d_src, int64_t bytes);
+int gki_memset(void *d_dst, int value, int64_t bytes);
+int gki_device_synchronize(void);
+/* bytes free / total on the current device */
+int gki_mem_info(int64_t *free_bytes, int64_t *total_bytes);
+
+/* ---------------------------------------------------------------- hashing (A1, A8, A10)
+ * hash = sum_i base[i] * 4^i, first base least significant, a/n/m=0 c=1 g=2 t=3
+ * (flat_kmers.py:134-145, kmer_hashing.py:4-9, snp_kmer_finder.py:19-26). */
+
+/* Every k-window of a numeric sequence: replaces np.convolve(seq, power_array(k), 'valid')
+ * (read_kmers.py:67-70, kmer_finder.py:350-352).  d_codes: uint8[n]; d_out: uint64[n-k+1]. */
+int gki_hash_sequence(const void *d_codes, int64_t n, int k, void *d_out);
+
+/* Reads laid out back to back (read r = bytes [read_start[r], read_start[r+1]) of ASCII
+ * letters); hashes of read r go to d_out[out_start[r] ...), out_start[r] = sum of
+ * max(0, len-k+1) of earlier reads (computed by the call, also returned in d_out_start).
+ * strand 0: forward (read_kmers.py:21-22); strand 1: reverse complement of the read
+ * (read_kmers.py:23-26, Bio.Seq.reverse_complement then the same hash).
+ * d_reads uint8[], d_read_start int64[n_reads+1], d_out_start int64[n_reads+1], d_out uint64[]. */
+int gki_hash_reads(const void *d_reads, const void *d_read_start, int64_t n_reads, int k, int strand,
+                   void *d_out_start, void *d_out, int64_t out_capacity, int64_t *n_out);
+
+/* kmer_hashing.py:24-28 kmer_hashes_to_reverse_complement_hash / :31-36 complement.
+ * d_in, d_out: uint64[n] (may alias). */
+int gki_reverse_complement(const void *d_in, int64_t n, int k, void *d_out);
+int gki_complement(const void *d_in, int64_t n, int k, void *d_out);
+
+/* ---------------------------------------------------------------- graph (the obgraph arrays in HBM)
+ * Replaces the per-node obgraph accessor calls of kmer_finder.py:50,62,259,279,350,384,138,143,374.
+ * Host arrays in (copied to HBM, 2-bit packed on device):
+ *   node_size int32[n_nodes]; seq uint8[n_bases] numeric bases, nodes concatenated in id order;
+ *   edge_start int64[n_nodes+1] / edges int32[n_edges]   successors (CSR, get_edges order);
+ *   rev_start  int64[n_nodes+1] / rev_edges int32[n_edges] predecessors (CSR);
+ *   is_ref uint8[n_nodes] (is_linear_ref_node_or_linear_ref_dummy_node); allele_freq double[n_nodes];
+ *   position_base int64[n_nodes] or NULL: PositionId.get(node, 0) (kmer_finder.py:117); NULL = the
+ *   exclusive prefix sum of node_size. */
+typedef struct gki_graph gki_graph;
+int gki_graph_create(gki_graph **out, int64_t n_nodes, const int32_t *h_node_size,
+                     const uint8_t *h_seq, int64_t n_bases,
+                     const int64_t *h_edge_start, const int32_t *h_edges,
+                     const int64_t *h_rev_start, const int32_t *h_rev_edges, int64_t n_edges,
+                     const uint8_t *h_is_ref, const double *h_allele_freq,
+                     const int64_t *h_position_base);
+/* Same, but seq already resident in HBM as uint8[n_bases] (synthetic generators, sharded loaders). */
+int gki_graph_create_dseq(gki_graph **out, int64_t n_nodes, const int32_t *h_node_size,
+                          const void *d_seq, int64_t n_bases,
+                          const int64_t *h_edge_start, const int32_t *h_edges,
+                          const int64_t *h_rev_start, const int32_t *h_rev_edges, int64_t n_edges,
+                          const uint8_t *h_is_ref, const double *h_allele_freq,
+                          const int64_t *h_position_base);
+/* Re-run the device-side preparation (2-bit pack, node-start bitmap + rank) from the resident
+ * uint8 sequence; gki_graph_create already did it once.  Exposed so a benchmark can time it. */
+int gki_graph_prepare(gki_graph *g);
+int gki_graph_destroy(gki_graph *g);
+int64_t gki_graph_n_bases(const gki_graph *g);
+
+/* critical_graph_paths.py:42-104 CriticalGraphPaths.from_graph (host-side walk over the
+ * linear reference; O(#linear nodes)).  h_chrom_start: chromosome start nodes.
+ * Outputs sized n_nodes by the caller.  GKI_ERR_BAD_ARG when the reference would raise
+ * (not exactly one linear successor :96-100, or offset -1 :104). */
+int gki_critical_paths(int64_t n_nodes, const int32_t *h_node_size,
+                       const int64_t *h_edge_start, const int32_t *h_edges,
+                       const int64_t *h_rev_start, const uint8_t *h_is_ref,
+                       const int32_t *h_chrom_start, int n_chrom, int k,
+                       uint32_t *h_out_nodes, uint16_t *h_out_offsets, int64_t *n_out);
+
+/* ---------------------------------------------------------------- DenseKmerFinder (A3-A5)
+ * Replaces DenseKmerFinder.find() (kmer_finder.py:179-244: search_from :254-347,
+ * _process_whole_node :349-381, _search_next_nodes :383-417, _add_kmer :128-168).
+ * Output = the reference's record multiset; order is by end position (node id, offset), windows
+ * of one end position in predecessor-list order, nodes of one window ascending. */
+typedef struct {
+    int32_t k;                    /* 1..31 */
+    int32_t max_variant_nodes;    /* kmer_finder.py:42 */
+    int32_t one_node_per_kmer;    /* only_save_one_node_per_kmer :145-146 */
+    int32_t reserved;
+    /* end positions processed: (node_begin, off_begin) inclusive .. (node_end, off_end) exclusive,
+     * in (node id, offset) order -- the chunking of command_line_interface.py:588-601.  Whole
+     * graph: node_begin = 0, off_begin = 0, node_end = n_nodes, off_end = 0. */
+    int64_t node_begin, off_begin, node_end, off_end;
+    /* per-node critical offset for lossy restarts (0 < c < k-1, SURVEY.md 8a' E1), uint16[n_nodes],
+     * 0xFFFF = none; NULL when the graph has none. */
+    const uint16_t *h_lossy_crit;
+} gki_find_params;
+
+typedef struct gki_finder gki_finder;
+int gki_finder_create(gki_graph *g, gki_finder **out);
+int gki_finder_destroy(gki_finder *f);
+/* pass 1: counts records (device count pass + prefix sums); returns the total. */
+int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records);
+/* pass 2, FlatKmers layout after FlatKmers.from_multiple_flat_kmers (flat_kmers.py:71-90):
+ * hashes uint64, nodes uint32, ref_offsets uint64 (= position id of the END position,
+ * kmer_finder.py:116-117), allele_frequencies float32.  Any pointer may be NULL (column skipped). */
+int gki_finder_emit_flat(gki_finder *f, void *d_hashes, void *d_nodes, void *d_ref_offsets, void *d_af32);
+/* pass 2, get_flat_kmers(v="2") layout (kmer_finder.py:124-126): hashes int64, start_nodes int32,
+ * start_offsets int16, nodes int32, allele_frequencies float64. */
+int gki_finder_emit_v2(gki_finder *f, void *d_hashes, void *d_start_nodes, void *d_start_offsets,
+                       void *d_nodes, void *d_af64);
+int gki_finder_synchronize(gki_finder *f);
+/* HIP-event time of the most recent launch of one kernel of this finder (after synchronize).
+ * which: 0 count-boundary, 1 emit-interior, 2 emit-boundary, 3 scans (sum), 4 graph prepare. */
+int gki_finder_kernel_ms(gki_finder *f, int which, float *ms);
+/* Records written by the interior kernel in the last emit (for roofline accounting). */
+int64_t gki_finder_interior_records(const gki_finder *f);
+
+/* ---------------------------------------------------------------- CollisionFreeKmerIndex (A9)
+ * Build: replaces CollisionFreeKmerIndex.from_flat_kmers (collision_free_kmer_index.py:423-467)
+ * and set_frequencies (:267-293).  Inputs are device columns of n records; outputs are device
+ * arrays sized by the caller: hashes_to_index int32[modulo], n_kmers uint32[modulo], and the
+ * permuted payload kmers uint64[n], nodes uint32[n], ref_offsets uint64[n], af float32[n],
+ * frequencies uint16[n], and optionally the permutation uint32[n] (`sorting` of :435; NULL to skip)
+ * so a caller can permute columns of other dtypes itself.  The sort is stable: inside a bucket
+ * records keep their input order (np.argsort leaves it unspecified).
+ * GKI_ERR_OVERFLOW if n >= 2^31 (the reference's directory is int32, :453). */
+int gki_index_build(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32,
+                    int64_t n, uint64_t modulo, int skip_frequencies,
+                    void *d_hashes_to_index, void *d_n_kmers,
+                    void *d_out_kmers, void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32,
+                    void *d_out_frequencies, void *d_out_permutation);
+
+/* Probe: replaces a loop of CollisionFreeKmerIndex.get (:303-315) over q queries
+ * (get_nodes_and_ref_offsets_from_multiple_kmers :354-376).  count -> emit.
+ * d_hit_start int64[q+1]: hits of query i are [hit_start[i], hit_start[i+1]) in bucket order;
+ * a query with no hit, or whose first hit has frequency > max_hits, contributes none.
+ * Emit columns (any may be NULL): nodes uint32, ref_offsets uint64, query index int64
+ * (`read_offsets` of :365), frequencies uint16, af float32, and the hit's position int64 in the
+ * payload arrays (lets a caller gather from its own columns of any dtype). */
+typedef struct {
+    const void *d_hashes_to_index, *d_n_kmers, *d_kmers, *d_nodes, *d_ref_offsets, *d_frequencies, *d_af32;
+    uint64_t modulo;
+    int64_t n;
+} gki_index_view;
+int gki_index_lookup_count(const gki_index_view *ix, const void *d_queries, int64_t q, int64_t max_hits,
+                           void *d_hit_start, int64_t *n_hits);
+int gki_index_lookup_emit(const gki_index_view *ix, const void *d_queries, int64_t q, int64_t max_hits,
+                          const void *d_hit_start, void *d_hit_nodes, void *d_hit_ref_offsets,
+                          void *d_hit_query, void *d_hit_frequencies, void *d_hit_af32, void *d_hit_position);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -117,8 +117,9 @@ CRITICAL_KATS = {
 
 
 def canonical_order(cols):
-    """Sort permutation by (start_node, start_offset, kmer, node)."""
-    return np.lexsort((np.asarray(cols["nodes"]).astype(np.int64), np.asarray(cols["kmers"]).astype(np.int64),
+    """Sort permutation by (start_node, start_offset, kmer, node, allele_frequency)."""
+    return np.lexsort((np.asarray(cols["allele_frequencies"]).astype(np.float64),
+                       np.asarray(cols["nodes"]).astype(np.int64), np.asarray(cols["kmers"]).astype(np.int64),
                        np.asarray(cols["start_offsets"]).astype(np.int64),
                        np.asarray(cols["start_nodes"]).astype(np.int64)))
 

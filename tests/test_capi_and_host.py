@@ -1,0 +1,189 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/gki.h declares; host logic of the
+drop-in classes (no GPU compute calls)."""
+import ctypes as C
+import os
+import re
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from graph_kmer_index_amd import _lib, GraphArrays, FlatKmers, CriticalGraphPaths
+from graph_kmer_index_amd import letter_sequence_to_numeric, sequence_to_kmer_hash, kmer_hash_to_sequence, NpList
+from graph_kmer_index_amd.kmer_hashing import power_array, reverse_power_array, kmer_hashes_to_bases, kmer_to_hash_fast
+from graph_kmer_index_amd.kmer_finder import check_supported_graph, lossy_table, update_hash, DenseKmerFinder
+from graph_kmer_index_amd.graph import synthetic_snp_graph, synthetic_linear_graph
+from golden_cases import CRITICAL_KATS, REFERENCE_TEST_GRAPHS
+from oracle import oracle
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "gki.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gki_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(_lib.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 30
+    for name in names:
+        assert hasattr(lib, name), name
+    assert sorted(_lib.SYMBOLS) == names          # the ctypes binding covers the whole header
+    _lib.load()
+
+
+def test_no_cpu_fallback_without_gpu():
+    if _lib.device_count() > 0:
+        pytest.skip("GPU present")
+    g = GraphArrays.from_dicts({1: "ACTG", 2: "A", 3: "G", 4: "CCCC"}, {1: [2, 3], 2: [4], 3: [4]}, [1, 2, 4])
+    with pytest.raises(_lib.GkiError):
+        DenseKmerFinder(g, 3).find()
+    from graph_kmer_index_amd.kmer_hashing import kmer_hashes_to_reverse_complement_hash
+    with pytest.raises(_lib.GkiError):
+        kmer_hashes_to_reverse_complement_hash(np.array([5], dtype=np.uint64), 3)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "graph_kmer_index_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "libgki_oracle" not in text, fn
+
+
+@pytest.mark.parametrize("name", sorted(CRITICAL_KATS))
+def test_critical_paths_known_answers(name):
+    # host-side walk inside libgki_hip.so (no GPU needed); tests/test_critical_graph_paths.py of the reference
+    (seqs, edges, lin), k, nodes, offsets = CRITICAL_KATS[name]
+    cp = CriticalGraphPaths.from_graph(GraphArrays.from_dicts(seqs, edges, lin), k)
+    assert cp.nodes.tolist() == nodes and cp.offsets.tolist() == offsets
+    assert cp.nodes.dtype == np.uint32 and cp.offsets.dtype == np.uint16
+    assert len(cp) == len(nodes) and list(cp) == list(zip(nodes, offsets))
+    for n, o in zip(nodes, offsets):
+        assert cp.is_critical(n, o) and not cp.is_critical(n, o + 1)
+
+
+def test_critical_paths_synthetic_vs_oracle():
+    for g in (synthetic_snp_graph(50000, 700, k=31, seed=1), synthetic_linear_graph(100000, 7000, seed=2)):
+        cp = CriticalGraphPaths.from_graph(g, 31)
+        on, oo = oracle.critical_paths(g, 31)
+        assert np.array_equal(cp.nodes, on) and np.array_equal(cp.offsets, oo)
+    with pytest.raises(Exception):      # reference crash E2: exactly k bases of chain before a node
+        CriticalGraphPaths.from_graph(GraphArrays.from_dicts({0: "ACG", 1: "TTTTTT"}, {0: [1]}, [0, 1]), 3)
+
+
+def test_hash_helpers_known_answers():
+    # tests/test_kmer_hashing.py:11,27,30-35,69-75
+    assert sequence_to_kmer_hash("ACTG") == 0 * 1 + 1 * 4 + 3 * 16 + 2 * 64
+    assert sequence_to_kmer_hash("T" * 31) == 4611686018427387903
+    for s in ["atg", "Acacatacgactacg", "CAtgAACAtttggtAATCTACAtgAACAttt", "G"]:
+        assert kmer_hash_to_sequence(sequence_to_kmer_hash(s), len(s)) == s.lower()
+        assert sequence_to_kmer_hash(s) == int(np.sum(reverse_power_array(len(s)) * letter_sequence_to_numeric(s)))
+        assert sequence_to_kmer_hash(s) == oracle.sequence_to_kmer_hash(s)
+    hashes = np.array([sequence_to_kmer_hash(s) for s in ["ACTG", "TGGC"]])
+    assert kmer_hashes_to_bases(hashes, 4).tolist() == [[0, 1, 3, 2], [3, 2, 2, 1]]
+    assert power_array(3).tolist() == [16, 4, 1] and reverse_power_array(3).tolist() == [1, 4, 16]
+    assert letter_sequence_to_numeric("acgtnmACGTNM").tolist() == [0, 1, 2, 3, 0, 0, 0, 1, 2, 3, 0, 0]
+    assert letter_sequence_to_numeric("acgt").dtype == np.uint64
+    assert kmer_to_hash_fast(np.array([1, 2], dtype=np.uint64), 2) == 9
+    for k in (3, 31):
+        h = 0
+        seq = np.random.default_rng(k).integers(0, 4, size=80)
+        for i, b in enumerate(seq):
+            h = update_hash(b, h, seq[i - k] if i >= k else 0, k, only_add=False if i >= k else i)
+            assert h == oracle.update_hash(b, 0 if i == 0 else prev, seq[i - k] if i >= k else 0, k,
+                                           only_add=False if i >= k else i)
+            prev = h
+
+
+def test_nplist_semantics():
+    # tests/test_nplist.py of the reference
+    l = NpList(dtype=np.int32)
+    for i in range(250):
+        l.append(i)
+    assert len(l) == 250 and l[-1] == 249 and l.get_nparray().dtype == np.int32
+    l.extend(np.arange(1000))
+    assert len(l) == 1250 and l[250] == 0
+    c = l.copy()
+    assert c == l
+    l.set_n_elements(10)
+    assert len(l) == 10 and l.get_nparray().tolist() == list(range(10))
+
+
+def test_flat_kmers_container(tmp_path):
+    f1 = FlatKmers(np.array([5, 6, 5], dtype=np.int64), np.array([1, 2, 3], dtype=np.int32), np.array([7, 8, 9]),
+                   np.array([0.5, 1.0, 0.25]))
+    f2 = FlatKmers(np.array([6], dtype=np.int64), np.array([4], dtype=np.int32), np.array([1]), np.array([1.0]))
+    m = FlatKmers.from_multiple_flat_kmers([f1, f2])
+    assert m._hashes.dtype == np.uint64 and m._nodes.dtype == np.uint32
+    assert m._ref_offsets.dtype == np.uint64 and m._allele_frequencies.dtype == np.float32
+    assert m._hashes.tolist() == [5, 6, 5, 6]
+    ns = m.get_new_without_singletons()          # 2nd+ occurrences, original order (flat_kmers.py:98-125)
+    assert ns._hashes.tolist() == [5, 6] and ns._nodes.tolist() == [3, 4]
+    assert np.array_equal(ns._hashes, m._hashes[oracle.without_singletons(m._hashes)])
+    path = str(tmp_path / "flat")
+    m.to_file(path)
+    assert set(np.load(path + ".npz").keys()) == {"hashes", "nodes", "ref_offsets", "allele_frequencies"}
+    back = FlatKmers.from_file(path)
+    assert np.array_equal(back._hashes, m._hashes) and np.array_equal(back._allele_frequencies, m._allele_frequencies)
+    with pytest.raises(AssertionError):
+        FlatKmers(np.zeros(2), np.zeros(3))
+
+
+def test_graph_arrays_accessors_and_adapter():
+    seqs, edges, lin, k, kw = REFERENCE_TEST_GRAPHS["multiple_critical_points"]
+    g = GraphArrays.from_dicts(seqs, edges, lin)
+    assert g.get_node_size(4) == 3 and g.get_edges(4) == [5, 6] and g.get_first_node() == 1
+    assert g.get_numeric_node_sequence(4).tolist() == [0, 1, 3]
+    assert g.is_linear_ref_node_or_linear_ref_dummy_node(3) is False      # sibling 2 is linear
+    assert sorted(g.get_reverse_edges_hashtable()[4]) == [2, 3]
+    g2 = GraphArrays.from_obgraph(_AccessorOnly(g))
+    for name in ("node_size", "seq", "edge_start", "edges", "rev_start", "rev_edges", "is_ref", "allele_freq"):
+        assert np.array_equal(getattr(g, name), getattr(g2, name)), name
+
+
+class _AccessorOnly:
+    """Exposes only the obgraph accessor methods, to exercise GraphArrays.from_obgraph."""
+
+    def __init__(self, g):
+        self._g = g
+        self.nodes = g.node_size
+        self.chromosome_start_nodes = g.chromosome_start_nodes
+        self.node_to_ref_offset = g.node_to_ref_offset
+
+    def __getattr__(self, name):
+        if name in ("max_node_id", "get_edges", "get_numeric_node_sequence", "get_reverse_edges_hashtable",
+                    "is_linear_ref_node_or_linear_ref_dummy_node", "get_node_allele_frequencies", "get_first_node"):
+            return getattr(self._g, name)
+        raise AttributeError(name)
+
+
+def test_supported_graph_checks():
+    g = GraphArrays.from_dicts({0: "ACGTACGT", 1: "A", 2: "C", 3: "G", 4: "TTTTTTTT"},
+                               {0: [1, 2], 2: [3], 1: [4], 3: [4]}, [0, 1, 4])
+    with pytest.raises(NotImplementedError):
+        check_supported_graph(g, 4)
+    check_supported_graph(synthetic_snp_graph(20000, 300, k=31, seed=3), 31)
+    # lossy restart table: critical (N, c) with 0 < c < k-1
+    g = GraphArrays.from_dicts({0: "A", 1: "CTTT", 2: "TAAGGGG", 3: "AA", 4: ""}, {0: [1], 1: [2, 4], 2: [3], 4: [3]},
+                               [0, 1, 2, 3])
+    assert lossy_table(g, 3, [1], [1]) is None or lossy_table(g, 3, [1], [1])[1] == 1      # c=1 = k-2
+    t = lossy_table(g, 5, [1], [1])
+    assert t[1] == 1 and t[0] == 0xFFFF
+    big = GraphArrays.from_dicts({0: "AC", 1: "A" * 40}, {0: [1]}, [0, 1])
+    with pytest.raises(ValueError):
+        lossy_table(big, 9, [1], [6])        # c=6 >= 3, node longer than 2k+3: reference undefined
+
+
+def test_synthetic_generators_are_prefix_stable_and_wellformed():
+    a = synthetic_snp_graph(100000, 900, k=31, seed=1234)
+    assert a.seq.max() <= 3 and a.node_size.min() >= 1
+    assert np.all(a.edges > np.repeat(np.arange(a.n_nodes), np.diff(a.edge_start)))       # topological ids
+    alt = np.nonzero(a.is_ref == 0)[0]
+    assert np.all(a.seq[a.seq_start[alt]] != a.seq[a.seq_start[alt - 1]])                # alt differs from ref allele
+    assert np.allclose(a.allele_freq[alt] + a.allele_freq[alt - 1], 1.0)
+    lin = synthetic_linear_graph(100000, 25000, seed=1234)
+    assert lin.n_nodes == 4 and int(lin.seq_start[-1]) == 100000
+    from graph_kmer_index_amd.graph import random_codes
+    assert np.array_equal(random_codes(1000, 5), random_codes(5000, 5)[:1000])

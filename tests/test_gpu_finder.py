@@ -1,0 +1,217 @@
+"""-m gpu: DenseKmerFinder on MI355X (through the C ABI) against the golden vectors generated from the
+reference and against the oracle on seeded inputs."""
+import json
+import os
+import numpy as np
+import pytest
+
+from golden_cases import canonical_digest
+from gpu_util import finder_cols, assert_same_records
+from graph_kmer_index_amd import DenseKmerFinder, GraphArrays, CriticalGraphPaths
+from graph_kmer_index_amd.graph import synthetic_linear_graph, synthetic_snp_graph
+from graphgen import random_bubble_graph, overlapping_bubble_graph
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+with open(os.path.join(GOLD, "finder_toy.json")) as _f:
+    TOY = json.load(_f)
+
+
+def graph_of(case):
+    seqs = {int(a): b for a, b in case["seqs"].items()}
+    edges = {int(a): b for a, b in case["edges"].items()}
+    af = None if case["af"] is None else {int(a): b for a, b in case["af"].items()}
+    return GraphArrays.from_dicts(seqs, edges, case["linear"], af)
+
+
+def is_linear(g):
+    return np.all(np.diff(g.edge_start) <= 1)
+
+
+@pytest.mark.parametrize("case", [c for c in TOY if "from_position" not in c["kw"]], ids=lambda c: c["name"])
+def test_toy_graphs_match_reference_records(case):
+    g = graph_of(case)
+    kw = dict(case["kw"])
+    if "only_store_nodes" in kw:
+        kw["only_store_nodes"] = set(kw["only_store_nodes"])
+    if case.get("raises") == "E2":
+        with pytest.raises(Exception):
+            CriticalGraphPaths.from_graph(g, case["k"])
+        return
+    cp = CriticalGraphPaths.from_graph(g, case["k"])
+    assert cp.nodes.tolist() == case["crit_nodes"] and cp.offsets.tolist() == case["crit_offsets"]
+    # graphs where the reference itself emits meaningless hashes are refused, not imitated
+    _, flags = oracle.find(g, case["k"], (cp.nodes, cp.offsets), return_flags=True)
+    f = DenseKmerFinder(g, case["k"], critical_graph_paths=cp, **kw)
+    if flags & oracle.ORC_FLAG_UNDEFINED_BULK:
+        with pytest.raises(ValueError):
+            f.find()
+        return
+    f.find()
+    exp = dict(kmers=np.array(case["kmers"], np.int64), nodes=np.array(case["nodes"], np.int32),
+               start_nodes=np.array(case["start_nodes"], np.int32),
+               start_offsets=np.array(case["start_offsets"], np.int16),
+               allele_frequencies=np.array(case["allele_frequencies"], np.float64))
+    got = finder_cols(f)
+    assert got["kmers"].dtype == np.int64 and got["nodes"].dtype == np.int32
+    assert got["start_nodes"].dtype == np.int32 and got["start_offsets"].dtype == np.int16
+    assert got["allele_frequencies"].dtype == np.float64
+    assert_same_records(got, exp, exact_order=is_linear(g))
+    k2, n2 = f.get_found_kmers_and_nodes()
+    assert np.array_equal(k2, got["kmers"]) and np.array_equal(n2, got["nodes"])
+
+
+def test_medium_linear_exact_order():
+    med = np.load(os.path.join(GOLD, "finder_medium.npz"))
+    g = synthetic_linear_graph(20000, node_len=3000, seed=1234)
+    for one in (False, True):
+        f = DenseKmerFinder(g, 31, only_save_one_node_per_kmer=one)
+        f.find()
+        got = finder_cols(f)
+        tag = "linear20k_one%d" % one
+        exp = dict(kmers=med[tag + "_kmers"], nodes=med[tag + "_nodes"], start_nodes=med[tag + "_start_nodes"],
+                   start_offsets=med[tag + "_start_offsets"], allele_frequencies=med[tag + "_af"])
+        assert_same_records(got, exp, exact_order=True)
+
+
+def test_medium_snp_graph_digests():
+    with open(os.path.join(GOLD, "finder_medium_meta.json")) as fh:
+        meta = json.load(fh)
+    for name, m in meta.items():
+        g = synthetic_snp_graph(m["G"], m["S"], k=m["k"], seed=m["seed"])
+        f = DenseKmerFinder(g, m["k"], only_save_one_node_per_kmer=m["one"], max_variant_nodes=m["M"])
+        f.find()
+        got = finder_cols(f)
+        assert len(got["kmers"]) == m["n_records"], name
+        assert canonical_digest(got) == m["digest"], name
+
+
+@pytest.mark.parametrize("mode,n,seed", [("bubble", 60, 21), ("overlap", 40, 22), ("chain", 80, 23)])
+def test_random_graphs_against_oracle(mode, n, seed):
+    rng = np.random.default_rng(seed)
+    checked = 0
+    for _ in range(n):
+        k = int(rng.integers(3, 12))
+        M = int(rng.choice([0, 1, 2, 3, 4, 100]))
+        one = bool(rng.integers(0, 2))
+        if mode == "bubble":
+            seqs, edges, lin, af = random_bubble_graph(rng, n_var=int(rng.integers(2, 30)), min_ref=1, max_ref=2 * k,
+                                                       p_indel=float(rng.choice([0.0, 0.5])), with_af=True)
+        elif mode == "overlap":
+            seqs, edges, lin, af = overlapping_bubble_graph(rng, n_var=int(rng.integers(3, 12)))
+        else:
+            nv = int(rng.integers(1, 6))
+            seqs, edges, lin, af = random_bubble_graph(
+                rng, n_var=nv, min_ref=1, max_ref=3 * k + 8, p_indel=0.3,
+                chain_after={int(rng.integers(-1, nv)): int(rng.integers(1, k + 2))})
+        g = GraphArrays.from_dicts(seqs, edges, lin, af)
+        try:
+            cn, co = oracle.critical_paths(g, k)
+        except oracle.OracleError:
+            with pytest.raises(Exception):
+                CriticalGraphPaths.from_graph(g, k)
+            continue
+        exp, flags = oracle.find(g, k, (cn, co), one, M, return_flags=True)
+        f = DenseKmerFinder(g, k, only_save_one_node_per_kmer=one, max_variant_nodes=M)
+        if flags & oracle.ORC_FLAG_UNDEFINED_BULK:
+            with pytest.raises(ValueError):
+                f.find()
+            continue
+        f.find()
+        assert_same_records(finder_cols(f), exp)
+        checked += 1
+    assert checked > n // 2
+
+
+@pytest.mark.parametrize("G,S,M,one", [(400000, 3000, 5, True), (200000, 4000, 3, False), (150000, 6000, 1, True)])
+def test_snp_graph_k31_against_oracle(G, S, M, one):
+    g = synthetic_snp_graph(G, S, k=31, seed=5)
+    exp = oracle.find(g, 31, None, one, M)
+    f = DenseKmerFinder(g, 31, only_save_one_node_per_kmer=one, max_variant_nodes=M)
+    f.find()
+    assert_same_records(finder_cols(f), exp)
+
+
+def test_flat_layout_on_device_matches_v2_columns():
+    g = synthetic_snp_graph(120000, 1500, k=31, seed=9)
+    f = DenseKmerFinder(g, 31, only_save_one_node_per_kmer=True, max_variant_nodes=5)
+    f.find()
+    v2 = finder_cols(f)
+    d = f.find_flat_on_device()
+    f.synchronize()
+    flat = d.to_flat_kmers()
+    assert flat._hashes.dtype == np.uint64 and flat._nodes.dtype == np.uint32
+    assert flat._ref_offsets.dtype == np.uint64 and flat._allele_frequencies.dtype == np.float32
+    assert np.array_equal(flat._hashes, v2["kmers"].astype(np.uint64))
+    assert np.array_equal(flat._nodes, v2["nodes"].astype(np.uint32))
+    pos = g.position_id_base()[v2["start_nodes"]] + v2["start_offsets"]
+    assert np.array_equal(flat._ref_offsets, pos.astype(np.uint64))
+    assert np.array_equal(flat._allele_frequencies, v2["allele_frequencies"].astype(np.float32))
+    # get_flat_kmers(v="1") agrees with the device layout
+    fl1 = f.get_flat_kmers(v="1")
+    assert np.array_equal(np.asarray(fl1._ref_offsets).astype(np.uint64), flat._ref_offsets)
+
+
+def test_chunked_find_partitions_the_records():
+    # command_line_interface.py:588-601: contiguous ranges of critical-path numbers
+    g = synthetic_snp_graph(300000, 2500, k=31, seed=13)
+    cp = CriticalGraphPaths.from_graph(g, 31)
+    full = DenseKmerFinder(g, 31, critical_graph_paths=cp, only_save_one_node_per_kmer=True, max_variant_nodes=5)
+    full.find()
+    exp = finder_cols(full)
+    n = len(cp)
+    cuts = [0] + sorted(np.random.default_rng(1).integers(1, n, size=6).tolist()) + [n]
+    parts = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        f = DenseKmerFinder(g, 31, critical_graph_paths=cp, only_save_one_node_per_kmer=True, max_variant_nodes=5,
+                            start_at_critical_path_number=a, stop_at_critical_path_number=b)
+        f.find()
+        parts.append(finder_cols(f))
+        # each chunk equals the oracle's chunk (which equals the reference's, tests/test_oracle_vs_reference.py)
+        o = oracle.find(g, 31, (cp.nodes, cp.offsets), True, 5, start_at_critical_path_number=a,
+                        stop_at_critical_path_number=b)
+        assert_same_records(parts[-1], o)
+    cat = {k: np.concatenate([p[k] for p in parts]) for k in exp}
+    assert_same_records(cat, exp, exact_order=True)     # end-position order: concatenation is the full run
+
+
+def test_golden_chunk_cases():
+    for case in TOY:
+        if not case["name"].startswith("rand_chunk_"):
+            continue
+        g = graph_of(case)
+        f = DenseKmerFinder(g, case["k"], **case["kw"])
+        f.find()
+        exp = dict(kmers=np.array(case["kmers"], np.int64), nodes=np.array(case["nodes"], np.int32),
+                   start_nodes=np.array(case["start_nodes"], np.int32),
+                   start_offsets=np.array(case["start_offsets"], np.int16),
+                   allele_frequencies=np.array(case["allele_frequencies"], np.float64))
+        assert_same_records(finder_cols(f), exp)
+
+
+def test_unsupported_graphs_raise():
+    # a variant node whose only predecessor is a variant node
+    g = GraphArrays.from_dicts({0: "ACGTACGT", 1: "A", 2: "C", 3: "G", 4: "TTTTTTTT"},
+                               {0: [1, 2], 2: [3], 1: [4], 3: [4]}, [0, 1, 4])
+    with pytest.raises(NotImplementedError):
+        DenseKmerFinder(g, 4).find()
+    g2 = GraphArrays.from_dicts({0: "ACGTACGT", 1: "A", 2: "C", 3: "TTTTTTTT"}, {0: [1, 2], 1: [3], 2: [3]}, [0, 1, 3])
+    with pytest.raises(NotImplementedError):
+        DenseKmerFinder(g2, 4, only_follow_nodes={2})
+    with pytest.raises(NotImplementedError):
+        DenseKmerFinder(g2, 4).find_only_kmers_starting_at_position(0, 2)
+
+
+def test_whitelist_and_only_store_nodes_filters():
+    g = synthetic_snp_graph(50000, 600, k=31, seed=3)
+    base = oracle.find(g, 31, None, False, 4)
+    wl = set(int(x) for x in base["kmers"][::7])
+    f = DenseKmerFinder(g, 31, whitelist=wl)
+    f.find()
+    assert_same_records(finder_cols(f), oracle.find(g, 31, None, False, 4, whitelist=wl))
+    variant_nodes = set(np.nonzero(g.is_ref == 0)[0].tolist())
+    f = DenseKmerFinder(g, 31, only_store_nodes=variant_nodes)
+    f.find()
+    assert_same_records(finder_cols(f), oracle.find(g, 31, None, False, 4, only_store_nodes=variant_nodes))

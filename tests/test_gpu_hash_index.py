@@ -1,0 +1,197 @@
+"""-m gpu: hashing kernels, CollisionFreeKmerIndex build and batched probe against golden vectors and oracle."""
+import os
+import numpy as np
+import pytest
+
+from graph_kmer_index_amd import (CollisionFreeKmerIndex, FlatKmers, ReadKmers, _lib, sequence_to_kmer_hash,
+                                  kmer_hash_to_sequence)
+from graph_kmer_index_amd.kmer_hashing import (kmer_hashes_to_reverse_complement_hash, kmer_hashes_to_complement_hashes,
+                                               kmer_hash_to_reverse_complement_hash, power_array)
+from graph_kmer_index_amd.read_kmers import hash_reads
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_reverse_complement_and_complement_golden():
+    h = np.load(os.path.join(GOLD, "hashing.npz"))
+    for k in (3, 9, 16, 31):
+        x = h["rc_in_k%d" % k]
+        rc = kmer_hashes_to_reverse_complement_hash(x, k)
+        assert rc.dtype == np.uint64
+        assert np.array_equal(rc, h["rc_out_k%d" % k])
+        assert np.array_equal(kmer_hashes_to_complement_hashes(x, k), h["comp_out_k%d" % k])
+        assert np.array_equal(kmer_hashes_to_reverse_complement_hash(rc, k), x)      # involution
+    # tests/test_kmer_hashing.py:38-54 known sequences
+    for seq, rc_seq in (("AcATaCAG", "ctgtatgt"), ("ACT", "agt"), ("G" * 31, "c" * 31)):
+        hh = sequence_to_kmer_hash(seq)
+        assert kmer_hash_to_sequence(int(kmer_hash_to_reverse_complement_hash(hh, len(seq))), len(seq)) == rc_seq
+
+
+def test_reverse_complement_large_random_vs_oracle():
+    rng = np.random.default_rng(1)
+    for k in (1, 2, 15, 30, 31):
+        x = rng.integers(0, 4 ** k, size=300001, dtype=np.uint64)
+        assert np.array_equal(kmer_hashes_to_reverse_complement_hash(x, k), oracle.reverse_complement(x, k))
+        assert np.array_equal(kmer_hashes_to_complement_hashes(x, k), oracle.complement(x, k))
+    assert len(kmer_hashes_to_reverse_complement_hash(np.zeros(0, np.uint64), 31)) == 0
+
+
+def test_read_kmers_golden_and_strands():
+    h = np.load(os.path.join(GOLD, "hashing.npz"))
+    reads = [str(r) for r in h["reads"]]
+    for k in (5, 31):
+        got, start = hash_reads(reads, k, 0)
+        assert np.array_equal(got, h["read_kmers_k%d" % k])
+        assert start[-1] == len(got)
+        one = ReadKmers.get_kmers_from_read_dynamic(reads[0], power_array(k))
+        assert np.array_equal(one, got[start[0]:start[1]])
+    comp = str.maketrans("ACGTacgt", "TGCAtgca")
+    rng = np.random.default_rng(2)
+    reads = ["".join("ACGTNacgtn"[i] for i in rng.integers(0, 10, size=int(n))) for n in rng.integers(1, 400, size=300)]
+    reads += ["", "A" * 31, "ACGT" * 50]
+    for k in (4, 31):
+        got, start = hash_reads(reads, k, 1)
+        exp = [oracle.read_kmers(r.translate(comp)[::-1], k) for r in reads]
+        assert np.array_equal(got, np.concatenate(exp))
+        assert np.array_equal(np.diff(start), [len(e) for e in exp])
+        fwd, _ = hash_reads(reads, k, 0)
+        assert np.array_equal(fwd, np.concatenate([oracle.read_kmers(r, k) for r in reads]))
+
+
+def test_hash_sequence_vs_oracle():
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    for n, k in ((1000, 31), (100003, 31), (64, 5), (31, 31), (30, 31)):
+        codes = rng.integers(0, 4, size=n).astype(np.uint8)
+        d_in = _lib.DeviceArray.from_host(codes)
+        d_out = _lib.DeviceArray(max(n - k + 1, 1), np.uint64)
+        _lib.check(_lib.load().gki_hash_sequence(d_in.ptr, n, k, d_out.ptr))
+        assert np.array_equal(d_out.to_host(max(n - k + 1, 0)), oracle.hash_sequence(codes, k))
+
+
+def _bucket_multisets(idx):
+    out = {}
+    h2i, nk = np.asarray(idx["_hashes_to_index"]), np.asarray(idx["_n_kmers"])
+    for b in np.nonzero(nk)[0]:
+        s, n = int(h2i[b]), int(nk[b])
+        out[int(b)] = sorted(zip(np.asarray(idx["_kmers"][s:s + n]).tolist(), np.asarray(idx["_nodes"][s:s + n]).tolist(),
+                                 np.asarray(idx["_ref_offsets"][s:s + n]).tolist(),
+                                 np.asarray(idx["_frequencies"][s:s + n]).tolist(),
+                                 np.asarray(idx["_allele_frequencies"][s:s + n], dtype=np.float64).tolist()))
+    return out
+
+
+def _attrs(index):
+    return {name: getattr(index, name) for name in ("_hashes_to_index", "_n_kmers", "_nodes", "_ref_offsets", "_kmers",
+                                                    "_frequencies", "_allele_frequencies")}
+
+
+@pytest.mark.parametrize("tag,kw", [("kat", {}), ("rand", {}), ("rand_skipfreq", {"skip_frequencies": True}),
+                                    ("rand_nosingle", {"skip_singletons": True})])
+def test_index_build_and_get_golden(tag, kw, tmp_path):
+    z = np.load(os.path.join(GOLD, "index.npz"))
+    modulo = int(z[tag + "_modulo"])
+    flat = FlatKmers(z[tag + "_in_hashes"], z[tag + "_in_nodes"], z[tag + "_in_ref_offsets"], z[tag + "_in_af"])
+    idx = CollisionFreeKmerIndex.from_flat_kmers(flat, modulo=modulo, **kw)
+    ref = {name: z[tag + name] for name in ("_hashes_to_index", "_n_kmers", "_nodes", "_ref_offsets", "_kmers",
+                                            "_frequencies", "_allele_frequencies")}
+    assert idx._hashes_to_index.dtype == np.int32 and idx._n_kmers.dtype == np.uint32
+    assert idx._frequencies.dtype == np.uint16
+    assert np.array_equal(idx._hashes_to_index, ref["_hashes_to_index"])
+    assert np.array_equal(idx._n_kmers, ref["_n_kmers"])
+    for name in ("_nodes", "_ref_offsets", "_kmers", "_allele_frequencies"):
+        assert getattr(idx, name).dtype == ref[name].dtype, name
+    assert _bucket_multisets(_attrs(idx)) == _bucket_multisets(ref)
+    # element-wise against the oracle (both stable)
+    o = oracle.index_build(z[tag + "_in_hashes"], z[tag + "_in_nodes"], z[tag + "_in_ref_offsets"], z[tag + "_in_af"],
+                           modulo=modulo, **kw)
+    for name in ref:
+        assert np.array_equal(getattr(idx, name), o[name]), name
+    # npz round trip with the reference's keys (collision_free_kmer_index.py:393-420)
+    path = str(tmp_path / "idx")
+    idx.to_file(path)
+    back = CollisionFreeKmerIndex.from_file(path)
+    assert set(np.load(path + ".npz").keys()) == {"hashes_to_index", "n_kmers", "nodes", "ref_offsets", "kmers", "modulo",
+                                                  "frequencies", "allele_frequencies"}
+    for index in (idx, back):
+        for mh in (10, 1):
+            pos = 0
+            for q, ne in zip(z[tag + "_queries"], z[tag + "_get%d_n" % mh]):
+                r = index.get(int(q), max_hits=mh)
+                if ne < 0:
+                    assert r == (None, None, None, None)
+                    continue
+                exp = sorted(zip(z[tag + "_get%d_nodes" % mh][pos:pos + ne].tolist(),
+                                 z[tag + "_get%d_ref_offsets" % mh][pos:pos + ne].tolist(),
+                                 z[tag + "_get%d_frequencies" % mh][pos:pos + ne].tolist(),
+                                 z[tag + "_get%d_af" % mh][pos:pos + ne].tolist()))
+                got = sorted(zip(r[0].tolist(), r[1].tolist(), r[2].tolist(), np.asarray(r[3], np.float64).tolist()))
+                assert got == exp
+                pos += ne
+
+
+def test_reference_known_answer_fixture():
+    # tests/test_collision_free_kmer_index.py:6-23 of the reference
+    flat = FlatKmers(np.array([1, 1, 2, 2, 4, 5, 3], dtype=np.uint64), np.array([5, 6, 7, 8, 10, 11, 100]),
+                     np.array([1, 1, 2, 3, 10, 11, 100]))
+    index = CollisionFreeKmerIndex.from_flat_kmers(flat, modulo=4)
+    assert list(index.get(1)[0]) == [5, 6]
+    assert list(index.get(1)[1]) == [1, 1]
+    assert list(index.get(5)[0]) == [11]
+    assert index.get(7) == (None, None, None, None)
+    assert 3 in index and 9 not in index
+    n, r, q, f = index.get_nodes_and_ref_offsets_from_multiple_kmers(np.array([1, 5]))
+    assert n.tolist() == [5, 6, 11] and r.tolist() == [1, 1, 11] and q.tolist() == [0.0, 0.0, 1.0]
+    assert f.tolist() == [1, 1, 1]
+    assert index.get_nodes_from_multiple_kmers(np.array([9, 9])).tolist() == []
+    assert index.has_kmers(np.array([1, 2, 3, 10, 10, 12, 100, 101, 102, 5], dtype=np.uint64)).tolist() == \
+        [True, True, True, False, False, False, False, False, False, True]     # :30-34
+
+
+@pytest.mark.parametrize("n,modulo,n_distinct", [(200000, 452930477, 150000), (300000, 65537, 5000), (50000, 7, 40),
+                                                  (70000, 1000003, 3)])
+def test_index_build_random_vs_oracle(n, modulo, n_distinct):
+    """Includes buckets far larger than the per-lane path (large-bucket sort) and tiny moduli."""
+    rng = np.random.default_rng(n)
+    pool = rng.integers(0, 4 ** 31, size=n_distinct, dtype=np.uint64)
+    kmers = pool[rng.integers(0, n_distinct, size=n)]
+    nodes = rng.integers(0, 1 << 24, size=n).astype(np.uint32)
+    refs = (kmers % np.uint64(50)) + rng.integers(0, 30, size=n).astype(np.uint64)
+    af = rng.uniform(0, 1, size=n).astype(np.float32)
+    idx = CollisionFreeKmerIndex.from_flat_kmers(FlatKmers(kmers, nodes, refs, af), modulo=modulo)
+    o = oracle.index_build(kmers, nodes, refs, af, modulo=modulo)
+    for name in ("_hashes_to_index", "_n_kmers", "_kmers", "_nodes", "_ref_offsets", "_allele_frequencies", "_frequencies"):
+        assert np.array_equal(getattr(idx, name), o[name]), name
+    # batched probe == loop of oracle gets (hits in bucket order)
+    queries = np.concatenate([pool[:2000], rng.integers(0, 4 ** 31, size=500, dtype=np.uint64)])
+    for mh in (10, 3, 10 ** 9):
+        got_nodes, got_refs, got_q, got_f = idx.get_nodes_and_ref_offsets_from_multiple_kmers(queries, max_hits=mh)
+        en, er, eq, ef = [], [], [], []
+        for i, q in enumerate(queries[:700]):
+            r = oracle.index_get(o, int(q), max_hits=mh)
+            if r[0] is None:
+                continue
+            en.append(r[0]); er.append(r[1]); eq.append(np.full(len(r[0]), i)); ef.append(r[2])
+        m = sum(len(x) for x in en)
+        sel = got_q < 700
+        assert sel.sum() == m
+        if m:
+            assert np.array_equal(got_nodes[sel], np.concatenate(en)) and np.array_equal(got_refs[sel], np.concatenate(er))
+            assert np.array_equal(got_q[sel], np.concatenate(eq)) and np.array_equal(got_f[sel], np.concatenate(ef))
+
+
+def test_index_from_finder_output_float64_af():
+    from graph_kmer_index_amd import DenseKmerFinder
+    from graph_kmer_index_amd.graph import synthetic_snp_graph
+    g = synthetic_snp_graph(60000, 800, k=31, seed=4)
+    f = DenseKmerFinder(g, 31)
+    f.find()
+    fl = f.get_flat_kmers(v="1")             # int64 hashes, int32 nodes, int64 ref_offsets, float64 af
+    idx = CollisionFreeKmerIndex.from_flat_kmers(fl, modulo=200003)
+    o = oracle.index_build(fl._hashes, fl._nodes, fl._ref_offsets, fl._allele_frequencies, modulo=200003)
+    for name in ("_hashes_to_index", "_n_kmers", "_kmers", "_nodes", "_ref_offsets", "_allele_frequencies", "_frequencies"):
+        assert getattr(idx, name).dtype == o[name].dtype, name
+        assert np.array_equal(getattr(idx, name), o[name]), name
+    assert idx.get_frequency(int(fl._hashes[0])) >= 1
