@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Headline benchmark: k-mers hashed+indexed per second, k=31, synthetic 3 Gbp linear-ref obgraph + 5 M SNP
+bubbles (BASELINE.json configs[2]), DenseKmerFinder -> FlatKmers columns resident in HBM (what the reference's
+`graph_kmer_index index` command computes, command_line_interface.py:553-622).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the environment under torch.distributed.run).  Every rank
+holds the whole graph and runs the critical-path range `sharding.shard_range` gives it (strong scaling: the 3 Gbp
+graph is fixed); there is no collective in the timed region.  torch.distributed (gloo) is used only for the barrier
+and the max-over-ranks of the timing -- the compute path is libgki_hip.so through ctypes.
+
+A step = gki_finder_count (boundary count kernel + prefix sums) + gki_finder_emit_flat (interior + boundary emit
+kernels) over the rank's shard, inputs (graph arrays) already in HBM.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+BYTES_PER_RECORD = 25            # 1 B of node sequence read + 24 B FlatKmers row written
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(sample_bases, k, max_variant_nodes):
+    """The oracle (scalar C restatement of the reference's DFS, 1 core) on a down-scaled graph from the same
+    generator and seed -- a reported baseline, not the thing measured above."""
+    from graph_kmer_index_amd.graph import synthetic_snp_graph
+    from oracle import oracle
+    sites = max(1, sample_bases // 600)
+    g = synthetic_snp_graph(sample_bases, sites, k=k, seed=1234)
+    crit = oracle.critical_paths(g, k)
+    t0 = time.perf_counter()
+    out = oracle.find(g, k, crit, True, max_variant_nodes)
+    dt = time.perf_counter() - t0
+    n = len(out["kmers"])
+    return {"value": n / dt, "unit": "k-mers/s", "cores": 1, "kind": "port",
+            "sample": "oracle/gki_oracle.c DenseKmerFinder restatement (find + v2 columns), same generator/seed, "
+                      "%d ref bases + %d SNP bubbles, %d records in %.1f s" % (sample_bases, sites, n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--bases", type=float, default=3e9, help="reference bases of the synthetic graph")
+    ap.add_argument("--sites", type=float, default=5e6, help="SNP bubbles")
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--max-variant-nodes", type=int, default=5)      # CLI `index` default, command_line_interface.py:637
+    ap.add_argument("--cpu-sample-bases", type=float, default=3e7)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="size-independent checks on the full output (slow)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log("WORLD_SIZE=%d but --gpus=%d; using WORLD_SIZE" % (world, args.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist            # gloo: barrier + max of a scalar only
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    from graph_kmer_index_amd import _lib, DenseKmerFinder, CriticalGraphPaths, DeviceGraph
+    from graph_kmer_index_amd.graph import synthetic_snp_graph
+    from graph_kmer_index_amd.sharding import shard_range
+    lib = _lib.load()
+    _lib.require_device()
+    n_dev = _lib.device_count()
+    _lib.check(lib.gki_set_device(local_rank % n_dev))
+
+    G, S, k = int(args.bases), int(args.sites), args.k
+    t0 = time.perf_counter()
+    g = synthetic_snp_graph(G, S, k=k, seed=1234)
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cp = CriticalGraphPaths.from_graph(g, k)
+    t_crit = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    dg = DeviceGraph(g)
+    t_up = time.perf_counter() - t0
+    if rank == 0:
+        log("graph: %d nodes, %d bases (+%d alt), %d critical points; generate %.1fs, critical paths %.2fs, "
+            "upload+prepare %.2fs" % (g.n_nodes, G, len(g.seq) - G, len(cp), t_gen, t_crit, t_up))
+    g._device = dg
+    a, b = shard_range(g, cp, rank, world)
+    finder = DenseKmerFinder(g, k, critical_graph_paths=cp, only_save_one_node_per_kmer=True,
+                             max_variant_nodes=args.max_variant_nodes,
+                             start_at_critical_path_number=a if world > 1 else None,
+                             stop_at_critical_path_number=b if world > 1 else None)
+
+    def barrier():
+        _lib.check(lib.gki_device_synchronize())
+        if dist is not None:
+            dist.barrier()
+
+    out = None
+    interior_ms = []
+    for _ in range(args.warmup):
+        out = finder.find_flat_on_device(out)
+        finder.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = finder.find_flat_on_device(out)
+        finder.synchronize()
+        interior_ms.append(finder.kernel_ms(1))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    n_local = out.n
+    kern = {name: finder.kernel_ms(i) for i, name in enumerate(["count_boundary", "emit_interior", "emit_boundary", "setup_scans"])}
+    n_interior = finder.interior_records()
+
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0])
+        nn = torch.tensor([n_local], dtype=torch.int64)
+        dist.all_reduce(nn, op=dist.ReduceOp.SUM)
+        n_total = int(nn[0])
+    else:
+        n_total = n_local
+
+    checks = None
+    if args.verify:
+        checks = verify(out, g, k)
+
+    if rank == 0:
+        ms_step = 1000.0 * elapsed / args.steps
+        value = n_total * args.steps / elapsed
+        avg_int_ms = float(np.mean(interior_ms))
+        achieved = BYTES_PER_RECORD * n_interior / (avg_int_ms * 1e-3) / 1e9
+        res = {
+            "metric": "k-mers hashed+indexed per second (k=31, 3 Gbp graph)", "value": value, "unit": "k-mers/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: synthetic %.3g bp linear-ref obgraph + %.3g SNP bubbles, k=%d, "
+                                   "DenseKmerFinder -> FlatKmers (hash u64, node u32, ref_offset u64, af f32) in HBM"
+                                   % (G, S, k),
+                       "n_ref_bases": G, "n_snp_bubbles": int(S), "k": k, "max_variant_nodes": args.max_variant_nodes,
+                       "only_save_one_node_per_kmer": True, "records_per_step": n_total, "n_nodes": int(g.n_nodes),
+                       "sharding": "critical-path ranges balanced by bases, whole graph resident on every GPU"},
+            "roofline": {"bound": "hbm", "kernel": "k_emit_interior", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_record": BYTES_PER_RECORD, "records_per_launch": int(n_interior),
+                         "avg_launch_ms": avg_int_ms},
+            "kernels_ms_rank0_last_step": kern,
+            "setup_s": {"generate_graph_host": t_gen, "critical_paths_host": t_crit, "upload_and_prepare": t_up},
+        }
+        if checks is not None:
+            res["verify"] = checks
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(int(args.cpu_sample_bases), k, args.max_variant_nodes)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def verify(out, g, k):
+    """Size-independent properties of the full-size output (tests/ compare small sizes with the oracle)."""
+    import numpy as np
+    n = out.n
+    step = max(1, n // 2_000_000)
+    h = out.hashes.to_host(n)[::step]
+    ro = out.ref_offsets.to_host(n)[::step]
+    nodes = out.nodes.to_host(n)[::step]
+    pos_all = ro.astype(np.int64)
+    ok_sorted = bool(np.all(np.diff(np.searchsorted(g.seq_start, pos_all, side="right")) >= 0))   # end-node order
+    ok_range = bool(h.max() < 4 ** k)
+    # the hash of a record equals the k bases read backwards from its end position whenever the end node is long
+    # enough to contain the window (interior records)
+    pos = ro.astype(np.int64)                                         # default position id == global base index
+    node_of = np.searchsorted(g.seq_start, pos, side="right") - 1
+    inside = (pos - g.seq_start[node_of]) >= k - 1
+    idx = np.nonzero(inside)[0][:200000]
+    win = pos[idx][:, None] - (k - 1) + np.arange(k)[None, :]
+    expect = (g.seq[win].astype(np.uint64) << (2 * np.arange(k, dtype=np.uint64))[None, :]).sum(axis=1)
+    ok_hash = bool(np.array_equal(expect, h[idx])) and bool(np.array_equal(nodes[idx], node_of[idx].astype(np.uint32)))
+    return {"sampled": int(len(h)), "end_nodes_sorted": ok_sorted, "hash_lt_4^k": ok_range,
+            "interior_hash_recomputed": ok_hash}
+
+
+if __name__ == "__main__":
+    main()

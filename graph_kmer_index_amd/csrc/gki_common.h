@@ -44,7 +44,7 @@ __device__ __forceinline__ uint64_t gki_extract(const uint64_t *__restrict__ seq
     int sh = (int)(P & 31) * 2;
     uint64_t lo = seq2[w];
     uint64_t hi = seq2[w + 1];
-    uint64_t v = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    uint64_t v = (lo >> sh) | ((hi << 1) << (63 - sh));       // branch-free funnel shift (sh may be 0)
     return v & ((1ull << (2 * t)) - 1ull);   // t <= 31
 }
 

@@ -4,26 +4,30 @@
 // emits, for every base position e = (node, offset) and every backward path P of exactly k real
 // bases ending at e whose window holds at most `max_variant_nodes` non-linear-ref nodes, one record
 // per distinct node of P.  End positions are independent, so
-//   * positions whose window lies inside their own node ("interior": offset >= bnd_len[node],
+//   * positions whose window lies inside their own node ("interior": offset >= bnd_len(node),
 //     normally k-1) have exactly one window and one node: a pure streaming kernel
-//     (k_emit_interior) -- this is ~90-100% of all records;
-//   * the first bnd_len bases of every node ("boundary") walk the predecessor lists backwards with
-//     a small per-lane stack (k_count_boundary / k_emit_boundary).
-// Output slots come from a count pass + exclusive scans, never from atomics, so the record order is
-// deterministic: by (node id, offset), windows in predecessor-list order, nodes ascending.
+//     (k_emit_interior) -- ~90-100% of all records;
+//   * the first bnd_len bases of a node ("boundary") share one predecessor tree: ONE lane walks it
+//     once per node and, each time it steps onto a predecessor q with c context bases already
+//     collected, completes the windows of every offset o with c < k-1-o <= c+size(q) from a single
+//     62-bit context register (k_count_boundary / k_emit_boundary).
+// Output slots come from a count pass + one exclusive scan over nodes, never from atomics, so the
+// record order is deterministic: by end node; inside a node first the boundary windows in walk
+// order (offset ascending inside one step, nodes of a window ascending), then the interior offsets.
 #include "gki_common.h"
 #include <limits.h>
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
 constexpr int MAXN = GKI_MAX_WINDOW_NODES;
 
-struct NodeEmit {       // per-node constants of the interior kernel, 32 B, one 2x16-B gather
-    int64_t seq_start;  // global base index of (node, 0)
+struct NodeEmit {       // per-node constants of the interior kernel, 32 B
+    int64_t glo;        // global base index of the first interior position of this node in this run
     int64_t D;          // record index of interior position p is p + D
     int64_t E;          // position id of base p is p + E
-    int32_t lo;         // first interior offset of this node in this run
+    int32_t node;       // node id
     float af;           // allele frequency as float32 (flat_kmers.py:90)
 };
 
@@ -34,131 +38,6 @@ struct FindArgs {
 
 struct OutFlat { uint64_t *hash; uint32_t *node; uint64_t *ref_offset; float *af; };
 struct OutV2 { int64_t *hash; int32_t *start_node; int16_t *start_offset; int32_t *node; double *af; };
-
-__device__ __forceinline__ bool in_range(const FindArgs &a, int64_t n, int64_t o) {
-    if (n < a.node_begin || n > a.node_end) return false;
-    if (n == a.node_begin && o < a.off_begin) return false;
-    if (n == a.node_end && o >= a.off_end) return false;
-    return true;
-}
-
-// SURVEY.md 8a' E1: a restart at a critical point (N, c) with 0 < c < k-1 is not rewound
-// (kmer_finder.py:231-232), so no window contains both (N, c-1) and (N, c).
-__device__ __forceinline__ bool lossy_hit(const uint16_t *__restrict__ lossy, int32_t node, int a, int b) {
-    int c = lossy[node];
-    return c != 0xFFFF && a <= c - 1 && c <= b;
-}
-
-// ------------------------------------------------------------------------------------ per-node setup
-__global__ __launch_bounds__(256) void k_node_setup(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
-                                                    int32_t *__restrict__ bnd_len, int32_t *__restrict__ icnt) {
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < g.n_nodes; n += stride) {
-        int32_t size = g.node_size[n];
-        int32_t bl = 0, ic = 0;
-        if (n >= a.node_begin && n <= a.node_end && size > 0) {
-            int32_t reach = a.k - 1;                                       // offsets < k-1 look into predecessors
-            if (a.has_lossy && lossy[n] != 0xFFFF) reach = lossy[n] + a.k - 1;   // E1 windows end up to c+k-2
-            if (!g.is_ref[n] && a.M < 1) reach = size;                     // variant node, limit 0: nothing admissible
-            bl = size < reach ? size : reach;
-            int64_t lo = bl, hi = size;
-            if (n == a.node_begin && a.off_begin > lo) lo = a.off_begin;
-            if (n == a.node_end && a.off_end < hi) hi = a.off_end;
-            ic = hi > lo ? (int32_t)(hi - lo) : 0;
-        }
-        bnd_len[n] = bl;
-        icnt[n] = ic;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_node_emit(DevGraph g, FindArgs a, const int32_t *__restrict__ bnd_len,
-                                                   const int64_t *__restrict__ bnd_start,
-                                                   const int64_t *__restrict__ bscan,
-                                                   const int64_t *__restrict__ iscan, NodeEmit *__restrict__ ne) {
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < g.n_nodes; n += stride) {
-        NodeEmit e;
-        int64_t lo = bnd_len[n];
-        if (n == a.node_begin && a.off_begin > lo) lo = a.off_begin;
-        e.seq_start = g.seq_start[n];
-        e.lo = (int32_t)lo;
-        e.D = bscan[bnd_start[n + 1]] + iscan[n] - lo - e.seq_start;
-        e.E = g.pos_base[n] - e.seq_start;
-        e.af = (float)g.allele_freq[n];
-        ne[n] = e;
-    }
-}
-
-// ------------------------------------------------------------------------------------ backward windows
-// Depth-first walk over predecessor lists from end position (n, o).  on_window(L) is called with
-// nd[0..L) = nodes of the window (end node first) and na[j] = bases still missing after level j.
-template <bool HAS_LOSSY, typename F>
-__device__ __forceinline__ uint32_t walk_windows(const DevGraph &g, const uint16_t *__restrict__ lossy, int k, int M,
-                                                 int32_t n, int32_t o, int32_t *nd, int32_t *cur, uint8_t *na,
-                                                 uint8_t *vc, int *err, F &&on_window) {
-    int t = o + 1 < k ? o + 1 : k;
-    if (HAS_LOSSY && lossy_hit(lossy, n, o + 1 - t, o)) return 0;
-    int v = g.is_ref[n] ? 0 : 1;
-    if (v > M) return 0;
-    nd[0] = n; na[0] = (uint8_t)(k - t); vc[0] = (uint8_t)v;
-    if (k - t == 0) return on_window(1);
-    cur[0] = (int32_t)g.rev_start[n];
-    uint32_t total = 0;
-    int L = 1;
-    while (L > 0) {
-        const int j = L - 1;
-        const int32_t e = cur[j];
-        if ((int64_t)e >= g.rev_start[nd[j] + 1]) { L--; continue; }
-        cur[j] = e + 1;
-        const int32_t q = g.rev_edges[e];
-        const int vq = vc[j] + (g.is_ref[q] ? 0 : 1);
-        if (vq > M) continue;                       // kmer_finder.py:391-403 in order-free form
-        if (L >= MAXN) { *err = GKI_ERR_WINDOW_TOO_DEEP; continue; }
-        const int s = g.node_size[q];
-        const int need = na[j];
-        nd[L] = q; vc[L] = (uint8_t)vq;
-        if (s == 0) {                               // empty node: in the node set, adds no base (:261-265)
-            na[L] = (uint8_t)need; cur[L] = (int32_t)g.rev_start[q]; L++;
-            continue;
-        }
-        const int tq = s < need ? s : need;
-        if (HAS_LOSSY && lossy_hit(lossy, q, s - tq, s - 1)) continue;
-        na[L] = (uint8_t)(need - tq);
-        if (need == tq) { total += on_window(L + 1); continue; }
-        cur[L] = (int32_t)g.rev_start[q]; L++;
-    }
-    return total;
-}
-
-__device__ __forceinline__ int64_t node_of_boundary_index(const int64_t *__restrict__ bnd_start, int64_t n_nodes, int64_t i) {
-    int64_t lo = 0, hi = n_nodes;           // largest n with bnd_start[n] <= i
-    while (hi - lo > 1) {
-        int64_t mid = (lo + hi) >> 1;
-        if (bnd_start[mid] <= i) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
-template <bool HAS_LOSSY>
-__global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
-                                                        const int64_t *__restrict__ bnd_start, int64_t B,
-                                                        uint32_t *__restrict__ cnt, int *__restrict__ err) {
-    int32_t nd[MAXN], cur[MAXN];
-    uint8_t na[MAXN], vc[MAXN];
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += stride) {
-        int64_t n = node_of_boundary_index(bnd_start, g.n_nodes, i);
-        int32_t o = (int32_t)(i - bnd_start[n]);
-        uint32_t c = 0;
-        if (in_range(a, n, o)) {
-            const bool one = a.one_node;
-            c = walk_windows<HAS_LOSSY>(g, lossy, a.k, a.M, (int32_t)n, o, nd, cur, na, vc, err,
-                                        [&](int L) -> uint32_t { return one ? 1u : (uint32_t)L; });
-        }
-        cnt[i] = c;
-    }
-}
-
 template <int FMT> struct OutSel;
 template <> struct OutSel<0> { typedef OutFlat T; };
 template <> struct OutSel<1> { typedef OutV2 T; };
@@ -181,139 +60,474 @@ __device__ __forceinline__ void put(const OutV2 &o, int64_t idx, uint64_t h, int
     if (o.af) o.af[idx] = af;
 }
 
-template <bool HAS_LOSSY, int FMT>
-__global__ __launch_bounds__(256) void k_emit_boundary(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
-                                                       const int64_t *__restrict__ bnd_start, int64_t B,
-                                                       const int64_t *__restrict__ bscan,
-                                                       const int64_t *__restrict__ iscan,
-                                                       typename OutSel<FMT>::T out, int *__restrict__ err) {
-    int32_t nd[MAXN], cur[MAXN];
-    uint8_t na[MAXN], vc[MAXN];
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += stride) {
-        if (bscan[i + 1] == bscan[i]) continue;           // nothing to write for this position
-        int64_t n = node_of_boundary_index(bnd_start, g.n_nodes, i);
-        int32_t o = (int32_t)(i - bnd_start[n]);
-        int64_t idx = bscan[i] + iscan[n];
-        const int64_t pos_id = g.pos_base[n] + o;
-        const int k = a.k;
-        const bool one = a.one_node;
-        walk_windows<HAS_LOSSY>(g, lossy, k, a.M, (int32_t)n, o, nd, cur, na, vc, err, [&](int L) -> uint32_t {
-            uint64_t h = 0;
-            int32_t mn = INT_MAX;
-            double maf = INFINITY;
-            int need_before = k;
-            for (int j = 0; j < L; j++) {
-                const int32_t q = nd[j];
-                mn = q < mn ? q : mn;
-                maf = fmin(maf, g.allele_freq[q]);               // np.min, kmer_finder.py:143
-                const int t = need_before - na[j];
-                if (t > 0) {
-                    const int avail = j == 0 ? o + 1 : g.node_size[q];
-                    h |= gki_extract(g.seq2, g.seq_start[q] + avail - t, t) << (2 * na[j]);
-                }
-                need_before = na[j];
-            }
-            if (one) {                                            // :145-146 nodes[0] of np.unique
-                put(out, idx, h, mn, (int32_t)n, o, pos_id, maf);
-                idx++;
-                return 1u;
-            }
-            // one record per distinct node, ascending (np.unique, :134): selection by repeated minimum
-            int32_t last = INT_MIN;
-            for (int r = 0; r < L; r++) {
-                int32_t best = INT_MAX;
-                for (int j = 0; j < L; j++) { int32_t q = nd[j]; if (q > last && q < best) best = q; }
-                put(out, idx, h, best, (int32_t)n, o, pos_id, maf);
-                idx++;
-                last = best;
-            }
-            return (uint32_t)L;
-        });
-    }
+// SURVEY.md 8a' E1: a restart at a critical point (N, c) with 0 < c < k-1 is not rewound
+// (kmer_finder.py:231-232), so no window contains both (N, c-1) and (N, c).
+__device__ __forceinline__ int lossy_of(const uint16_t *__restrict__ lossy, int32_t node) {
+    int c = lossy[node];
+    return c == 0xFFFF ? -1 : c;
 }
 
-// ------------------------------------------------------------------------------------ interior stream
-// One wave per 64-base word of the sequence, WPW consecutive words per wave trip.  Lane l owns base
-// p = 64*w + l: node = rank + popcount(mask bits <= l) - 1 (wave-uniform mask/rank), per-node
-// constants from one 32-B gather, hash = 2k-bit field of the 2-bit stream, four coalesced stores.
-constexpr int WPW = 8;
+// Number of leading offsets of node n that are handled by the boundary walk.
+__device__ __forceinline__ int32_t bnd_len_of(const DevGraph &g, const FindArgs &a, const uint16_t *__restrict__ lossy,
+                                              int64_t n, int32_t size) {
+    if (n < a.node_begin || n > a.node_end || size <= 0) return 0;
+    int32_t reach = a.k - 1;                                          // offsets < k-1 look into predecessors
+    if (a.has_lossy && lossy[n] != 0xFFFF) reach = lossy[n] + a.k - 1;      // E1 windows end up to c+k-2
+    if (!g.is_ref[n] && a.M < 1) reach = size;                        // variant node, limit 0: nothing admissible
+    return size < reach ? size : reach;
+}
 
-template <int FMT>
-__global__ __launch_bounds__(256) void k_emit_interior(DevGraph g, FindArgs a, const NodeEmit *__restrict__ ne,
-                                                       typename OutSel<FMT>::T out, int64_t word_begin,
-                                                       int64_t word_end) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+// ------------------------------------------------------------------------------------ boundary walk
+// One lane per node: depth-first over predecessor lists with an explicit stack.  The Emitter hooks:
+//   own_window(o)                 the window of offset o lies inside the node itself (o >= k-1; E1 nodes only)
+//   begin(hi)                     offsets [.., hi) need context bases
+//   step(L, q, s, c, from, to)    stepping onto q = nd[L-1] (size s) with c context bases collected before it
+//                                 completes the windows of offsets [from, to); nd[0..L) are their nodes
+//   push_empty / push_full        the walk descends below an empty node / below q taking all its bases
+struct WalkStack {
+    int32_t nd[MAXN], cur[MAXN], end[MAXN];
+    uint8_t cum[MAXN], vc[MAXN];
+};
+
+template <bool HAS_LOSSY, typename Emitter>
+__device__ __forceinline__ void walk_node(const DevGraph &g, const FindArgs &a, const uint16_t *__restrict__ lossy,
+                                          int32_t n, int32_t bl, WalkStack &st, int *err, Emitter &em) {
     const int k = a.k;
-    const uint64_t lane_mask = ~0ull >> (63 - lane);       // bits 0..lane
-    for (int64_t w0 = word_begin + wave * WPW; w0 < word_end; w0 += n_waves * WPW) {
-#pragma unroll
-        for (int u = 0; u < WPW; u++) {
-            const int64_t w = w0 + u;
-            if (w >= word_end) break;
-            const uint64_t mask = g.start_mask[w];
-            const uint32_t rank = g.start_rank[w];
-            const int64_t p = w * 64 + lane;
-            if (p >= g.n_bases) continue;
-            const uint32_t j = rank + (uint32_t)__popcll(mask & lane_mask) - 1u;
-            const int32_t n = g.nonempty[j];
-            const NodeEmit e = ne[n];
-            const int64_t o = p - e.seq_start;
-            if (o < e.lo) continue;
-            if (n < a.node_begin || n > a.node_end) continue;
-            if (n == a.node_end && o >= a.off_end) continue;
-            const uint64_t h = gki_extract(g.seq2, p - (k - 1), k);
-            const double af = FMT == 1 ? g.allele_freq[n] : (double)e.af;   // v2 keeps float64 (kmer_finder.py:58)
-            put(out, p + e.D, h, n, n, (int32_t)o, p + e.E, af);
+    const int o_lo = (n == a.node_begin) ? (int)(a.off_begin < bl ? a.off_begin : bl) : 0;
+    const int o_hi = (n == a.node_end) ? (int)(a.off_end < bl ? a.off_end : bl) : bl;
+    if (o_lo >= o_hi) return;
+    const int v0 = g.is_ref[n] ? 0 : 1;
+    if (v0 > a.M) return;
+    const int cn = HAS_LOSSY ? lossy_of(lossy, n) : -1;
+    // windows inside the node (only nodes whose boundary reaches past k-1: lossy restarts)
+    for (int o = o_lo > k - 1 ? o_lo : k - 1; o < o_hi; o++) {
+        if (HAS_LOSSY && cn >= 0 && o + 1 - k <= cn - 1 && cn <= o) continue;
+        em.own_window(o);
+    }
+    int hi = o_hi < k - 1 ? o_hi : k - 1;
+    if (HAS_LOSSY && cn >= 1 && cn < hi) hi = cn;          // offsets >= c would span (c-1, c)
+    if (o_lo >= hi) return;
+    st.nd[0] = n; st.cur[0] = (int32_t)g.rev_start[n]; st.end[0] = (int32_t)g.rev_start[n + 1];
+    st.cum[0] = 0; st.vc[0] = (uint8_t)v0;
+    em.begin(hi);
+    int L = 1;
+    while (L > 0) {
+        const int j = L - 1;
+        const int32_t e = st.cur[j];
+        if (e >= st.end[j]) { L--; continue; }
+        st.cur[j] = e + 1;
+        const int32_t q = g.rev_edges[e];
+        const int vq = st.vc[j] + (g.is_ref[q] ? 0 : 1);
+        if (vq > a.M) continue;                          // kmer_finder.py:391-403 in order-free form
+        if (L >= MAXN - 1) { *err = GKI_ERR_WINDOW_TOO_DEEP; continue; }
+        const int s = g.node_size[q];
+        const int c = st.cum[j];
+        st.nd[L] = q; st.vc[L] = (uint8_t)vq;
+        if (s == 0) {                                    // empty node: in the node set, adds no base (:261-265)
+            st.cum[L] = (uint8_t)c; st.cur[L] = (int32_t)g.rev_start[q]; st.end[L] = (int32_t)g.rev_start[q + 1];
+            em.push_empty(L);
+            L++;
+            continue;
+        }
+        // offsets completing inside q: c < k-1-o <= c+s
+        int from = k - 1 - c - s; if (from < o_lo) from = o_lo;
+        int to = k - 1 - c; if (to > hi) to = hi;
+        const int cq = HAS_LOSSY ? lossy_of(lossy, q) : -1;
+        if (HAS_LOSSY && cq >= 0) {
+            // a window taking t = k-1-o-c bases of q covers its offsets s-t .. s-1: forbidden when s-t <= cq-1,
+            // i.e. o <= k-1-c-s+cq-1
+            const int min_ok = k - 1 - c - s + cq;
+            if (from < min_ok) from = min_ok;
+        }
+        if (from < to) em.step(L + 1, q, s, c, from, to);
+        const bool deeper = (k - 1 - c - s > o_lo) && !(HAS_LOSSY && cq >= 1);
+        if (deeper) {
+            st.cum[L] = (uint8_t)(c + s); st.cur[L] = (int32_t)g.rev_start[q]; st.end[L] = (int32_t)g.rev_start[q + 1];
+            em.push_full(L, q, s, c);
+            L++;
         }
     }
 }
 
-__global__ void k_totals(const int64_t *bscan, int64_t B, const int64_t *iscan, int64_t n_nodes, const int *err,
-                         int64_t *out3) {
-    out3[0] = bscan[B];
-    out3[1] = iscan[n_nodes];
-    out3[2] = *err;
+struct CountEmitter {
+    uint32_t count; bool one;
+    __device__ __forceinline__ void own_window(int) { count += 1; }
+    __device__ __forceinline__ void begin(int) {}
+    __device__ __forceinline__ void push_empty(int) {}
+    __device__ __forceinline__ void push_full(int, int32_t, int, int) {}
+    __device__ __forceinline__ void step(int L, int32_t, int, int, int from, int to) {
+        count += (uint32_t)(to - from) * (one ? 1u : (uint32_t)L);
+    }
+};
+
+template <bool HAS_LOSSY>
+__global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
+                                                        uint32_t *__restrict__ bcount, uint32_t *__restrict__ total,
+                                                        int *__restrict__ err) {
+    WalkStack st;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < g.n_nodes; n += stride) {
+        const int32_t size = g.node_size[n];
+        const int32_t bl = bnd_len_of(g, a, lossy, n, size);
+        CountEmitter em{0u, a.one_node != 0};
+        if (bl > 0) walk_node<HAS_LOSSY>(g, a, lossy, (int32_t)n, bl, st, err, em);
+        uint32_t ic = 0;                              // interior offsets of this node in this run
+        if (n >= a.node_begin && n <= a.node_end && size > 0) {
+            int64_t lo = bl, hi = size;
+            if (n == a.node_begin && a.off_begin > lo) lo = a.off_begin;
+            if (n == a.node_end && a.off_end < hi) hi = a.off_end;
+            ic = hi > lo ? (uint32_t)(hi - lo) : 0u;
+        }
+        bcount[n] = em.count;
+        total[n] = em.count + ic;
+    }
+}
+
+// Emit pass.  Each lane walks the predecessor tree of one node (as in the count pass); whenever a lane
+// has a finished step -- a run of offsets [from, to) that share one context register and one node
+// list -- the WAVE writes that run together: ballot over the lanes holding a step, broadcast the
+// step's constants from its lane, lane t writes record t.  A step of a SNP join node is ~30 records,
+// i.e. 240 contiguous bytes of hashes per store instruction instead of 64 scattered 8-byte stores.
+// Steps are issued in post-order (a node's own step after the steps below it), so the offsets of a
+// single predecessor chain come out ascending: on a linear graph the order is the reference's.
+template <bool HAS_LOSSY, int FMT>
+__global__ __launch_bounds__(256) void k_emit_boundary(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
+                                                       const uint32_t *__restrict__ bcount,
+                                                       const int64_t *__restrict__ rec_base,
+                                                       typename OutSel<FMT>::T out, int *__restrict__ err) {
+    __shared__ int32_t s_nodes[4][MAXN];
+    WalkStack st;
+    uint8_t evf[MAXN], evt[MAXN];
+    uint64_t ctx[MAXN];                 // context bases collected through level j; the d-th base before the end node
+                                        // sits in 2-bit slot k-1-d, so the window of offset o is (ctx >> 2o) | own << 2(k-1-o)
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k = a.k;
+    const uint64_t kmask = (1ull << (2 * k)) - 1ull;
+    const int64_t n_threads = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + wib * 64; base < g.n_nodes; base += n_threads) {
+        const int64_t n = base + lane;
+        int L = 0, o_lo = 0, hi = 0;
+        int64_t idx = 0, pos0 = 0;
+        uint64_t own = 0;
+        if (n < g.n_nodes && bcount[n] > 0) {
+            const int32_t size = g.node_size[n];
+            const int32_t bl = bnd_len_of(g, a, lossy, n, size);
+            idx = rec_base[n];
+            pos0 = g.pos_base[n];
+            o_lo = (n == a.node_begin) ? (int)(a.off_begin < bl ? a.off_begin : bl) : 0;
+            const int o_hi = (n == a.node_end) ? (int)(a.off_end < bl ? a.off_end : bl) : bl;
+            const int v0 = g.is_ref[n] ? 0 : 1;
+            const int cn = HAS_LOSSY ? lossy_of(lossy, (int32_t)n) : -1;
+            if (o_lo < o_hi && v0 <= a.M) {
+                // windows inside the node itself (lossy-restart nodes only; rare, written by the lane alone)
+                for (int o = o_lo > k - 1 ? o_lo : k - 1; o < o_hi; o++) {
+                    if (HAS_LOSSY && cn >= 0 && o + 1 - k <= cn - 1 && cn <= o) continue;
+                    put(out, idx++, gki_extract(g.seq2, g.seq_start[n] + o + 1 - k, k), (int32_t)n, (int32_t)n, o, pos0 + o,
+                        g.allele_freq[n]);
+                }
+                hi = o_hi < k - 1 ? o_hi : k - 1;
+                if (HAS_LOSSY && cn >= 1 && cn < hi) hi = cn;
+                if (o_lo < hi) {
+                    st.nd[0] = (int32_t)n; st.cur[0] = (int32_t)g.rev_start[n]; st.end[0] = (int32_t)g.rev_start[n + 1];
+                    st.cum[0] = 0; st.vc[0] = (uint8_t)v0;
+                    evf[0] = evt[0] = 0; ctx[0] = 0;
+                    own = gki_extract(g.seq2, g.seq_start[n], hi);
+                    L = 1;
+                }
+            }
+        }
+        while (__any(L > 0)) {
+            bool ev = false;
+            int e_from = 0, e_to = 0, e_L = 0;
+            uint64_t e_ctx = 0;
+            if (L > 0) {
+                const int j = L - 1;
+                const int32_t e = st.cur[j];
+                if (e >= st.end[j]) {                       // leave level j: its own step comes after its subtree
+                    if (evf[j] < evt[j]) { ev = true; e_from = evf[j]; e_to = evt[j]; e_L = j + 1; e_ctx = ctx[j]; }
+                    L--;
+                } else {
+                    st.cur[j] = e + 1;
+                    const int32_t q = g.rev_edges[e];
+                    const int vq = st.vc[j] + (g.is_ref[q] ? 0 : 1);
+                    if (vq <= a.M) {
+                        if (L >= MAXN - 1) {
+                            *err = GKI_ERR_WINDOW_TOO_DEEP;
+                        } else {
+                            const int s = g.node_size[q];
+                            const int c = st.cum[j];
+                            st.nd[L] = q; st.vc[L] = (uint8_t)vq;
+                            if (s == 0) {
+                                st.cum[L] = (uint8_t)c; st.cur[L] = (int32_t)g.rev_start[q]; st.end[L] = (int32_t)g.rev_start[q + 1];
+                                evf[L] = evt[L] = 0; ctx[L] = ctx[j];
+                                L++;
+                            } else {
+                                int from = k - 1 - c - s; if (from < o_lo) from = o_lo;
+                                int to = k - 1 - c; if (to > hi) to = hi;
+                                const int cq = HAS_LOSSY ? lossy_of(lossy, q) : -1;
+                                if (HAS_LOSSY && cq >= 0) { const int min_ok = k - 1 - c - s + cq; if (from < min_ok) from = min_ok; }
+                                const int tq = s < k - 1 - c ? s : k - 1 - c;
+                                const uint64_t cx = ctx[j] | (gki_extract(g.seq2, g.seq_start[q] + s - tq, tq) << (2 * (k - 1 - c - tq)));
+                                const bool deeper = (k - 1 - c - s > o_lo) && !(HAS_LOSSY && cq >= 1);
+                                if (deeper) {
+                                    st.cum[L] = (uint8_t)(c + s); st.cur[L] = (int32_t)g.rev_start[q]; st.end[L] = (int32_t)g.rev_start[q + 1];
+                                    evf[L] = (uint8_t)(from < to ? from : 0); evt[L] = (uint8_t)(from < to ? to : 0); ctx[L] = cx;
+                                    L++;
+                                } else if (from < to) {
+                                    ev = true; e_from = from; e_to = to; e_L = L + 1; e_ctx = cx;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            int32_t mn = INT_MAX;
+            double maf = INFINITY;
+            if (ev) {
+                for (int j = 0; j < e_L; j++) {
+                    const int32_t q = st.nd[j];
+                    mn = q < mn ? q : mn;
+                    maf = fmin(maf, g.allele_freq[q]);                // np.min, kmer_finder.py:143
+                }
+            }
+            uint64_t pending = __ballot(ev);
+            while (pending) {
+                const int src = __builtin_ctzll(pending);
+                pending &= pending - 1;
+                const uint64_t b_ctx = __shfl(e_ctx, src, 64), b_own = __shfl(own, src, 64);
+                const int b_from = __shfl(e_from, src, 64), b_cnt = __shfl(e_to, src, 64) - b_from, b_L = __shfl(e_L, src, 64);
+                const int64_t b_idx = __shfl(idx, src, 64), b_pos0 = __shfl(pos0, src, 64);
+                const int32_t b_mn = __shfl(mn, src, 64);
+                const double b_maf = __shfl(maf, src, 64);
+                const int32_t b_n = (int32_t)(base + src);
+                if (a.one_node) {                                     // :145-146 nodes[0] of np.unique
+                    if (lane < b_cnt) {
+                        const int o = b_from + lane;
+                        const uint64_t h = ((b_ctx >> (2 * o)) | (b_own << (2 * (k - 1 - o)))) & kmask;
+                        put(out, b_idx + lane, h, b_mn, b_n, o, b_pos0 + o, b_maf);
+                    }
+                    if (lane == src) idx += b_cnt;
+                } else {
+                    if (lane == src) {                                // ascending distinct nodes (np.unique :134)
+                        int32_t last = INT_MIN;
+                        for (int r = 0; r < e_L; r++) {
+                            int32_t best = INT_MAX;
+                            for (int j = 0; j < e_L; j++) { const int32_t q = st.nd[j]; if (q > last && q < best) best = q; }
+                            s_nodes[wib][r] = best;
+                            last = best;
+                        }
+                        idx += (int64_t)b_cnt * b_L;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const int total = b_cnt * b_L;
+                    for (int t = lane; t < total; t += 64) {
+                        const int o = b_from + t / b_L;
+                        const uint64_t h = ((b_ctx >> (2 * o)) | (b_own << (2 * (k - 1 - o)))) & kmask;
+                        put(out, b_idx + t, h, s_nodes[wib][t % b_L], b_n, o, b_pos0 + o, b_maf);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ per-node constants
+__global__ __launch_bounds__(256) void k_node_emit(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
+                                                   const uint32_t *__restrict__ bcount,
+                                                   const int64_t *__restrict__ rec_base, NodeEmit *__restrict__ ne) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < g.n_nonempty; j += stride) {
+        const int32_t n = g.nonempty[j];
+        const int32_t size = g.node_size[n];
+        int64_t lo = bnd_len_of(g, a, lossy, n, size);
+        if (n == a.node_begin && a.off_begin > lo) lo = a.off_begin;
+        const int64_t ss = g.seq_start[n];
+        NodeEmit e;
+        e.glo = (n < a.node_begin || n > a.node_end) ? (int64_t)0x7FFFFFFFFFFFFFFFll : ss + lo;   // out of range: never
+        e.D = rec_base[n] + (int64_t)bcount[n] - lo - ss;
+        e.E = g.pos_base[n] - ss;
+        e.node = n;
+        e.af = (float)g.allele_freq[n];
+        ne[j] = e;                      // indexed by rank among non-empty nodes: what the bitmap popcount yields
+    }
+}
+
+// ------------------------------------------------------------------------------------ interior stream
+// Lane l of a wave owns base p = 64*w + l of a 64-base word w: rank of its node = rank[w] +
+// popcount(mask[w] bits <= l) - 1, per-node constants from one 32-B record, hash = 2k-bit field of the
+// 2-bit stream, four coalesced column stores.
+//
+// FlatKmers variant: LDS-staged.  Measured on MI355X: while the chip is saturated with the 24 B/record
+// output stream a dependent global load takes several microseconds, and on gfx950 vmcnt retires loads
+// and stores in order, so a load issued after a store waits for that store.  A version that did
+// mask/rank -> per-node-record gather -> store for every 64-base word ran at 2.6 TB/s; dropping only the
+// gather gave 4.5 TB/s.  So a wave now takes SW = 64 consecutive words (4096 bases) at a time:
+//   1. one coalesced load of the 64 bitmap words and ranks (lane u <-> word u), three coalesced loads of
+//      the 2-bit sequence window into LDS;
+//   2. per chunk of words whose nodes fit NE_CAP records: coalesced copy of that slice of the per-node
+//      table into LDS;
+//   3. a loop over the words that touches only registers (v_readlane of mask/rank) and LDS, and issues
+//      the four coalesced column stores back to back with no global load in between.
+constexpr int SW = 64;
+constexpr int NE_CAP = 128;
+constexpr int SEQ_W = 2 * SW + 8;
+constexpr int INTERIOR_MAX_BLOCKS = 256 * 7;
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(256) void k_emit_interior_flat(DevGraph g, FindArgs a, const NodeEmit *__restrict__ ne,
+                                                            OutFlat out, int64_t word_begin, int64_t word_end,
+                                                            int64_t p_end) {
+    __shared__ uint4 s_ne[4][NE_CAP * 2];
+    __shared__ uint64_t s_seq[4][SEQ_W];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wib;
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const int k = a.k;
+    const uint64_t kmask = (1ull << (2 * k)) - 1ull;
+    const uint64_t lane_mask = ~0ull >> (63 - lane);       // bits 0..lane
+    const int64_t n_seq_words = ((g.n_bases + 31) >> 5) + 2;
+    const uint4 *ne4 = reinterpret_cast<const uint4 *>(ne);
+    uint4 *my_ne = s_ne[wib];
+    uint64_t *my_seq = s_seq[wib];
+    for (int64_t sw0 = word_begin + wave * SW; sw0 < word_end; sw0 += n_waves * SW) {
+        const int nw = (int)((word_end - sw0) < SW ? (word_end - sw0) : SW);
+        // ---- stage 1: bitmap words, ranks, 2-bit window
+        const int64_t wl = sw0 + (lane < nw ? lane : nw - 1);
+        const uint64_t mask_v = g.start_mask[wl];
+        const uint32_t rank_v = g.start_rank[wl];
+        const int64_t sb = 2 * sw0 - 2 > 0 ? 2 * sw0 - 2 : 0;          // first staged 2-bit word
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int i = t * 64 + lane;
+            if (i < SEQ_W) {
+                int64_t gw = sb + i;
+                my_seq[i] = g.seq2[gw < n_seq_words ? gw : n_seq_words - 1];
+            }
+        }
+        const uint32_t last_j_v = rank_v + (uint32_t)__popcll(mask_v) - 1u;      // last node (rank) touching word `lane`
+        int u0 = 0;
+        while (u0 < nw) {
+            // ---- stage 2: per-node records of words [u0, u1)
+            const uint64_t m0 = readlane64(mask_v, u0);
+            const uint32_t jbase = (uint32_t)__builtin_amdgcn_readlane((int)rank_v, u0) + (uint32_t)(m0 & 1ull) - 1u;
+            const uint64_t fits = __ballot(lane >= u0 && lane < nw && (last_j_v - jbase) < (uint32_t)NE_CAP) >> u0;
+            // run of fitting words starting at u0; ctz(0) is undefined, and the loop must always advance
+            int u1 = (~fits == 0ull) ? nw : u0 + (int)__builtin_ctzll(~fits);
+            if (u1 > nw) u1 = nw;
+            if (u1 <= u0) u1 = u0 + 1;
+            const uint32_t n_rec = (uint32_t)__builtin_amdgcn_readlane((int)last_j_v, u1 - 1) - jbase + 1u;
+            for (uint32_t t = lane; t < 2u * n_rec; t += 64) my_ne[t] = ne4[2 * (int64_t)jbase + t];
+            // ---- stage 3: words of the chunk, registers + LDS only
+            for (int u = u0; u < u1; u++) {
+                const uint64_t mask = readlane64(mask_v, u);
+                const uint32_t rank = (uint32_t)__builtin_amdgcn_readlane((int)rank_v, u);
+                const int64_t p = (sw0 + u) * 64 + lane;
+                const uint32_t jj = rank + (uint32_t)__popcll(mask & lane_mask) - 1u - jbase;
+                const uint4 ea = my_ne[2 * jj], eb = my_ne[2 * jj + 1];
+                const int64_t glo = (int64_t)(((uint64_t)ea.y << 32) | ea.x);
+                const int64_t D = (int64_t)(((uint64_t)ea.w << 32) | ea.z);
+                const int64_t E = (int64_t)(((uint64_t)eb.y << 32) | eb.x);
+                if (p >= glo && p < p_end) {
+                    const int64_t P = p - (k - 1);                       // >= 0 for an interior position
+                    const int si = (int)((P >> 5) - sb);
+                    const int sh = (int)(P & 31) * 2;
+                    const uint64_t lo = my_seq[si], hi = my_seq[si + 1];
+                    const uint64_t h = ((lo >> sh) | ((hi << 1) << (63 - sh))) & kmask;
+                    const int64_t idx = p + D;
+                    out.hash[idx] = h;
+                    out.node[idx] = eb.z;
+                    out.ref_offset[idx] = (uint64_t)(p + E);
+                    out.af[idx] = __uint_as_float(eb.w);
+                }
+            }
+            u0 = u1;
+        }
+    }
+}
+
+// General variant (any subset of columns, v2 layout): same mapping, branchy.
+template <int FMT>
+__global__ __launch_bounds__(256) void k_emit_interior(DevGraph g, FindArgs a, const NodeEmit *__restrict__ ne,
+                                                       typename OutSel<FMT>::T out, int64_t word_begin,
+                                                       int64_t word_end, int64_t p_end) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int k = a.k;
+    const uint64_t lane_mask = ~0ull >> (63 - lane);
+    for (int64_t w = word_begin + wave; w < word_end; w += n_waves) {
+        const uint64_t mask = g.start_mask[w];
+        const uint32_t rank = g.start_rank[w];
+        const int64_t p = w * 64 + lane;
+        const uint32_t j = rank + (uint32_t)__popcll(mask & lane_mask) - 1u;
+        const NodeEmit e = ne[j];
+        if (p < e.glo || p >= p_end) continue;
+        const uint64_t h = gki_extract(g.seq2, p - (k - 1), k);
+        if (FMT == 0) {
+            put(out, p + e.D, h, e.node, e.node, 0, p + e.E, (double)e.af);
+        } else {
+            const int64_t o = p - g.seq_start[e.node];
+            put(out, p + e.D, h, e.node, e.node, (int32_t)o, 0, g.allele_freq[e.node]);   // v2 keeps float64 (:58)
+        }
+    }
+}
+
+__global__ void k_totals(const int64_t *rec_base, int64_t n_nodes, const int *err, int64_t *out2) {
+    out2[0] = rec_base[n_nodes];
+    out2[1] = *err;
+}
+
+__global__ __launch_bounds__(256) void k_sum_u32(const uint32_t *__restrict__ x, int64_t n, unsigned long long *__restrict__ out) {
+    unsigned long long s = 0;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += x[i];
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
 }
 
 }  // namespace
 
 struct gki_finder {
     gki_graph *g;
-    hipStream_t stream;
-    int32_t *bnd_len, *icnt;
-    int64_t *bnd_start, *iscan;
-    uint32_t *cnt; int64_t cnt_cap;
-    int64_t *bscan;
+    hipStream_t stream, stream2;
+    uint32_t *bcount, *total;
+    int64_t *rec_base;
     NodeEmit *ne;
     uint16_t *lossy;
     void *scan_tmp; int64_t scan_tmp_bytes;
-    int *d_err; int64_t *d_totals;
+    int *d_err; int64_t *d_totals; unsigned long long *d_bsum; 
     FindArgs args;
-    int64_t B, n_boundary_records, n_interior_records;
-    int64_t word_begin, word_end;
+    int64_t n_records, n_boundary_records, n_interior_records;
+    int64_t word_begin, word_end, p_end;
     bool counted;
-    hipEvent_t ev[10];   // pairs: 0/1 count-boundary, 2/3 emit-interior, 4/5 emit-boundary, 6/7 scans(count phase)
-    bool ev_valid[5];
+    hipEvent_t ev[8];    // pairs: 0/1 count-boundary, 2/3 emit-interior, 4/5 emit-boundary, 6/7 scan + per-node constants
+    hipEvent_t ev_ready, ev_join;
+    bool ev_valid[4];
 };
 
-static int ensure_cnt(gki_finder *f, int64_t B) {
-    if (B <= f->cnt_cap) return GKI_OK;
-    if (f->cnt) HIP_TRY(hipFree(f->cnt));
-    if (f->bscan) HIP_TRY(hipFree(f->bscan));
-    f->cnt = nullptr; f->bscan = nullptr; f->cnt_cap = 0;
-    int64_t cap = B + B / 8 + 1024;
-    HIP_TRY(hipMalloc((void **)&f->cnt, (size_t)cap * 4));
-    HIP_TRY(hipMalloc((void **)&f->bscan, (size_t)(cap + 1) * 8));
-    f->cnt_cap = cap;
-    int64_t need = gki_scan_tmp_bytes(cap > f->g->d.n_nodes ? cap : f->g->d.n_nodes);
-    if (need > f->scan_tmp_bytes) {
-        if (f->scan_tmp) HIP_TRY(hipFree(f->scan_tmp));
-        HIP_TRY(hipMalloc(&f->scan_tmp, (size_t)need));
-        f->scan_tmp_bytes = need;
-    }
+static int launch_interior(gki_finder *f, const DevGraph &d, const FindArgs &a, OutFlat out, unsigned blocks) {
+    hipStream_t s = f->stream;
+    if (out.hash && out.node && out.ref_offset && out.af)
+        hipLaunchKernelGGL(k_emit_interior_flat, dim3(blocks), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end,
+                           f->p_end);
+    else
+        hipLaunchKernelGGL(k_emit_interior<0>, dim3(blocks), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end,
+                           f->p_end);
+    HIP_TRY(hipGetLastError());
+    return GKI_OK;
+}
+static int launch_interior(gki_finder *f, const DevGraph &d, const FindArgs &a, OutV2 out, unsigned blocks) {
+    hipLaunchKernelGGL(k_emit_interior<1>, dim3(blocks), dim3(256), 0, f->stream, d, a, f->ne, out, f->word_begin, f->word_end,
+                       f->p_end);
+    HIP_TRY(hipGetLastError());
     return GKI_OK;
 }
 
@@ -321,30 +535,34 @@ template <int FMT>
 static int emit_impl(gki_finder *f, typename OutSel<FMT>::T out) {
     if (!f->counted) return gki_set_error(GKI_ERR_STATE, "gki_finder_emit_* called before gki_finder_count");
     const DevGraph &d = f->g->d;
-    hipStream_t s = f->stream;
+    hipStream_t s = f->stream, s2 = f->stream2;
     const FindArgs a = f->args;
+    // the boundary walk is latency-bound, the interior stream bandwidth-bound: run them side by side
+    static const bool serial = getenv("GKI_SERIAL_EMIT") != nullptr;     // diagnostics: one stream, kernels back to back
+    if (serial) s2 = s;
+    HIP_TRY(hipEventRecord(f->ev_ready, s));
+    HIP_TRY(hipStreamWaitEvent(s2, f->ev_ready, 0));
+    HIP_TRY(hipEventRecord(f->ev[4], s2));
+    if (f->n_boundary_records > 0) {
+        if (a.has_lossy)
+            hipLaunchKernelGGL((k_emit_boundary<true, FMT>), dim3(stream_grid(d.n_nodes, 256)), dim3(256), 0, s2, d, a, f->lossy,
+                               f->bcount, f->rec_base, out, f->d_err);
+        else
+            hipLaunchKernelGGL((k_emit_boundary<false, FMT>), dim3(stream_grid(d.n_nodes, 256)), dim3(256), 0, s2, d, a, f->lossy,
+                               f->bcount, f->rec_base, out, f->d_err);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(f->ev[5], s2));
+    HIP_TRY(hipEventRecord(f->ev_join, s2));
     HIP_TRY(hipEventRecord(f->ev[2], s));
     if (f->n_interior_records > 0 && f->word_end > f->word_begin) {
         int64_t n_words = f->word_end - f->word_begin;
-        int64_t waves = ceil_div(n_words, WPW);
-        int64_t blocks = ceil_div(waves, 4);
-        if (blocks > 256 * 8) blocks = 256 * 8;
-        hipLaunchKernelGGL(k_emit_interior<FMT>, dim3((unsigned)blocks), dim3(256), 0, s, d, a, f->ne, out, f->word_begin,
-                           f->word_end);
-        HIP_TRY(hipGetLastError());
+        int64_t blocks = ceil_div(ceil_div(n_words, SW), 4);
+        if (blocks > INTERIOR_MAX_BLOCKS) blocks = INTERIOR_MAX_BLOCKS;
+        GKI_TRY(launch_interior(f, d, a, out, (unsigned)blocks));
     }
     HIP_TRY(hipEventRecord(f->ev[3], s));
-    HIP_TRY(hipEventRecord(f->ev[4], s));
-    if (f->n_boundary_records > 0) {
-        if (a.has_lossy)
-            hipLaunchKernelGGL((k_emit_boundary<true, FMT>), dim3(stream_grid(f->B, 256)), dim3(256), 0, s, d, a, f->lossy,
-                               f->bnd_start, f->B, f->bscan, f->iscan, out, f->d_err);
-        else
-            hipLaunchKernelGGL((k_emit_boundary<false, FMT>), dim3(stream_grid(f->B, 256)), dim3(256), 0, s, d, a, f->lossy,
-                               f->bnd_start, f->B, f->bscan, f->iscan, out, f->d_err);
-        HIP_TRY(hipGetLastError());
-    }
-    HIP_TRY(hipEventRecord(f->ev[5], s));
+    HIP_TRY(hipStreamWaitEvent(s, f->ev_join, 0));
     f->ev_valid[1] = true; f->ev_valid[2] = true;
     return GKI_OK;
 }
@@ -359,15 +577,18 @@ int gki_finder_create(gki_graph *g, gki_finder **out) {
     f->g = g;
     const int64_t n = g->d.n_nodes;
     HIP_TRY(hipStreamCreate(&f->stream));
-    for (int i = 0; i < 10; i++) HIP_TRY(hipEventCreate(&f->ev[i]));
-    HIP_TRY(hipMalloc((void **)&f->bnd_len, (size_t)n * 4));
-    HIP_TRY(hipMalloc((void **)&f->icnt, (size_t)n * 4));
-    HIP_TRY(hipMalloc((void **)&f->bnd_start, (size_t)(n + 1) * 8));
-    HIP_TRY(hipMalloc((void **)&f->iscan, (size_t)(n + 1) * 8));
-    HIP_TRY(hipMalloc((void **)&f->ne, (size_t)n * sizeof(NodeEmit)));
+    HIP_TRY(hipStreamCreate(&f->stream2));
+    for (int i = 0; i < 8; i++) HIP_TRY(hipEventCreate(&f->ev[i]));
+    HIP_TRY(hipEventCreateWithFlags(&f->ev_ready, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&f->ev_join, hipEventDisableTiming));
+    HIP_TRY(hipMalloc((void **)&f->bcount, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void **)&f->total, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void **)&f->rec_base, (size_t)(n + 1) * 8));
+    HIP_TRY(hipMalloc((void **)&f->ne, (size_t)(g->d.n_nonempty + 1) * sizeof(NodeEmit)));
     HIP_TRY(hipMalloc((void **)&f->lossy, (size_t)n * 2));
     HIP_TRY(hipMalloc((void **)&f->d_err, 4));
-    HIP_TRY(hipMalloc((void **)&f->d_totals, 3 * 8));
+    HIP_TRY(hipMalloc((void **)&f->d_totals, 2 * 8));
+    HIP_TRY(hipMalloc((void **)&f->d_bsum, 8));
     f->scan_tmp_bytes = gki_scan_tmp_bytes(n);
     HIP_TRY(hipMalloc(&f->scan_tmp, (size_t)f->scan_tmp_bytes));
     *out = f;
@@ -377,11 +598,14 @@ int gki_finder_create(gki_graph *g, gki_finder **out) {
 int gki_finder_destroy(gki_finder *f) {
     if (!f) return GKI_OK;
     (void)hipStreamSynchronize(f->stream);
-    void *ptrs[] = {f->bnd_len, f->icnt, f->bnd_start, f->iscan, f->cnt, f->bscan, f->ne, f->lossy, f->scan_tmp,
-                    f->d_err, f->d_totals};
+    (void)hipStreamSynchronize(f->stream2);
+    void *ptrs[] = {f->bcount, f->total, f->rec_base, f->ne, f->lossy, f->scan_tmp, f->d_err, f->d_totals, f->d_bsum};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    for (int i = 0; i < 10; i++) (void)hipEventDestroy(f->ev[i]);
+    for (int i = 0; i < 8; i++) (void)hipEventDestroy(f->ev[i]);
+    (void)hipEventDestroy(f->ev_ready);
+    (void)hipEventDestroy(f->ev_join);
     (void)hipStreamDestroy(f->stream);
+    (void)hipStreamDestroy(f->stream2);
     delete f;
     return GKI_OK;
 }
@@ -396,64 +620,61 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
         return gki_set_error(GKI_ERR_BAD_ARG, "bad node range [%lld, %lld]", (long long)p->node_begin, (long long)p->node_end);
     hipStream_t s = f->stream;
     FindArgs a;
-    a.k = p->k; a.M = p->max_variant_nodes > 255 ? 255 : p->max_variant_nodes;
+    a.k = p->k; a.M = p->max_variant_nodes > 250 ? 250 : p->max_variant_nodes;
     a.one_node = p->one_node_per_kmer ? 1 : 0;
     a.has_lossy = p->h_lossy_crit ? 1 : 0;
     a.node_begin = p->node_begin; a.off_begin = p->off_begin; a.node_end = p->node_end; a.off_end = p->off_end;
     f->args = a;
     if (a.has_lossy) HIP_TRY(hipMemcpyAsync(f->lossy, p->h_lossy_crit, (size_t)d.n_nodes * 2, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(f->d_err, 0, 4, s));
-
-    HIP_TRY(hipEventRecord(f->ev[6], s));
-    hipLaunchKernelGGL(k_node_setup, dim3(stream_grid(d.n_nodes, 256)), dim3(256), 0, s, d, a, f->lossy, f->bnd_len, f->icnt);
-    HIP_TRY(hipGetLastError());
-    GKI_TRY(gki_scan_i32_to_i64(f->bnd_len, d.n_nodes, f->bnd_start, f->scan_tmp, f->scan_tmp_bytes, s));
-    GKI_TRY(gki_scan_i32_to_i64(f->icnt, d.n_nodes, f->iscan, f->scan_tmp, f->scan_tmp_bytes, s));
-    HIP_TRY(hipEventRecord(f->ev[7], s));
-    int64_t B = 0;
-    HIP_TRY(hipMemcpyAsync(&B, f->bnd_start + d.n_nodes, 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    f->B = B;
-    GKI_TRY(ensure_cnt(f, B > 0 ? B : 1));
+    HIP_TRY(hipMemsetAsync(f->d_bsum, 0, 8, s));
 
     HIP_TRY(hipEventRecord(f->ev[0], s));
-    if (B > 0) {
-        if (a.has_lossy)
-            hipLaunchKernelGGL(k_count_boundary<true>, dim3(stream_grid(B, 256)), dim3(256), 0, s, d, a, f->lossy,
-                               f->bnd_start, B, f->cnt, f->d_err);
-        else
-            hipLaunchKernelGGL(k_count_boundary<false>, dim3(stream_grid(B, 256)), dim3(256), 0, s, d, a, f->lossy,
-                               f->bnd_start, B, f->cnt, f->d_err);
-        HIP_TRY(hipGetLastError());
-    }
+    if (a.has_lossy)
+        hipLaunchKernelGGL(k_count_boundary<true>, dim3(stream_grid(d.n_nodes, 256)), dim3(256), 0, s, d, a, f->lossy,
+                           f->bcount, f->total, f->d_err);
+    else
+        hipLaunchKernelGGL(k_count_boundary<false>, dim3(stream_grid(d.n_nodes, 256)), dim3(256), 0, s, d, a, f->lossy,
+                           f->bcount, f->total, f->d_err);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(f->ev[1], s));
-    GKI_TRY(gki_scan_u32_to_i64(f->cnt, B, f->bscan, f->scan_tmp, f->scan_tmp_bytes, s));
-    hipLaunchKernelGGL(k_node_emit, dim3(stream_grid(d.n_nodes, 256)), dim3(256), 0, s, d, a, f->bnd_len, f->bnd_start,
-                       f->bscan, f->iscan, f->ne);
+    HIP_TRY(hipEventRecord(f->ev[6], s));
+    GKI_TRY(gki_scan_u32_to_i64(f->total, d.n_nodes, f->rec_base, f->scan_tmp, f->scan_tmp_bytes, s));
+    hipLaunchKernelGGL(k_node_emit, dim3(stream_grid(d.n_nonempty, 256)), dim3(256), 0, s, d, a, f->lossy, f->bcount,
+                       f->rec_base, f->ne);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, s, f->bscan, B, f->iscan, d.n_nodes, f->d_err, f->d_totals);
+    hipLaunchKernelGGL(k_sum_u32, dim3(stream_grid(d.n_nodes, 256)), dim3(256), 0, s, f->bcount, d.n_nodes, f->d_bsum);
     HIP_TRY(hipGetLastError());
-    int64_t tot[3];
-    HIP_TRY(hipMemcpyAsync(tot, f->d_totals, 24, hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, s, f->rec_base, d.n_nodes, f->d_err, f->d_totals);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(f->ev[7], s));
+    int64_t tot[2];
+    unsigned long long bsum = 0;
+    HIP_TRY(hipMemcpyAsync(tot, f->d_totals, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&bsum, f->d_bsum, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if (tot[2] != 0)
-        return gki_set_error((int)tot[2], "a k-window crosses more than %d nodes (too many empty nodes in a row)", MAXN);
-    f->n_boundary_records = tot[0];
-    f->n_interior_records = tot[1];
+    if (tot[1] != 0)
+        return gki_set_error((int)tot[1], "a k-window crosses more than %d nodes (too many empty nodes in a row)", MAXN - 2);
+    f->n_records = tot[0];
+    f->n_boundary_records = (int64_t)bsum;
+    f->n_interior_records = tot[0] - (int64_t)bsum;
     // words of the sequence covered by the node range
     int64_t p0 = 0, p1 = d.n_bases;
     if (a.node_begin > 0 || a.node_end < d.n_nodes) {
-        int64_t v[2];
-        int64_t nb = a.node_begin, ne_ = a.node_end < d.n_nodes ? a.node_end + 1 : d.n_nodes;
-        HIP_TRY(hipMemcpy(&v[0], d.seq_start + nb, 8, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(&v[1], d.seq_start + ne_, 8, hipMemcpyDeviceToHost));
-        p0 = v[0]; p1 = v[1];
+        int64_t nb = a.node_begin < d.n_nodes ? a.node_begin : d.n_nodes;
+        HIP_TRY(hipMemcpy(&p0, d.seq_start + nb, 8, hipMemcpyDeviceToHost));
+        if (a.node_end < d.n_nodes) {
+            HIP_TRY(hipMemcpy(&p1, d.seq_start + a.node_end, 8, hipMemcpyDeviceToHost));
+            p1 += a.off_end;                        // (node_end, off_end) is exclusive
+            if (p1 > d.n_bases) p1 = d.n_bases;
+        }
     }
     f->word_begin = p0 >> 6;
     f->word_end = ceil_div(p1, 64);
+    f->p_end = p1;
     f->ev_valid[0] = true; f->ev_valid[3] = true;
     f->counted = true;
-    *n_records = tot[0] + tot[1];
+    *n_records = tot[0];
     return GKI_OK;
 }
 
@@ -468,7 +689,11 @@ int gki_finder_emit_v2(gki_finder *f, void *d_hashes, void *d_start_nodes, void 
     return emit_impl<1>(f, o);
 }
 
-int gki_finder_synchronize(gki_finder *f) { HIP_TRY(hipStreamSynchronize(f->stream)); return GKI_OK; }
+int gki_finder_synchronize(gki_finder *f) {
+    HIP_TRY(hipStreamSynchronize(f->stream));
+    HIP_TRY(hipStreamSynchronize(f->stream2));
+    return GKI_OK;
+}
 
 int gki_finder_kernel_ms(gki_finder *f, int which, float *ms) {
     *ms = 0.f;

@@ -96,6 +96,7 @@ class DenseKmerFinder:
         if only_follow_nodes is not None:
             raise NotImplementedError("only_follow_nodes (forced traversal, kmer_finder.py:386-388) is not "
                                       "implemented on the device path")
+        self._params_cache = None
         self._cols = None          # host columns after find()
         self._device = None
         self._finder = None
@@ -132,6 +133,12 @@ class DenseKmerFinder:
             pass
 
     def _params(self):
+        """Validated launch parameters; computed once per finder (graph checks are O(nodes + edges))."""
+        if self._params_cache is None:
+            self._params_cache = (self._make_params(),)
+        return self._params_cache[0]
+
+    def _make_params(self):
         g, k = self._arrays, self._k
         check_supported_graph(g, k)
         if self._critical_graph_paths is None:

