@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--max-variant-nodes", type=int, default=5)      # CLI `index` default, command_line_interface.py:637
     ap.add_argument("--cpu-sample-bases", type=float, default=3e7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--linear", action="store_true", help="diagnostic: linear chain graph without variants (BASELINE configs[1] shape)")
+    ap.add_argument("--all-nodes", action="store_true", help="diagnostic: only_save_one_node_per_kmer=False")
     ap.add_argument("--verify", action="store_true", help="size-independent checks on the full output (slow)")
     args = ap.parse_args()
 
@@ -74,7 +76,7 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     from graph_kmer_index_amd import _lib, DenseKmerFinder, CriticalGraphPaths, DeviceGraph
-    from graph_kmer_index_amd.graph import synthetic_snp_graph
+    from graph_kmer_index_amd.graph import synthetic_snp_graph, synthetic_linear_graph
     from graph_kmer_index_amd.sharding import shard_range
     lib = _lib.load()
     _lib.require_device()
@@ -83,7 +85,7 @@ def main():
 
     G, S, k = int(args.bases), int(args.sites), args.k
     t0 = time.perf_counter()
-    g = synthetic_snp_graph(G, S, k=k, seed=1234)
+    g = synthetic_linear_graph(G, 25000, seed=1234) if args.linear else synthetic_snp_graph(G, S, k=k, seed=1234)
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
     cp = CriticalGraphPaths.from_graph(g, k)
@@ -96,7 +98,7 @@ def main():
             "upload+prepare %.2fs" % (g.n_nodes, G, len(g.seq) - G, len(cp), t_gen, t_crit, t_up))
     g._device = dg
     a, b = shard_range(g, cp, rank, world)
-    finder = DenseKmerFinder(g, k, critical_graph_paths=cp, only_save_one_node_per_kmer=True,
+    finder = DenseKmerFinder(g, k, critical_graph_paths=cp, only_save_one_node_per_kmer=not args.all_nodes,
                              max_variant_nodes=args.max_variant_nodes,
                              start_at_critical_path_number=a if world > 1 else None,
                              stop_at_critical_path_number=b if world > 1 else None)

@@ -38,9 +38,11 @@ struct FindArgs {
 
 struct OutFlat { uint64_t *hash; uint32_t *node; uint64_t *ref_offset; float *af; };
 struct OutV2 { int64_t *hash; int32_t *start_node; int16_t *start_offset; int32_t *node; double *af; };
+struct OutFlatAll { uint64_t *hash; uint32_t *node; uint64_t *ref_offset; float *af; };   // all four columns present
 template <int FMT> struct OutSel;
 template <> struct OutSel<0> { typedef OutFlat T; };
 template <> struct OutSel<1> { typedef OutV2 T; };
+template <> struct OutSel<2> { typedef OutFlatAll T; };
 
 __device__ __forceinline__ void put(const OutFlat &o, int64_t idx, uint64_t h, int32_t node, int32_t end_node,
                                     int32_t end_off, int64_t pos_id, double af) {
@@ -49,6 +51,16 @@ __device__ __forceinline__ void put(const OutFlat &o, int64_t idx, uint64_t h, i
     if (o.node) o.node[idx] = (uint32_t)node;
     if (o.ref_offset) o.ref_offset[idx] = (uint64_t)pos_id;
     if (o.af) o.af[idx] = (float)af;
+}
+// No null checks: on gfx950 a branch between two stores makes the compiler drain the first one (vmcnt counts
+// stores, in order), which turns four back-to-back column stores into four serialized round trips.
+__device__ __forceinline__ void put(const OutFlatAll &o, int64_t idx, uint64_t h, int32_t node, int32_t end_node,
+                                    int32_t end_off, int64_t pos_id, double af) {
+    (void)end_node; (void)end_off;
+    o.hash[idx] = h;
+    o.node[idx] = (uint32_t)node;
+    o.ref_offset[idx] = (uint64_t)pos_id;
+    o.af[idx] = (float)af;
 }
 __device__ __forceinline__ void put(const OutV2 &o, int64_t idx, uint64_t h, int32_t node, int32_t end_node,
                                     int32_t end_off, int64_t pos_id, double af) {
@@ -333,6 +345,178 @@ __global__ __launch_bounds__(256) void k_emit_boundary(DevGraph g, FindArgs a, c
     }
 }
 
+// Emit pass for only_save_one_node_per_kmer (the CLI `index` configuration): walk and write are separated
+// inside the wave.  Phase A -- the lanes walk their nodes (loads only) and park every finished step as a
+// 50-byte descriptor in the wave's LDS queue: {context register, own bases, first record slot, ...}.
+// Phase B -- when the queue fills up or the walk is over, the wave expands the queue with one lane per
+// RECORD (prefix sum of the step sizes, binary search of the lane's step in LDS) and streams the column
+// stores with no load in between.  Keeping the stores out of the walk matters on gfx950: loads and stores
+// retire in order through one counter, so a store inside the walk stalls the next dependent load.
+constexpr int EVQ = 128;            // step descriptors per wave queue (a walk round adds at most 64)
+
+template <int FMT>
+struct EvQueue {
+    uint64_t ctx[EVQ], own[EVQ];
+    int64_t idx[EVQ], pos0[EVQ];
+    double maf[EVQ];
+    int32_t mn[EVQ], n[EVQ];
+    uint32_t pre[EVQ + 1];
+    uint8_t from[EVQ], cnt[EVQ];
+};
+
+__device__ int g_dbg_skip_expand = 0;     // diagnostics only (GKI_DBG_SKIP_EXPAND): phase A alone
+
+template <int FMT>
+__device__ __forceinline__ void expand_queue(EvQueue<FMT> &q, int n_ev, typename OutSel<FMT>::T out, int k, uint64_t kmask,
+                                             int lane) {
+    if (g_dbg_skip_expand) return;
+    // exclusive prefix of the step sizes
+    uint32_t run = 0;
+#pragma unroll
+    for (int b = 0; b < EVQ / 64; b++) {
+        const int e = b * 64 + lane;
+        const uint32_t c = e < n_ev ? q.cnt[e] : 0u;
+        uint32_t inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        q.pre[e] = run + inc - c;
+        run += __shfl(inc, 63, 64);
+    }
+    const uint32_t total = run;
+    if (lane == 0) q.pre[n_ev] = total;
+    for (uint32_t t = lane; t < total; t += 64) {
+        int lo = 0, hi = n_ev;                   // largest e with pre[e] <= t
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (q.pre[mid] <= t) lo = mid; else hi = mid; }
+        const int e = lo;
+        const uint32_t r = t - q.pre[e];
+        const int o = q.from[e] + (int)r;
+        const uint64_t h = ((q.ctx[e] >> (2 * o)) | (q.own[e] << (2 * (k - 1 - o)))) & kmask;
+        put(out, q.idx[e] + r, h, q.mn[e], q.n[e], o, q.pos0[e] + o, q.maf[e]);
+    }
+}
+
+template <bool HAS_LOSSY, int FMT>
+__global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
+                                                           const uint32_t *__restrict__ bcount,
+                                                           const int64_t *__restrict__ rec_base,
+                                                           typename OutSel<FMT>::T out, int *__restrict__ err) {
+    __shared__ EvQueue<FMT> s_q[4];
+    WalkStack st;
+    uint8_t evf[MAXN], evt[MAXN];
+    uint64_t ctx[MAXN];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    EvQueue<FMT> &q = s_q[wib];
+    const int k = a.k;
+    const uint64_t kmask = (1ull << (2 * k)) - 1ull;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const int64_t n_threads = (int64_t)gridDim.x * blockDim.x;
+    int n_ev = 0;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + wib * 64; base < g.n_nodes; base += n_threads) {
+        const int64_t n = base + lane;
+        int L = 0, o_lo = 0, hi = 0;
+        int64_t idx = 0, pos0 = 0;
+        uint64_t own = 0;
+        if (n < g.n_nodes && bcount[n] > 0) {
+            const int32_t size = g.node_size[n];
+            const int32_t bl = bnd_len_of(g, a, lossy, n, size);
+            idx = rec_base[n];
+            pos0 = g.pos_base[n];
+            o_lo = (n == a.node_begin) ? (int)(a.off_begin < bl ? a.off_begin : bl) : 0;
+            const int o_hi = (n == a.node_end) ? (int)(a.off_end < bl ? a.off_end : bl) : bl;
+            const int v0 = g.is_ref[n] ? 0 : 1;
+            const int cn = HAS_LOSSY ? lossy_of(lossy, (int32_t)n) : -1;
+            if (o_lo < o_hi && v0 <= a.M) {
+                // windows inside the node itself (lossy-restart nodes only; rare, written by the lane alone)
+                for (int o = o_lo > k - 1 ? o_lo : k - 1; o < o_hi; o++) {
+                    if (HAS_LOSSY && cn >= 0 && o + 1 - k <= cn - 1 && cn <= o) continue;
+                    put(out, idx++, gki_extract(g.seq2, g.seq_start[n] + o + 1 - k, k), (int32_t)n, (int32_t)n, o, pos0 + o,
+                        g.allele_freq[n]);
+                }
+                hi = o_hi < k - 1 ? o_hi : k - 1;
+                if (HAS_LOSSY && cn >= 1 && cn < hi) hi = cn;
+                if (o_lo < hi) {
+                    st.nd[0] = (int32_t)n; st.cur[0] = (int32_t)g.rev_start[n]; st.end[0] = (int32_t)g.rev_start[n + 1];
+                    st.cum[0] = 0; st.vc[0] = (uint8_t)v0;
+                    evf[0] = evt[0] = 0; ctx[0] = 0;
+                    own = gki_extract(g.seq2, g.seq_start[n], hi);
+                    L = 1;
+                }
+            }
+        }
+        while (__any(L > 0)) {
+            bool ev = false;
+            int e_from = 0, e_to = 0, e_L = 0;
+            uint64_t e_ctx = 0;
+            if (L > 0) {
+                const int j = L - 1;
+                const int32_t e = st.cur[j];
+                if (e >= st.end[j]) {                       // leave level j: its own step comes after its subtree
+                    if (evf[j] < evt[j]) { ev = true; e_from = evf[j]; e_to = evt[j]; e_L = j + 1; e_ctx = ctx[j]; }
+                    L--;
+                } else {
+                    st.cur[j] = e + 1;
+                    const int32_t qn = g.rev_edges[e];
+                    const int vq = st.vc[j] + (g.is_ref[qn] ? 0 : 1);
+                    if (vq <= a.M) {
+                        if (L >= MAXN - 1) {
+                            *err = GKI_ERR_WINDOW_TOO_DEEP;
+                        } else {
+                            const int s = g.node_size[qn];
+                            const int c = st.cum[j];
+                            st.nd[L] = qn; st.vc[L] = (uint8_t)vq;
+                            if (s == 0) {
+                                st.cum[L] = (uint8_t)c; st.cur[L] = (int32_t)g.rev_start[qn]; st.end[L] = (int32_t)g.rev_start[qn + 1];
+                                evf[L] = evt[L] = 0; ctx[L] = ctx[j];
+                                L++;
+                            } else {
+                                int from = k - 1 - c - s; if (from < o_lo) from = o_lo;
+                                int to = k - 1 - c; if (to > hi) to = hi;
+                                const int cq = HAS_LOSSY ? lossy_of(lossy, qn) : -1;
+                                if (HAS_LOSSY && cq >= 0) { const int min_ok = k - 1 - c - s + cq; if (from < min_ok) from = min_ok; }
+                                const int tq = s < k - 1 - c ? s : k - 1 - c;
+                                const uint64_t cx = ctx[j] | (gki_extract(g.seq2, g.seq_start[qn] + s - tq, tq) << (2 * (k - 1 - c - tq)));
+                                const bool deeper = (k - 1 - c - s > o_lo) && !(HAS_LOSSY && cq >= 1);
+                                if (deeper) {
+                                    st.cum[L] = (uint8_t)(c + s); st.cur[L] = (int32_t)g.rev_start[qn]; st.end[L] = (int32_t)g.rev_start[qn + 1];
+                                    evf[L] = (uint8_t)(from < to ? from : 0); evt[L] = (uint8_t)(from < to ? to : 0); ctx[L] = cx;
+                                    L++;
+                                } else if (from < to) {
+                                    ev = true; e_from = from; e_to = to; e_L = L + 1; e_ctx = cx;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            const uint64_t pending = __ballot(ev);
+            if (pending) {
+                const int n_new = __popcll(pending);
+                if (n_ev + n_new > EVQ) {                    // wave-uniform: make room first
+                    expand_queue<FMT>(q, n_ev, out, k, kmask, lane);
+                    n_ev = 0;
+                }
+                if (ev) {
+                    int32_t mn = INT_MAX;
+                    double maf = INFINITY;
+                    for (int j = 0; j < e_L; j++) {
+                        const int32_t qn = st.nd[j];
+                        mn = qn < mn ? qn : mn;
+                        maf = fmin(maf, g.allele_freq[qn]);            // np.min, kmer_finder.py:143
+                    }
+                    const int slot = n_ev + __popcll(pending & lt_mask);
+                    q.ctx[slot] = e_ctx; q.own[slot] = own; q.idx[slot] = idx; q.pos0[slot] = pos0;
+                    q.maf[slot] = maf; q.mn[slot] = mn; q.n[slot] = (int32_t)n;
+                    q.from[slot] = (uint8_t)e_from; q.cnt[slot] = (uint8_t)(e_to - e_from);
+                    idx += e_to - e_from;
+                }
+                n_ev += n_new;
+            }
+        }
+    }
+    if (n_ev > 0) expand_queue<FMT>(q, n_ev, out, k, kmask, lane);
+}
+
 // ------------------------------------------------------------------------------------ per-node constants
 __global__ __launch_bounds__(256) void k_node_emit(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
                                                    const uint32_t *__restrict__ bcount,
@@ -513,6 +697,39 @@ struct gki_finder {
     bool ev_valid[4];
 };
 
+template <int FMT>
+static int launch_boundary_fmt(gki_finder *f, const DevGraph &d, const FindArgs &a, typename OutSel<FMT>::T out, hipStream_t s2) {
+    static bool dbg_set = false;
+    if (!dbg_set) {
+        int v = getenv("GKI_DBG_SKIP_EXPAND") ? 1 : 0;
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_skip_expand), &v, sizeof(int)));
+        dbg_set = true;
+    }
+    static const int bnd_blocks = getenv("GKI_BND_BLOCKS") ? atoi(getenv("GKI_BND_BLOCKS")) : 0;   // tuning knob
+    int gb = stream_grid(d.n_nodes, 256);
+    if (bnd_blocks > 0 && gb > bnd_blocks) gb = bnd_blocks;
+    const dim3 grid(gb), block(256);
+    if (a.one_node) {
+        if (a.has_lossy) hipLaunchKernelGGL((k_emit_boundary_one<true, FMT>), grid, block, 0, s2, d, a, f->lossy, f->bcount, f->rec_base, out, f->d_err);
+        else hipLaunchKernelGGL((k_emit_boundary_one<false, FMT>), grid, block, 0, s2, d, a, f->lossy, f->bcount, f->rec_base, out, f->d_err);
+    } else {
+        if (a.has_lossy) hipLaunchKernelGGL((k_emit_boundary<true, FMT>), grid, block, 0, s2, d, a, f->lossy, f->bcount, f->rec_base, out, f->d_err);
+        else hipLaunchKernelGGL((k_emit_boundary<false, FMT>), grid, block, 0, s2, d, a, f->lossy, f->bcount, f->rec_base, out, f->d_err);
+    }
+    HIP_TRY(hipGetLastError());
+    return GKI_OK;
+}
+static int launch_boundary(gki_finder *f, const DevGraph &d, const FindArgs &a, OutFlat out, hipStream_t s2) {
+    if (out.hash && out.node && out.ref_offset && out.af) {
+        OutFlatAll all{out.hash, out.node, out.ref_offset, out.af};
+        return launch_boundary_fmt<2>(f, d, a, all, s2);
+    }
+    return launch_boundary_fmt<0>(f, d, a, out, s2);
+}
+static int launch_boundary(gki_finder *f, const DevGraph &d, const FindArgs &a, OutV2 out, hipStream_t s2) {
+    return launch_boundary_fmt<1>(f, d, a, out, s2);
+}
+
 static int launch_interior(gki_finder *f, const DevGraph &d, const FindArgs &a, OutFlat out, unsigned blocks) {
     hipStream_t s = f->stream;
     if (out.hash && out.node && out.ref_offset && out.af)
@@ -537,28 +754,22 @@ static int emit_impl(gki_finder *f, typename OutSel<FMT>::T out) {
     const DevGraph &d = f->g->d;
     hipStream_t s = f->stream, s2 = f->stream2;
     const FindArgs a = f->args;
-    // the boundary walk is latency-bound, the interior stream bandwidth-bound: run them side by side
-    static const bool serial = getenv("GKI_SERIAL_EMIT") != nullptr;     // diagnostics: one stream, kernels back to back
-    if (serial) s2 = s;
+    // Measured on MI355X (3 Gbp graph): running the boundary and interior kernels on two streams is ~4% slower
+    // than back to back (both press on the same write path), so one stream is the default.
+    static const bool overlap = getenv("GKI_OVERLAP_EMIT") != nullptr;
+    if (!overlap) s2 = s;
     HIP_TRY(hipEventRecord(f->ev_ready, s));
     HIP_TRY(hipStreamWaitEvent(s2, f->ev_ready, 0));
     HIP_TRY(hipEventRecord(f->ev[4], s2));
-    if (f->n_boundary_records > 0) {
-        if (a.has_lossy)
-            hipLaunchKernelGGL((k_emit_boundary<true, FMT>), dim3(stream_grid(d.n_nodes, 256)), dim3(256), 0, s2, d, a, f->lossy,
-                               f->bcount, f->rec_base, out, f->d_err);
-        else
-            hipLaunchKernelGGL((k_emit_boundary<false, FMT>), dim3(stream_grid(d.n_nodes, 256)), dim3(256), 0, s2, d, a, f->lossy,
-                               f->bcount, f->rec_base, out, f->d_err);
-        HIP_TRY(hipGetLastError());
-    }
+    if (f->n_boundary_records > 0) GKI_TRY(launch_boundary(f, d, a, out, s2));
     HIP_TRY(hipEventRecord(f->ev[5], s2));
     HIP_TRY(hipEventRecord(f->ev_join, s2));
     HIP_TRY(hipEventRecord(f->ev[2], s));
     if (f->n_interior_records > 0 && f->word_end > f->word_begin) {
         int64_t n_words = f->word_end - f->word_begin;
         int64_t blocks = ceil_div(ceil_div(n_words, SW), 4);
-        if (blocks > INTERIOR_MAX_BLOCKS) blocks = INTERIOR_MAX_BLOCKS;
+        static const int int_blocks = getenv("GKI_INT_BLOCKS") ? atoi(getenv("GKI_INT_BLOCKS")) : INTERIOR_MAX_BLOCKS;   // tuning knob
+        if (blocks > int_blocks) blocks = int_blocks;
         GKI_TRY(launch_interior(f, d, a, out, (unsigned)blocks));
     }
     HIP_TRY(hipEventRecord(f->ev[3], s));
