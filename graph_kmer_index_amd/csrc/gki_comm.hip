@@ -1,0 +1,126 @@
+// Multi-GPU exchange: all-gather(v) of the FlatKmers columns over RCCL (xGMI inside a node).
+//
+// The enumeration shards by critical-path ranges and needs no exchange; the one collective of the
+// build is gathering every rank's finished columns before the table build.  Shards
+// have different sizes, so the gather is a group of point-to-point transfers: every rank sends its
+// shard to each peer and receives each peer's shard at its offset.  On MI355X's fully connected xGMI
+// every pair has its own link, so all 7 sends of a rank run in parallel -- a ring schedule would
+// move the same bytes 7 hops over one link each.
+//
+// librccl.so is loaded lazily (dlopen) so that single-GPU users never touch it.
+#include "gki_common.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+struct gki_comm {
+    ncclComm_t comm;
+    int world, rank;
+    hipStream_t stream;
+};
+
+namespace {
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+int load_rccl() {
+    if (g_rccl.h) return GKI_OK;
+    void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return gki_set_error(GKI_ERR_HIP, "cannot load librccl.so: %s", dlerror());
+#define SYM(field, name)                                                                     \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name));                 \
+    if (!g_rccl.field) return gki_set_error(GKI_ERR_HIP, "librccl.so lacks %s", name);
+    SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+    SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd")
+    SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    g_rccl.h = h;
+    return GKI_OK;
+}
+
+#define NCCL_TRY(call)                                                                                      \
+    do {                                                                                                    \
+        ncclResult_t r_ = (call);                                                                           \
+        if (r_ != ncclSuccess) return gki_set_error(GKI_ERR_HIP, "%s -> %s", #call, g_rccl.GetErrorString(r_)); \
+    } while (0)
+}  // namespace
+
+extern "C" {
+
+int gki_comm_get_unique_id(void *h_id) {
+    GKI_TRY(load_rccl());
+    static_assert(sizeof(ncclUniqueId) == GKI_COMM_ID_BYTES, "ncclUniqueId size");
+    NCCL_TRY(g_rccl.GetUniqueId(reinterpret_cast<ncclUniqueId *>(h_id)));
+    return GKI_OK;
+}
+
+int gki_comm_create(gki_comm **out, int world_size, int rank, const void *h_id) {
+    *out = nullptr;
+    if (world_size < 1 || rank < 0 || rank >= world_size) return gki_set_error(GKI_ERR_BAD_ARG, "bad rank %d of %d", rank, world_size);
+    GKI_TRY(load_rccl());
+    gki_comm *c = new gki_comm();
+    c->world = world_size; c->rank = rank;
+    ncclUniqueId id;
+    memcpy(&id, h_id, sizeof(id));
+    HIP_TRY(hipStreamCreate(&c->stream));
+    NCCL_TRY(g_rccl.CommInitRank(&c->comm, world_size, id, rank));
+    *out = c;
+    return GKI_OK;
+}
+
+int gki_comm_destroy(gki_comm *c) {
+    if (!c) return GKI_OK;
+    (void)hipStreamSynchronize(c->stream);
+    if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return GKI_OK;
+}
+
+int gki_comm_allgather_flat(gki_comm *c, const int64_t *h_counts, const void *d_hashes, const void *d_nodes,
+                            const void *d_ref_offsets, const void *d_af32, void *d_out_hashes, void *d_out_nodes,
+                            void *d_out_ref_offsets, void *d_out_af32) {
+    const int W = c->world, me = c->rank;
+    int64_t off = 0, my_off = 0;
+    for (int r = 0; r < W; r++) { if (h_counts[r] < 0) return gki_set_error(GKI_ERR_BAD_ARG, "negative count"); if (r == me) my_off = off; off += h_counts[r]; }
+    const void *in[4] = {d_hashes, d_nodes, d_ref_offsets, d_af32};
+    void *outp[4] = {d_out_hashes, d_out_nodes, d_out_ref_offsets, d_out_af32};
+    const size_t esz[4] = {8, 4, 8, 4};
+    hipStream_t s = c->stream;
+    // own shard: device-to-device copy
+    for (int col = 0; col < 4; col++)
+        if (h_counts[me] > 0)
+            HIP_TRY(hipMemcpyAsync((char *)outp[col] + (size_t)my_off * esz[col], in[col], (size_t)h_counts[me] * esz[col],
+                                   hipMemcpyDeviceToDevice, s));
+    if (W > 1) {
+        NCCL_TRY(g_rccl.GroupStart());
+        for (int col = 0; col < 4; col++) {
+            int64_t o = 0;
+            for (int r = 0; r < W; r++) {
+                if (r != me) {
+                    if (h_counts[me] > 0)
+                        NCCL_TRY(g_rccl.Send(in[col], (size_t)h_counts[me] * esz[col], ncclUint8, r, c->comm, s));
+                    if (h_counts[r] > 0)
+                        NCCL_TRY(g_rccl.Recv((char *)outp[col] + (size_t)o * esz[col], (size_t)h_counts[r] * esz[col], ncclUint8, r,
+                                             c->comm, s));
+                }
+                o += h_counts[r];
+            }
+        }
+        NCCL_TRY(g_rccl.GroupEnd());
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return GKI_OK;
+}
+
+}  // extern "C"

@@ -181,6 +181,21 @@ int gki_index_lookup_emit(const gki_index_view *ix, const void *d_queries, int64
                           const void *d_hit_start, void *d_hit_nodes, void *d_hit_ref_offsets,
                           void *d_hit_query, void *d_hit_frequencies, void *d_hit_af32, void *d_hit_position);
 
+/* ---------------------------------------------------------------- multi-GPU exchange (RCCL over xGMI)
+ * One process per GPU.  The reference gathers its per-process FlatKmers by pickling them through a
+ * process pool and concatenating (command_line_interface.py:607-614, flat_kmers.py:71-90); here every
+ * rank's finished columns are exchanged once, shard r landing at offset sum(counts[:r]), so that every
+ * GPU holds the concatenation in rank order.  The 128-byte id comes from rank 0 and travels over the
+ * caller's control plane (bench / parallel.py use torch.distributed gloo); h_counts[world] likewise. */
+#define GKI_COMM_ID_BYTES 128
+typedef struct gki_comm gki_comm;
+int gki_comm_get_unique_id(void *h_id);
+int gki_comm_create(gki_comm **out, int world_size, int rank, const void *h_id);
+int gki_comm_destroy(gki_comm *c);
+int gki_comm_allgather_flat(gki_comm *c, const int64_t *h_counts, const void *d_hashes, const void *d_nodes,
+                            const void *d_ref_offsets, const void *d_af32, void *d_out_hashes, void *d_out_nodes,
+                            void *d_out_ref_offsets, void *d_out_af32);
+
 #ifdef __cplusplus
 }
 #endif

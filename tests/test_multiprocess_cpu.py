@@ -1,0 +1,63 @@
+"""world_size-2 tests on CPU (gloo): the sharding of the enumeration and the bookkeeping of the exchange.
+The HIP kernels cannot run here, so each rank's shard is computed by the oracle (checker standing in for the
+device in this test only); what is under test is graph_kmer_index_amd.sharding / parallel's control plane."""
+import os
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from graph_kmer_index_amd.graph import synthetic_snp_graph
+from graph_kmer_index_amd.sharding import critical_path_cuts, shard_range
+from graph_kmer_index_amd import CriticalGraphPaths
+from oracle import oracle
+
+
+def _worker(rank, world, port, tmpdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from graph_kmer_index_amd.parallel import TorchControlPlane
+    cp_plane = TorchControlPlane()
+    g = synthetic_snp_graph(60000, 700, k=31, seed=21)
+    cp = CriticalGraphPaths.from_graph(g, 31)
+    a, b = shard_range(g, cp, rank, world)
+    mine = oracle.find(g, 31, (cp.nodes, cp.offsets), True, 5, start_at_critical_path_number=a,
+                       stop_at_critical_path_number=b)
+    counts = cp_plane.allgather_int(len(mine["kmers"]))
+    ident = cp_plane.broadcast_bytes(bytes(range(128)) if rank == 0 else None, 0)
+    np.savez(os.path.join(tmpdir, "r%d.npz" % rank), counts=np.array(counts), ident=np.frombuffer(ident, np.uint8),
+             **mine)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_control_plane(tmp_path):
+    world, port = 2, 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(str(tmp_path / ("r%d.npz" % r))) for r in range(world)]
+    g = synthetic_snp_graph(60000, 700, k=31, seed=21)
+    full = oracle.find(g, 31, None, True, 5)
+    for key in ("kmers", "nodes", "start_nodes", "start_offsets"):
+        assert np.array_equal(np.concatenate([p[key] for p in parts]), full[key])      # rank order == full run
+    for p in parts:
+        assert p["counts"].tolist() == [len(q["kmers"]) for q in parts]
+        assert p["ident"].tolist() == list(range(128))
+    # shards are balanced by bases
+    assert abs(len(parts[0]["kmers"]) - len(parts[1]["kmers"])) < 0.1 * len(full["kmers"])
+
+
+def test_cuts_cover_all_critical_points():
+    g = synthetic_snp_graph(200000, 2500, k=31, seed=3)
+    cp = CriticalGraphPaths.from_graph(g, 31)
+    for w in (1, 2, 3, 8, 64):
+        cuts = critical_path_cuts(g, cp, w)
+        assert cuts[0] == 0 and cuts[-1] == len(cp) and len(cuts) == w + 1
+        assert all(x <= y for x, y in zip(cuts[:-1], cuts[1:]))
+        total = 0
+        for r in range(w):
+            a, b = shard_range(g, cp, r, w)
+            total += len(oracle.find(g, 31, (cp.nodes, cp.offsets), True, 5, start_at_critical_path_number=a,
+                                     stop_at_critical_path_number=b)["kmers"]) if w <= 3 else 0
+        if w <= 3:
+            assert total == len(oracle.find(g, 31, (cp.nodes, cp.offsets), True, 5)["kmers"])
