@@ -28,6 +28,21 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s
 BYTES_PER_RECORD = 25            # 1 B of node sequence read + 24 B FlatKmers row written
 
 
+def pmc_traffic(n_ref_bases, n_sites, k):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (collected with
+    tools/collect_pmc.sh on the same workload; counters cannot be read from inside this process)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_3gbp.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        w = d["workload"]
+        if (w["n_ref_bases"], w["n_snp_bubbles"], w["k"]) != (n_ref_bases, n_sites, k):
+            return None, None
+        return d["k_emit_interior_flat_traffic_bytes_per_launch"], "profiles/r01_pmc_3gbp.json"
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
@@ -145,6 +160,7 @@ def main():
         value = n_total * args.steps / elapsed
         avg_int_ms = float(np.mean(interior_ms))
         achieved = BYTES_PER_RECORD * n_interior / (avg_int_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(G, S, k) if world == 1 and not args.linear else (None, None)
         res = {
             "metric": "k-mers hashed+indexed per second (k=31, 3 Gbp graph)", "value": value, "unit": "k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -156,7 +172,7 @@ def main():
                        "only_save_one_node_per_kmer": True, "records_per_step": n_total, "n_nodes": int(g.n_nodes),
                        "sharding": "critical-path ranges balanced by bases, whole graph resident on every GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_emit_interior", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_record": BYTES_PER_RECORD, "records_per_launch": int(n_interior),
                          "avg_launch_ms": avg_int_ms},
             "kernels_ms_rank0_last_step": kern,
