@@ -49,6 +49,14 @@ __device__ __forceinline__ uint64_t gki_extract(const uint64_t *__restrict__ seq
 }
 
 // ---------------------------------------------------------------------------------- device graph view
+struct NodeWalk {            // everything the boundary walk needs about a node, one aligned 32-B record
+    int64_t seq_start;
+    int32_t rev_begin, rev_end;
+    int32_t size;
+    int32_t is_ref;
+    double af;
+};
+
 struct DevGraph {
     int64_t n_nodes, n_bases, n_words64;     // n_words64 = ceil(n_bases / 64): one bitmap word per 64 bases
     const int32_t *node_size;
@@ -64,6 +72,7 @@ struct DevGraph {
     const int64_t *pos_base;                 // position id of (node, 0)
     const uint64_t *start_mask;              // bit p%64 of word p/64 set iff a non-empty node starts at base p
     const uint32_t *start_rank;              // number of node starts in words before this one
+    const NodeWalk *walk;                    // [n_nodes] packed per-node records for the predecessor walk
     const int32_t *nonempty;                 // ids of non-empty nodes, ascending (= sequence order)
     int64_t n_nonempty;
 };

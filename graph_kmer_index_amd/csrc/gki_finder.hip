@@ -172,26 +172,85 @@ struct CountEmitter {
     }
 };
 
+// The walk used by the count pass and by the one-node emit pass keeps the TOP of the stack in registers and only
+// the levels below it in (scratch) arrays: PMC showed the first version, with the whole stack in scratch, writing
+// 1.4 GB of spills in the count pass and ~5 GB in the emit pass of the 3 Gbp graph, and every step began with a
+// dependent scratch load.  Node facts come from one aligned 32-byte NodeWalk record per visited node.
+struct LevelLo {                 // what a suspended level needs to resume
+    int32_t cur, end;
+    uint8_t cum, vc;
+};
+
 template <bool HAS_LOSSY>
 __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
                                                         uint32_t *__restrict__ bcount, uint32_t *__restrict__ total,
                                                         int *__restrict__ err) {
-    WalkStack st;
+    LevelLo below[MAXN];
+    const int k = a.k;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < g.n_nodes; n += stride) {
-        const int32_t size = g.node_size[n];
+        const NodeWalk wn = g.walk[n];
+        const int32_t size = wn.size;
         const int32_t bl = bnd_len_of(g, a, lossy, n, size);
-        CountEmitter em{0u, a.one_node != 0};
-        if (bl > 0) walk_node<HAS_LOSSY>(g, a, lossy, (int32_t)n, bl, st, err, em);
+        uint32_t count = 0;
+        const int o_lo = (n == a.node_begin) ? (int)(a.off_begin < bl ? a.off_begin : bl) : 0;
+        const int o_hi = (n == a.node_end) ? (int)(a.off_end < bl ? a.off_end : bl) : bl;
+        const int v0 = wn.is_ref ? 0 : 1;
+        if (bl > 0 && o_lo < o_hi && v0 <= a.M) {
+            const int cn = HAS_LOSSY ? lossy_of(lossy, (int32_t)n) : -1;
+            for (int o = o_lo > k - 1 ? o_lo : k - 1; o < o_hi; o++) {
+                if (HAS_LOSSY && cn >= 0 && o + 1 - k <= cn - 1 && cn <= o) continue;
+                count += 1;
+            }
+            int hi = o_hi < k - 1 ? o_hi : k - 1;
+            if (HAS_LOSSY && cn >= 1 && cn < hi) hi = cn;
+            if (o_lo < hi) {
+                int32_t t_cur = wn.rev_begin, t_end = wn.rev_end;
+                int t_cum = 0, t_vc = v0;
+                int L = 1;
+                while (L > 0) {
+                    if (t_cur >= t_end) {
+                        L--;
+                        if (L > 0) { const LevelLo b = below[L - 1]; t_cur = b.cur; t_end = b.end; t_cum = b.cum; t_vc = b.vc; }
+                        continue;
+                    }
+                    const int32_t q = g.rev_edges[t_cur++];
+                    const NodeWalk wq = g.walk[q];
+                    const int vq = t_vc + (wq.is_ref ? 0 : 1);
+                    if (vq > a.M) continue;                          // kmer_finder.py:391-403 in order-free form
+                    if (L >= MAXN - 1) { *err = GKI_ERR_WINDOW_TOO_DEEP; continue; }
+                    const int s = wq.size, c = t_cum;
+                    bool deeper;
+                    int new_cum;
+                    if (s == 0) {                                    // empty node: in the node set, adds no base
+                        deeper = true; new_cum = c;
+                    } else {
+                        int from = k - 1 - c - s; if (from < o_lo) from = o_lo;
+                        int to = k - 1 - c; if (to > hi) to = hi;
+                        const int cq = HAS_LOSSY ? lossy_of(lossy, q) : -1;
+                        if (HAS_LOSSY && cq >= 0) { const int min_ok = k - 1 - c - s + cq; if (from < min_ok) from = min_ok; }
+                        if (from < to) count += (uint32_t)(to - from) * (a.one_node ? 1u : (uint32_t)(L + 1));
+                        deeper = (k - 1 - c - s > o_lo) && !(HAS_LOSSY && cq >= 1);
+                        new_cum = c + s;
+                    }
+                    if (deeper) {
+                        LevelLo b; b.cur = t_cur; b.end = t_end; b.cum = (uint8_t)t_cum; b.vc = (uint8_t)t_vc;
+                        below[L - 1] = b;
+                        t_cur = wq.rev_begin; t_end = wq.rev_end; t_cum = new_cum; t_vc = vq;
+                        L++;
+                    }
+                }
+            }
+        }
         uint32_t ic = 0;                              // interior offsets of this node in this run
         if (n >= a.node_begin && n <= a.node_end && size > 0) {
-            int64_t lo = bl, hi = size;
+            int64_t lo = bl, hi2 = size;
             if (n == a.node_begin && a.off_begin > lo) lo = a.off_begin;
-            if (n == a.node_end && a.off_end < hi) hi = a.off_end;
-            ic = hi > lo ? (uint32_t)(hi - lo) : 0u;
+            if (n == a.node_end && a.off_end < hi2) hi2 = a.off_end;
+            ic = hi2 > lo ? (uint32_t)(hi2 - lo) : 0u;
         }
-        bcount[n] = em.count;
-        total[n] = em.count + ic;
+        bcount[n] = count;
+        total[n] = count + ic;
     }
 }
 
@@ -395,15 +454,20 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT> &q, int n_ev, typename
     }
 }
 
+struct LevelEmit {               // a suspended level of the emit walk
+    uint64_t ctx;
+    double maf;
+    int32_t cur, end, mn;
+    uint8_t cum, vc, evf, evt;
+};
+
 template <bool HAS_LOSSY, int FMT>
 __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
                                                            const uint32_t *__restrict__ bcount,
                                                            const int64_t *__restrict__ rec_base,
                                                            typename OutSel<FMT>::T out, int *__restrict__ err) {
     __shared__ EvQueue<FMT> s_q[4];
-    WalkStack st;
-    uint8_t evf[MAXN], evt[MAXN];
-    uint64_t ctx[MAXN];
+    LevelEmit below[MAXN];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     EvQueue<FMT> &q = s_q[wib];
@@ -417,73 +481,88 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
         int L = 0, o_lo = 0, hi = 0;
         int64_t idx = 0, pos0 = 0;
         uint64_t own = 0;
+        // top of the stack, in registers
+        int32_t t_cur = 0, t_end = 0, t_mn = 0;
+        int t_cum = 0, t_vc = 0, t_evf = 0, t_evt = 0;
+        uint64_t t_ctx = 0;
+        double t_maf = 0.0;
         if (n < g.n_nodes && bcount[n] > 0) {
-            const int32_t size = g.node_size[n];
-            const int32_t bl = bnd_len_of(g, a, lossy, n, size);
+            const NodeWalk wn = g.walk[n];
+            const int32_t bl = bnd_len_of(g, a, lossy, n, wn.size);
             idx = rec_base[n];
             pos0 = g.pos_base[n];
             o_lo = (n == a.node_begin) ? (int)(a.off_begin < bl ? a.off_begin : bl) : 0;
             const int o_hi = (n == a.node_end) ? (int)(a.off_end < bl ? a.off_end : bl) : bl;
-            const int v0 = g.is_ref[n] ? 0 : 1;
+            const int v0 = wn.is_ref ? 0 : 1;
             const int cn = HAS_LOSSY ? lossy_of(lossy, (int32_t)n) : -1;
             if (o_lo < o_hi && v0 <= a.M) {
                 // windows inside the node itself (lossy-restart nodes only; rare, written by the lane alone)
                 for (int o = o_lo > k - 1 ? o_lo : k - 1; o < o_hi; o++) {
                     if (HAS_LOSSY && cn >= 0 && o + 1 - k <= cn - 1 && cn <= o) continue;
-                    put(out, idx++, gki_extract(g.seq2, g.seq_start[n] + o + 1 - k, k), (int32_t)n, (int32_t)n, o, pos0 + o,
-                        g.allele_freq[n]);
+                    put(out, idx++, gki_extract(g.seq2, wn.seq_start + o + 1 - k, k), (int32_t)n, (int32_t)n, o, pos0 + o, wn.af);
                 }
                 hi = o_hi < k - 1 ? o_hi : k - 1;
                 if (HAS_LOSSY && cn >= 1 && cn < hi) hi = cn;
                 if (o_lo < hi) {
-                    st.nd[0] = (int32_t)n; st.cur[0] = (int32_t)g.rev_start[n]; st.end[0] = (int32_t)g.rev_start[n + 1];
-                    st.cum[0] = 0; st.vc[0] = (uint8_t)v0;
-                    evf[0] = evt[0] = 0; ctx[0] = 0;
-                    own = gki_extract(g.seq2, g.seq_start[n], hi);
+                    t_cur = wn.rev_begin; t_end = wn.rev_end; t_cum = 0; t_vc = v0; t_evf = t_evt = 0; t_ctx = 0;
+                    t_mn = (int32_t)n; t_maf = wn.af;
+                    own = gki_extract(g.seq2, wn.seq_start, hi);
                     L = 1;
                 }
             }
         }
         while (__any(L > 0)) {
             bool ev = false;
-            int e_from = 0, e_to = 0, e_L = 0;
+            int e_from = 0, e_to = 0;
+            int32_t e_mn = 0;
             uint64_t e_ctx = 0;
+            double e_maf = 0.0;
             if (L > 0) {
-                const int j = L - 1;
-                const int32_t e = st.cur[j];
-                if (e >= st.end[j]) {                       // leave level j: its own step comes after its subtree
-                    if (evf[j] < evt[j]) { ev = true; e_from = evf[j]; e_to = evt[j]; e_L = j + 1; e_ctx = ctx[j]; }
+                if (t_cur >= t_end) {                       // leave the level: its own step comes after its subtree
+                    if (t_evf < t_evt) { ev = true; e_from = t_evf; e_to = t_evt; e_ctx = t_ctx; e_mn = t_mn; e_maf = t_maf; }
                     L--;
+                    if (L > 0) {
+                        const LevelEmit b = below[L - 1];
+                        t_cur = b.cur; t_end = b.end; t_cum = b.cum; t_vc = b.vc; t_evf = b.evf; t_evt = b.evt;
+                        t_ctx = b.ctx; t_mn = b.mn; t_maf = b.maf;
+                    }
                 } else {
-                    st.cur[j] = e + 1;
-                    const int32_t qn = g.rev_edges[e];
-                    const int vq = st.vc[j] + (g.is_ref[qn] ? 0 : 1);
+                    const int32_t qn = g.rev_edges[t_cur++];
+                    const NodeWalk wq = g.walk[qn];
+                    const int vq = t_vc + (wq.is_ref ? 0 : 1);
                     if (vq <= a.M) {
                         if (L >= MAXN - 1) {
                             *err = GKI_ERR_WINDOW_TOO_DEEP;
                         } else {
-                            const int s = g.node_size[qn];
-                            const int c = st.cum[j];
-                            st.nd[L] = qn; st.vc[L] = (uint8_t)vq;
+                            const int s = wq.size, c = t_cum;
+                            const int32_t mn = qn < t_mn ? qn : t_mn;
+                            const double maf = fmin(t_maf, wq.af);               // np.min, kmer_finder.py:143
+                            bool deeper;
+                            int new_cum, from = 0, to = 0;
+                            uint64_t cx = t_ctx;
                             if (s == 0) {
-                                st.cum[L] = (uint8_t)c; st.cur[L] = (int32_t)g.rev_start[qn]; st.end[L] = (int32_t)g.rev_start[qn + 1];
-                                evf[L] = evt[L] = 0; ctx[L] = ctx[j];
-                                L++;
+                                deeper = true; new_cum = c;
                             } else {
-                                int from = k - 1 - c - s; if (from < o_lo) from = o_lo;
-                                int to = k - 1 - c; if (to > hi) to = hi;
+                                from = k - 1 - c - s; if (from < o_lo) from = o_lo;
+                                to = k - 1 - c; if (to > hi) to = hi;
                                 const int cq = HAS_LOSSY ? lossy_of(lossy, qn) : -1;
                                 if (HAS_LOSSY && cq >= 0) { const int min_ok = k - 1 - c - s + cq; if (from < min_ok) from = min_ok; }
                                 const int tq = s < k - 1 - c ? s : k - 1 - c;
-                                const uint64_t cx = ctx[j] | (gki_extract(g.seq2, g.seq_start[qn] + s - tq, tq) << (2 * (k - 1 - c - tq)));
-                                const bool deeper = (k - 1 - c - s > o_lo) && !(HAS_LOSSY && cq >= 1);
-                                if (deeper) {
-                                    st.cum[L] = (uint8_t)(c + s); st.cur[L] = (int32_t)g.rev_start[qn]; st.end[L] = (int32_t)g.rev_start[qn + 1];
-                                    evf[L] = (uint8_t)(from < to ? from : 0); evt[L] = (uint8_t)(from < to ? to : 0); ctx[L] = cx;
-                                    L++;
-                                } else if (from < to) {
-                                    ev = true; e_from = from; e_to = to; e_L = L + 1; e_ctx = cx;
-                                }
+                                cx = t_ctx | (gki_extract(g.seq2, wq.seq_start + s - tq, tq) << (2 * (k - 1 - c - tq)));
+                                deeper = (k - 1 - c - s > o_lo) && !(HAS_LOSSY && cq >= 1);
+                                new_cum = c + s;
+                            }
+                            if (deeper) {
+                                LevelEmit b;
+                                b.cur = t_cur; b.end = t_end; b.cum = (uint8_t)t_cum; b.vc = (uint8_t)t_vc;
+                                b.evf = (uint8_t)t_evf; b.evt = (uint8_t)t_evt; b.ctx = t_ctx; b.mn = t_mn; b.maf = t_maf;
+                                below[L - 1] = b;
+                                t_cur = wq.rev_begin; t_end = wq.rev_end; t_cum = new_cum; t_vc = vq;
+                                t_evf = from < to ? from : 0; t_evt = from < to ? to : 0;
+                                t_ctx = cx; t_mn = mn; t_maf = maf;
+                                L++;
+                            } else if (from < to) {
+                                ev = true; e_from = from; e_to = to; e_ctx = cx; e_mn = mn; e_maf = maf;
                             }
                         }
                     }
@@ -497,16 +576,9 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                     n_ev = 0;
                 }
                 if (ev) {
-                    int32_t mn = INT_MAX;
-                    double maf = INFINITY;
-                    for (int j = 0; j < e_L; j++) {
-                        const int32_t qn = st.nd[j];
-                        mn = qn < mn ? qn : mn;
-                        maf = fmin(maf, g.allele_freq[qn]);            // np.min, kmer_finder.py:143
-                    }
                     const int slot = n_ev + __popcll(pending & lt_mask);
                     q.ctx[slot] = e_ctx; q.own[slot] = own; q.idx[slot] = idx; q.pos0[slot] = pos0;
-                    q.maf[slot] = maf; q.mn[slot] = mn; q.n[slot] = (int32_t)n;
+                    q.maf[slot] = e_maf; q.mn[slot] = e_mn; q.n[slot] = (int32_t)n;
                     q.from[slot] = (uint8_t)e_from; q.cnt[slot] = (uint8_t)(e_to - e_from);
                     idx += e_to - e_from;
                 }

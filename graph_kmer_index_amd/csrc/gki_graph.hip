@@ -41,6 +41,20 @@ __global__ __launch_bounds__(256) void k_start_mask(const int32_t *__restrict__ 
     }
 }
 
+__global__ __launch_bounds__(256) void k_build_walk(DevGraph g, NodeWalk *__restrict__ out) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < g.n_nodes; n += stride) {
+        NodeWalk w;
+        w.seq_start = g.seq_start[n];
+        w.rev_begin = (int32_t)g.rev_start[n];
+        w.rev_end = (int32_t)g.rev_start[n + 1];
+        w.size = g.node_size[n];
+        w.is_ref = g.is_ref[n] ? 1 : 0;
+        w.af = g.allele_freq[n];
+        out[n] = w;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_popcount(const uint64_t *__restrict__ mask, int64_t n, uint32_t *__restrict__ cnt) {
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) cnt[i] = (uint32_t)__popcll(mask[i]);
@@ -120,6 +134,7 @@ int graph_create_common(gki_graph **out, int64_t n_nodes, const int32_t *h_node_
     HIP_TRY(hipMalloc(&p, (size_t)n_u64 * 8)); g->owned[g->n_owned++] = p; d.seq2 = (const uint64_t *)p;
     HIP_TRY(hipMalloc(&p, (size_t)(d.n_words64 + 1) * 8)); g->owned[g->n_owned++] = p; d.start_mask = (const uint64_t *)p;
     HIP_TRY(hipMalloc(&p, (size_t)(d.n_words64 + 2) * 4)); g->owned[g->n_owned++] = p; d.start_rank = (const uint32_t *)p;
+    HIP_TRY(hipMalloc(&p, (size_t)n_nodes * sizeof(NodeWalk))); g->owned[g->n_owned++] = p; d.walk = (const NodeWalk *)p;
     *out = g;
     return gki_graph_prepare(g);
 }
@@ -134,6 +149,8 @@ int gki_graph_prepare(gki_graph *g) {
     HIP_TRY(hipEventRecord(g->ev_prep0, s));
     HIP_TRY(hipMemsetAsync((void *)d.seq2, 0, (size_t)n_u64 * 8, s));
     GKI_TRY(gki_launch_pack(d.seq, d.n_bases, (uint32_t *)d.seq2, s));
+    hipLaunchKernelGGL(k_build_walk, dim3(stream_grid(d.n_nodes, 256)), dim3(256), 0, s, d, (NodeWalk *)d.walk);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync((void *)d.start_mask, 0, (size_t)(d.n_words64 + 1) * 8, s));
     if (d.n_nonempty > 0) {
         hipLaunchKernelGGL(k_start_mask, dim3(stream_grid(d.n_nonempty, 256)), dim3(256), 0, s, d.nonempty,
