@@ -830,21 +830,30 @@ static int emit_impl(gki_finder *f, typename OutSel<FMT>::T out) {
     // than back to back (both press on the same write path), so one stream is the default.
     static const bool overlap = getenv("GKI_OVERLAP_EMIT") != nullptr;
     if (!overlap) s2 = s;
+    static const bool boundary_first = getenv("GKI_BOUNDARY_FIRST") != nullptr;     // tuning knob
     HIP_TRY(hipEventRecord(f->ev_ready, s));
     HIP_TRY(hipStreamWaitEvent(s2, f->ev_ready, 0));
-    HIP_TRY(hipEventRecord(f->ev[4], s2));
-    if (f->n_boundary_records > 0) GKI_TRY(launch_boundary(f, d, a, out, s2));
-    HIP_TRY(hipEventRecord(f->ev[5], s2));
+    auto run_boundary = [&]() -> int {
+        HIP_TRY(hipEventRecord(f->ev[4], s2));
+        if (f->n_boundary_records > 0) GKI_TRY(launch_boundary(f, d, a, out, s2));
+        HIP_TRY(hipEventRecord(f->ev[5], s2));
+        return GKI_OK;
+    };
+    auto run_interior = [&]() -> int {
+        HIP_TRY(hipEventRecord(f->ev[2], s));
+        if (f->n_interior_records > 0 && f->word_end > f->word_begin) {
+            int64_t n_words = f->word_end - f->word_begin;
+            int64_t blocks = ceil_div(ceil_div(n_words, SW), 4);
+            static const int int_blocks = getenv("GKI_INT_BLOCKS") ? atoi(getenv("GKI_INT_BLOCKS")) : INTERIOR_MAX_BLOCKS;   // tuning knob
+            if (blocks > int_blocks) blocks = int_blocks;
+            GKI_TRY(launch_interior(f, d, a, out, (unsigned)blocks));
+        }
+        HIP_TRY(hipEventRecord(f->ev[3], s));
+        return GKI_OK;
+    };
+    if (boundary_first) { GKI_TRY(run_boundary()); GKI_TRY(run_interior()); }
+    else { GKI_TRY(run_interior()); GKI_TRY(run_boundary()); }
     HIP_TRY(hipEventRecord(f->ev_join, s2));
-    HIP_TRY(hipEventRecord(f->ev[2], s));
-    if (f->n_interior_records > 0 && f->word_end > f->word_begin) {
-        int64_t n_words = f->word_end - f->word_begin;
-        int64_t blocks = ceil_div(ceil_div(n_words, SW), 4);
-        static const int int_blocks = getenv("GKI_INT_BLOCKS") ? atoi(getenv("GKI_INT_BLOCKS")) : INTERIOR_MAX_BLOCKS;   // tuning knob
-        if (blocks > int_blocks) blocks = int_blocks;
-        GKI_TRY(launch_interior(f, d, a, out, (unsigned)blocks));
-    }
-    HIP_TRY(hipEventRecord(f->ev[3], s));
     HIP_TRY(hipStreamWaitEvent(s, f->ev_join, 0));
     f->ev_valid[1] = true; f->ev_valid[2] = true;
     return GKI_OK;

@@ -238,8 +238,50 @@ class DenseKmerFinder:
         return _lib.load().gki_finder_interior_records(self._finder_handle())
 
     def find_only_kmers_starting_at_position(self, node, offset):
-        raise NotImplementedError("find_only_kmers_starting_at_position (kmer_finder.py:170-177) is the per-variant "
-                                  "entry point of UniqueVariantKmersFinder; not on the device path yet")
+        """kmer_finder.py:170-177: the first k-mer of every forward path from (node, offset); records accumulate
+        over calls like in the reference.  Each call behaves like a call on a fresh reference finder (the
+        reference's `_positions_treated` carries over between calls on one object)."""
+        self.find_kmers_starting_at_positions([node], [offset])
+
+    def find_kmers_starting_at_positions(self, nodes, offsets):
+        """Batched form of the above (one kernel launch for many start positions)."""
+        lib = _lib.load()
+        g = self._arrays
+        check_supported_graph(g, self._k)
+        graph = self._device_graph()
+        n_pos = len(nodes)
+        d_nodes = _lib.DeviceArray.from_host(np.ascontiguousarray(nodes, dtype=np.int32))
+        d_offs = _lib.DeviceArray.from_host(np.ascontiguousarray(offsets, dtype=np.int32))
+        d_start = _lib.DeviceArray(n_pos + 1, np.int64)
+        n = C.c_int64(0)
+        args = (graph.handle, self._k, self._max_variant_nodes, int(self._only_save_one_node_per_kmer), d_nodes.ptr,
+                d_offs.ptr, n_pos)
+        _lib.check(lib.gki_forward_count(*args, d_start.ptr, C.byref(n)))
+        dt = [np.int64, np.int32, np.int16, np.int32, np.float64]
+        if n.value:
+            bufs = [_lib.DeviceArray(n.value, d) for d in dt]
+            _lib.check(lib.gki_forward_emit(*args, d_start.ptr, *[b.ptr for b in bufs]))
+            cols = [b.to_host() for b in bufs]
+            for b in bufs:
+                b.free()
+        else:
+            cols = [np.zeros(0, dtype=d) for d in dt]
+        for b in (d_nodes, d_offs, d_start):
+            b.free()
+        kmers, start_nodes, start_offsets, out_nodes, af = cols
+        keep = None
+        if self._whitelist is not None:
+            keep = np.isin(kmers, np.fromiter((int(x) for x in self._whitelist), dtype=np.int64))
+        if self._only_store_nodes is not None:
+            sel = np.isin(out_nodes, np.fromiter((int(x) for x in self._only_store_nodes), dtype=np.int64))
+            keep = sel if keep is None else keep & sel
+        if keep is not None:
+            kmers, start_nodes, start_offsets, out_nodes, af = (c[keep] for c in (kmers, start_nodes, start_offsets, out_nodes, af))
+        new = dict(kmers=kmers, start_nodes=start_nodes, start_offsets=start_offsets, nodes=out_nodes, af=af)
+        if self._cols is None:
+            self._cols = new
+        else:
+            self._cols = {k_: np.concatenate([self._cols[k_], new[k_]]) for k_ in new}
 
     def _require_found(self):
         if self._cols is None:

@@ -202,8 +202,6 @@ def test_unsupported_graphs_raise():
     g2 = GraphArrays.from_dicts({0: "ACGTACGT", 1: "A", 2: "C", 3: "TTTTTTTT"}, {0: [1, 2], 1: [3], 2: [3]}, [0, 1, 3])
     with pytest.raises(NotImplementedError):
         DenseKmerFinder(g2, 4, only_follow_nodes={2})
-    with pytest.raises(NotImplementedError):
-        DenseKmerFinder(g2, 4).find_only_kmers_starting_at_position(0, 2)
 
 
 def test_whitelist_and_only_store_nodes_filters():
@@ -217,3 +215,40 @@ def test_whitelist_and_only_store_nodes_filters():
     f = DenseKmerFinder(g, 31, only_store_nodes=variant_nodes)
     f.find()
     assert_same_records(finder_cols(f), oracle.find(g, 31, None, False, 4, only_store_nodes=variant_nodes))
+
+
+@pytest.mark.parametrize("case", [c for c in TOY if "from_position" in c["kw"]], ids=lambda c: c["name"])
+def test_kmers_from_position_reference_cases(case):
+    # tests/test_kmer_finder.py:118-129, 300-382 of the reference (early-stop searches), exact order
+    g = graph_of(case)
+    kw = dict(case["kw"])
+    pos = kw.pop("from_position")
+    if "only_store_nodes" in kw:
+        kw["only_store_nodes"] = set(kw["only_store_nodes"])
+    f = DenseKmerFinder(g, case["k"], **kw)
+    f.find_only_kmers_starting_at_position(*pos)
+    got = finder_cols(f)
+    exp = dict(kmers=np.array(case["kmers"], np.int64), nodes=np.array(case["nodes"], np.int32),
+               start_nodes=np.array(case["start_nodes"], np.int32),
+               start_offsets=np.array(case["start_offsets"], np.int16),
+               allele_frequencies=np.array(case["allele_frequencies"], np.float64))
+    assert_same_records(got, exp, exact_order=True)
+
+
+def test_kmers_from_positions_random_vs_oracle():
+    rng = np.random.default_rng(31)
+    for it in range(40):
+        k = int(rng.integers(3, 14))
+        M = int(rng.choice([0, 1, 2, 4, 100]))
+        one = bool(rng.integers(0, 2))
+        seqs, edges, lin, af = random_bubble_graph(rng, n_var=int(rng.integers(2, 12)), min_ref=1, max_ref=2 * k,
+                                                   p_indel=0.5, with_af=True)
+        g = GraphArrays.from_dicts(seqs, edges, lin, af)
+        nodes = rng.integers(0, g.n_nodes, size=12)
+        offs = [int(rng.integers(0, max(1, g.node_size[n]))) for n in nodes]
+        f = DenseKmerFinder(g, k, only_save_one_node_per_kmer=one, max_variant_nodes=M)
+        f.find_kmers_starting_at_positions(nodes, offs)
+        got = finder_cols(f)
+        exp = [oracle.find_from_position(g, k, int(n), int(o), one, M) for n, o in zip(nodes, offs)]
+        exp = {key: np.concatenate([e[key] for e in exp]) for key in exp[0]}
+        assert_same_records(got, exp, exact_order=True)
