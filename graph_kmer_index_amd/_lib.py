@@ -61,8 +61,8 @@ SYMBOLS = {
     "gki_finder_synchronize": (_I32, [_P]),
     "gki_finder_kernel_ms": (_I32, [_P, _I32, C.POINTER(C.c_float)]),
     "gki_finder_interior_records": (_I64, [_P]),
-    "gki_forward_count": (_I32, [_P, _I32, _I32, _I32, _P, _P, _I64, _P, C.POINTER(_I64)]),
-    "gki_forward_emit": (_I32, [_P, _I32, _I32, _I32, _P, _P, _I64, _P, _P, _P, _P, _P, _P]),
+    "gki_forward_count": (_I32, [_P, _I32, _I32, _I32, _P, _P, _P, _I64, _P, C.POINTER(_I64)]),
+    "gki_forward_emit": (_I32, [_P, _I32, _I32, _I32, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P]),
     "gki_index_build": (_I32, [_P, _P, _P, _P, _I64, _U64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gki_index_lookup_count": (_I32, [C.POINTER(IndexView), _P, _I64, _I64, _P, C.POINTER(_I64)]),
     "gki_index_lookup_emit": (_I32, [C.POINTER(IndexView), _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),

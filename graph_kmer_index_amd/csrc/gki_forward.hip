@@ -14,11 +14,19 @@ constexpr int FMAX = GKI_MAX_WINDOW_NODES;
 
 struct FwdOut { int64_t *hash; int32_t *start_node; int16_t *start_offset; int32_t *node; double *af; };
 
+// only_follow_nodes (kmer_finder.py:386-388): when a node has successors in the follow set, only those are taken
+// and the variant limit is waived for that step.
+__device__ __forceinline__ bool any_followed(const DevGraph &g, const uint8_t *__restrict__ follow, int32_t node) {
+    if (!follow) return false;
+    for (int64_t e = g.edge_start[node]; e < g.edge_start[node + 1]; e++) if (follow[g.edges[e]]) return true;
+    return false;
+}
+
 template <bool EMIT>
-__device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, int32_t n0, int32_t o0, int64_t idx,
-                             FwdOut out, uint32_t *count_out, int *err) {
+__device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, const uint8_t *__restrict__ follow,
+                             int32_t n0, int32_t o0, int64_t idx, FwdOut out, uint32_t *count_out, int *err) {
     int32_t nd[FMAX], cur[FMAX], end[FMAX];
-    uint8_t have[FMAX], vc[FMAX];
+    uint8_t have[FMAX], vc[FMAX], forced[FMAX];
     uint64_t hs[FMAX];
     uint32_t count = 0;
     const NodeWalk w0 = g.walk[n0];
@@ -32,6 +40,7 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, int
         hs[0] = t > 0 ? gki_extract(g.seq2, w0.seq_start + o0, t) : 0ull;
         have[0] = (uint8_t)t;
         cur[0] = (int32_t)g.edge_start[n0]; end[0] = (int32_t)g.edge_start[n0 + 1];
+        forced[0] = any_followed(g, follow, n0) ? 1 : 0;
         L = 1;
         if (t == k) { cur[0] = end[0]; }       // window complete inside the start node: handled below as a completion
     }
@@ -50,8 +59,11 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, int
         const int32_t e = cur[j]++;
         const int32_t q = g.edges[e];
         const NodeWalk wq = g.walk[q];
-        // kmer_finder.py:397-403: with >= M variant nodes on the path only the linear-ref successor is followed
-        if (vc[j] >= M && !wq.is_ref) continue;
+        if (forced[j]) {
+            if (!follow[q]) continue;                                   // :386-388 forced traversal
+        } else if (vc[j] >= M && !wq.is_ref) {
+            continue;                                                   // :397-403 only the linear-ref successor
+        }
         if (L >= FMAX - 1) { *err = GKI_ERR_WINDOW_TOO_DEEP; continue; }
         const int hv = have[j];
         const int t = wq.size < k - hv ? wq.size : k - hv;
@@ -81,13 +93,15 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, int
             continue;
         }
         cur[L] = (int32_t)g.edge_start[q]; end[L] = (int32_t)g.edge_start[q + 1];
+        forced[L] = any_followed(g, follow, q) ? 1 : 0;
         L++;
     }
     *count_out = count;
 }
 
 template <bool EMIT>
-__global__ __launch_bounds__(64) void k_forward(DevGraph g, int k, int M, int one_node, const int32_t *__restrict__ nodes,
+__global__ __launch_bounds__(64) void k_forward(DevGraph g, int k, int M, int one_node, const uint8_t *__restrict__ follow,
+                                                const int32_t *__restrict__ nodes,
                                                 const int32_t *__restrict__ offsets, int64_t n_pos,
                                                 uint32_t *__restrict__ cnt, const int64_t *__restrict__ rec_start, FwdOut out,
                                                 int *__restrict__ err) {
@@ -96,15 +110,15 @@ __global__ __launch_bounds__(64) void k_forward(DevGraph g, int k, int M, int on
     uint32_t c = 0;
     const int32_t n0 = nodes[i];
     if (n0 < 0 || n0 >= g.n_nodes) { if (!EMIT) cnt[i] = 0; return; }
-    forward_walk<EMIT>(g, k, M, one_node != 0, n0, offsets[i], EMIT ? rec_start[i] : 0, out, &c, err);
+    forward_walk<EMIT>(g, k, M, one_node != 0, follow, n0, offsets[i], EMIT ? rec_start[i] : 0, out, &c, err);
     if (!EMIT) cnt[i] = c;
 }
 }  // namespace
 
 extern "C" {
 
-int gki_forward_count(gki_graph *gr, int k, int max_variant_nodes, int one_node, const void *d_nodes, const void *d_offsets,
-                      int64_t n_pos, void *d_rec_start, int64_t *n_records) {
+int gki_forward_count(gki_graph *gr, int k, int max_variant_nodes, int one_node, const void *d_follow, const void *d_nodes,
+                      const void *d_offsets, int64_t n_pos, void *d_rec_start, int64_t *n_records) {
     *n_records = 0;
     if (k < 1 || k > GKI_MAX_K) return gki_set_error(GKI_ERR_BAD_ARG, "k must be in 1..31");
     if (n_pos <= 0) { HIP_TRY(hipMemset(d_rec_start, 0, 8)); return GKI_OK; }
@@ -116,7 +130,8 @@ int gki_forward_count(gki_graph *gr, int k, int max_variant_nodes, int one_node,
     HIP_TRY(hipMemset(d_err, 0, 4));
     FwdOut none{nullptr, nullptr, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(k_forward<false>, dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, k, max_variant_nodes > 250 ? 250 : max_variant_nodes,
-                       one_node, (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, cnt, (const int64_t *)nullptr, none, d_err);
+                       one_node, (const uint8_t *)d_follow, (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, cnt,
+                       (const int64_t *)nullptr, none, d_err);
     int rc = hipGetLastError() == hipSuccess ? GKI_OK : gki_set_error(GKI_ERR_HIP, "k_forward launch failed");
     if (rc == GKI_OK) rc = gki_scan_u32_to_i64(cnt, n_pos, (int64_t *)d_rec_start, tmp, tmp_bytes, 0);
     int64_t total = 0; int herr = 0;
@@ -130,8 +145,8 @@ int gki_forward_count(gki_graph *gr, int k, int max_variant_nodes, int one_node,
     return GKI_OK;
 }
 
-int gki_forward_emit(gki_graph *gr, int k, int max_variant_nodes, int one_node, const void *d_nodes, const void *d_offsets,
-                     int64_t n_pos, const void *d_rec_start, void *d_hashes, void *d_start_nodes, void *d_start_offsets,
+int gki_forward_emit(gki_graph *gr, int k, int max_variant_nodes, int one_node, const void *d_follow, const void *d_nodes,
+                     const void *d_offsets, int64_t n_pos, const void *d_rec_start, void *d_hashes, void *d_start_nodes, void *d_start_offsets,
                      void *d_nodes_out, void *d_af64) {
     if (n_pos <= 0) return GKI_OK;
     int *d_err = nullptr;
@@ -139,8 +154,8 @@ int gki_forward_emit(gki_graph *gr, int k, int max_variant_nodes, int one_node, 
     HIP_TRY(hipMemset(d_err, 0, 4));
     FwdOut out{(int64_t *)d_hashes, (int32_t *)d_start_nodes, (int16_t *)d_start_offsets, (int32_t *)d_nodes_out, (double *)d_af64};
     hipLaunchKernelGGL(k_forward<true>, dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, k, max_variant_nodes > 250 ? 250 : max_variant_nodes,
-                       one_node, (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, (uint32_t *)nullptr,
-                       (const int64_t *)d_rec_start, out, d_err);
+                       one_node, (const uint8_t *)d_follow, (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos,
+                       (uint32_t *)nullptr, (const int64_t *)d_rec_start, out, d_err);
     hipError_t e = hipGetLastError();
     hipError_t e2 = hipDeviceSynchronize();
     (void)hipFree(d_err);

@@ -93,9 +93,8 @@ class DenseKmerFinder:
         self._stop_at_critical_path_number = stop_at_critical_path_number
         self._whitelist = whitelist
         self._only_store_nodes = only_store_nodes
-        if only_follow_nodes is not None:
-            raise NotImplementedError("only_follow_nodes (forced traversal, kmer_finder.py:386-388) is not "
-                                      "implemented on the device path")
+        self._only_follow_nodes = only_follow_nodes   # honoured by find_only_kmers_starting_at_position (its only caller,
+        # unique_variant_kmers.py:91-96); find() with forced traversal raises
         self._params_cache = None
         self._cols = None          # host columns after find()
         self._device = None
@@ -139,6 +138,9 @@ class DenseKmerFinder:
         return self._params_cache[0]
 
     def _make_params(self):
+        if self._only_follow_nodes is not None:
+            raise NotImplementedError("find() with only_follow_nodes (forced traversal, kmer_finder.py:386-388) is not "
+                                      "implemented; find_only_kmers_starting_at_position honours it")
         g, k = self._arrays, self._k
         check_supported_graph(g, k)
         if self._critical_graph_paths is None:
@@ -254,8 +256,13 @@ class DenseKmerFinder:
         d_offs = _lib.DeviceArray.from_host(np.ascontiguousarray(offsets, dtype=np.int32))
         d_start = _lib.DeviceArray(n_pos + 1, np.int64)
         n = C.c_int64(0)
-        args = (graph.handle, self._k, self._max_variant_nodes, int(self._only_save_one_node_per_kmer), d_nodes.ptr,
-                d_offs.ptr, n_pos)
+        d_follow = None
+        if self._only_follow_nodes is not None:
+            mask = np.zeros(g.n_nodes, dtype=np.uint8)
+            mask[np.fromiter((int(x) for x in self._only_follow_nodes), dtype=np.int64)] = 1
+            d_follow = _lib.DeviceArray.from_host(mask)
+        args = (graph.handle, self._k, self._max_variant_nodes, int(self._only_save_one_node_per_kmer),
+                None if d_follow is None else d_follow.ptr, d_nodes.ptr, d_offs.ptr, n_pos)
         _lib.check(lib.gki_forward_count(*args, d_start.ptr, C.byref(n)))
         dt = [np.int64, np.int32, np.int16, np.int32, np.float64]
         if n.value:
@@ -266,7 +273,7 @@ class DenseKmerFinder:
                 b.free()
         else:
             cols = [np.zeros(0, dtype=d) for d in dt]
-        for b in (d_nodes, d_offs, d_start):
+        for b in (d_nodes, d_offs, d_start) + (() if d_follow is None else (d_follow,)):
             b.free()
         kmers, start_nodes, start_offsets, out_nodes, af = cols
         keep = None

@@ -152,11 +152,13 @@ int64_t gki_finder_interior_records(const gki_finder *f);
  * (kmer_finder.py:170-177): for every start position (d_nodes[i], d_offsets[i]) every forward path of exactly k
  * bases gives one window; records carry the END position like all finder records.  count -> emit; records of
  * start position i are [rec_start[i], rec_start[i+1]) in depth-first successor order (the reference's order).
- * d_nodes int32[n_pos], d_offsets int32[n_pos], d_rec_start int64[n_pos+1]; output = the v2 columns. */
-int gki_forward_count(gki_graph *g, int k, int max_variant_nodes, int one_node, const void *d_nodes,
-                      const void *d_offsets, int64_t n_pos, void *d_rec_start, int64_t *n_records);
-int gki_forward_emit(gki_graph *g, int k, int max_variant_nodes, int one_node, const void *d_nodes,
-                     const void *d_offsets, int64_t n_pos, const void *d_rec_start, void *d_hashes,
+ * d_nodes int32[n_pos], d_offsets int32[n_pos], d_rec_start int64[n_pos+1]; output = the v2 columns.
+ * d_follow: uint8[n_nodes] membership of only_follow_nodes (:386-388) or NULL. */
+int gki_forward_count(gki_graph *g, int k, int max_variant_nodes, int one_node, const void *d_follow,
+                      const void *d_nodes, const void *d_offsets, int64_t n_pos, void *d_rec_start,
+                      int64_t *n_records);
+int gki_forward_emit(gki_graph *g, int k, int max_variant_nodes, int one_node, const void *d_follow,
+                     const void *d_nodes, const void *d_offsets, int64_t n_pos, const void *d_rec_start, void *d_hashes,
                      void *d_start_nodes, void *d_start_offsets, void *d_nodes_out, void *d_af64);
 
 /* ---------------------------------------------------------------- CollisionFreeKmerIndex (A9)

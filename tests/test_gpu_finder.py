@@ -201,7 +201,7 @@ def test_unsupported_graphs_raise():
         DenseKmerFinder(g, 4).find()
     g2 = GraphArrays.from_dicts({0: "ACGTACGT", 1: "A", 2: "C", 3: "TTTTTTTT"}, {0: [1, 2], 1: [3], 2: [3]}, [0, 1, 3])
     with pytest.raises(NotImplementedError):
-        DenseKmerFinder(g2, 4, only_follow_nodes={2})
+        DenseKmerFinder(g2, 4, only_follow_nodes={2}).find()
 
 
 def test_whitelist_and_only_store_nodes_filters():
@@ -252,3 +252,22 @@ def test_kmers_from_positions_random_vs_oracle():
         exp = [oracle.find_from_position(g, k, int(n), int(o), one, M) for n, o in zip(nodes, offs)]
         exp = {key: np.concatenate([e[key] for e in exp]) for key in exp[0]}
         assert_same_records(got, exp, exact_order=True)
+
+
+def test_only_follow_nodes_from_position():
+    # unique_variant_kmers.py:91-96: only_store_nodes = only_follow_nodes = {variant node}, early-stop search
+    rng = np.random.default_rng(41)
+    for it in range(30):
+        k = int(rng.integers(4, 12))
+        seqs, edges, lin, af = random_bubble_graph(rng, n_var=int(rng.integers(2, 8)), min_ref=2, max_ref=2 * k,
+                                                   p_indel=0.4, shuffle_succ=False)
+        g = GraphArrays.from_dicts(seqs, edges, lin, af)
+        variant = np.nonzero((g.is_ref == 0) & (g.exists != 0))[0]
+        node = int(rng.choice(variant))
+        pred = int(g.rev_edges[g.rev_start[node]])
+        off = int(rng.integers(0, max(1, g.node_size[pred])))
+        for M in (0, 1, 4):
+            f = DenseKmerFinder(g, k, max_variant_nodes=M, only_store_nodes={node}, only_follow_nodes={node})
+            f.find_only_kmers_starting_at_position(pred, off)
+            exp = oracle.find_from_position(g, k, pred, off, False, M, only_store_nodes={node}, only_follow_nodes={node})
+            assert_same_records(finder_cols(f), exp, exact_order=True)
