@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--linear", action="store_true", help="diagnostic: linear chain graph without variants (BASELINE configs[1] shape)")
     ap.add_argument("--all-nodes", action="store_true", help="diagnostic: only_save_one_node_per_kmer=False")
+    ap.add_argument("--pretend-shard", default=None, help="diagnostic: R/W -> run only rank R's shard of W on this one GPU")
     ap.add_argument("--verify", action="store_true", help="size-independent checks on the full output (slow)")
     args = ap.parse_args()
 
@@ -88,7 +89,17 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist            # gloo: barrier + max of a scalar only
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        # gloo prints its connection banner on stdout; keep stdout clean for the one JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     from graph_kmer_index_amd import _lib, DenseKmerFinder, CriticalGraphPaths, DeviceGraph
     from graph_kmer_index_amd.graph import synthetic_snp_graph, synthetic_linear_graph
@@ -112,11 +123,14 @@ def main():
         log("graph: %d nodes, %d bases (+%d alt), %d critical points; generate %.1fs, critical paths %.2fs, "
             "upload+prepare %.2fs" % (g.n_nodes, G, len(g.seq) - G, len(cp), t_gen, t_crit, t_up))
     g._device = dg
-    a, b = shard_range(g, cp, rank, world)
+    shard_r, shard_w = rank, world
+    if args.pretend_shard:
+        shard_r, shard_w = (int(x) for x in args.pretend_shard.split("/"))
+    a, b = shard_range(g, cp, shard_r, shard_w)
     finder = DenseKmerFinder(g, k, critical_graph_paths=cp, only_save_one_node_per_kmer=not args.all_nodes,
                              max_variant_nodes=args.max_variant_nodes,
-                             start_at_critical_path_number=a if world > 1 else None,
-                             stop_at_critical_path_number=b if world > 1 else None)
+                             start_at_critical_path_number=a if shard_w > 1 else None,
+                             stop_at_critical_path_number=b if shard_w > 1 else None)
 
     def barrier():
         _lib.check(lib.gki_device_synchronize())

@@ -74,6 +74,7 @@ struct DevGraph {
     const uint32_t *start_rank;              // number of node starts in words before this one
     const NodeWalk *walk;                    // [n_nodes] packed per-node records for the predecessor walk
     const int32_t *nonempty;                 // ids of non-empty nodes, ascending (= sequence order)
+    const int32_t *node_rank;                // [n_nodes] rank of a non-empty node in `nonempty` (unused for empty ones)
     int64_t n_nonempty;
 };
 

@@ -34,6 +34,7 @@ struct NodeEmit {       // per-node constants of the interior kernel, 32 B
 struct FindArgs {
     int32_t k, M, one_node, has_lossy;
     int64_t node_begin, off_begin, node_end, off_end;
+    int64_t n0, n1;          // nodes [n0, n1) are the only ones this run touches (per-shard cost, not per-graph)
 };
 
 struct OutFlat { uint64_t *hash; uint32_t *node; uint64_t *ref_offset; float *af; };
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
     LevelLo below[MAXN];
     const int k = a.k;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < g.n_nodes; n += stride) {
+    for (int64_t n = a.n0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.n1; n += stride) {
         const NodeWalk wn = g.walk[n];
         const int32_t size = wn.size;
         const int32_t bl = bnd_len_of(g, a, lossy, n, size);
@@ -276,12 +277,12 @@ __global__ __launch_bounds__(256) void k_emit_boundary(DevGraph g, FindArgs a, c
     const int k = a.k;
     const uint64_t kmask = (1ull << (2 * k)) - 1ull;
     const int64_t n_threads = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + wib * 64; base < g.n_nodes; base += n_threads) {
+    for (int64_t base = a.n0 + (int64_t)blockIdx.x * blockDim.x + wib * 64; base < a.n1; base += n_threads) {
         const int64_t n = base + lane;
         int L = 0, o_lo = 0, hi = 0;
         int64_t idx = 0, pos0 = 0;
         uint64_t own = 0;
-        if (n < g.n_nodes && bcount[n] > 0) {
+        if (n < a.n1 && bcount[n] > 0) {
             const int32_t size = g.node_size[n];
             const int32_t bl = bnd_len_of(g, a, lossy, n, size);
             idx = rec_base[n];
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const int64_t n_threads = (int64_t)gridDim.x * blockDim.x;
     int n_ev = 0;
-    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + wib * 64; base < g.n_nodes; base += n_threads) {
+    for (int64_t base = a.n0 + (int64_t)blockIdx.x * blockDim.x + wib * 64; base < a.n1; base += n_threads) {
         const int64_t n = base + lane;
         int L = 0, o_lo = 0, hi = 0;
         int64_t idx = 0, pos0 = 0;
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
         int t_cum = 0, t_vc = 0, t_evf = 0, t_evt = 0;
         uint64_t t_ctx = 0;
         double t_maf = 0.0;
-        if (n < g.n_nodes && bcount[n] > 0) {
+        if (n < a.n1 && bcount[n] > 0) {
             const NodeWalk wn = g.walk[n];
             const int32_t bl = bnd_len_of(g, a, lossy, n, wn.size);
             idx = rec_base[n];
@@ -594,19 +595,22 @@ __global__ __launch_bounds__(256) void k_node_emit(DevGraph g, FindArgs a, const
                                                    const uint32_t *__restrict__ bcount,
                                                    const int64_t *__restrict__ rec_base, NodeEmit *__restrict__ ne) {
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < g.n_nonempty; j += stride) {
-        const int32_t n = g.nonempty[j];
+    // Only the run's nodes are refreshed; records of other nodes may be stale from an earlier run, which is why the
+    // interior kernels also bound p by the run's base range [p_begin, p_end).
+    for (int64_t n = a.n0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.n1; n += stride) {
         const int32_t size = g.node_size[n];
-        int64_t lo = bnd_len_of(g, a, lossy, n, size);
+        if (size <= 0) continue;
+        const bool inside = n >= a.node_begin && n <= a.node_end;
+        int64_t lo = inside ? bnd_len_of(g, a, lossy, n, size) : 0;
         if (n == a.node_begin && a.off_begin > lo) lo = a.off_begin;
         const int64_t ss = g.seq_start[n];
         NodeEmit e;
-        e.glo = (n < a.node_begin || n > a.node_end) ? (int64_t)0x7FFFFFFFFFFFFFFFll : ss + lo;   // out of range: never
-        e.D = rec_base[n] + (int64_t)bcount[n] - lo - ss;
+        e.glo = inside ? ss + lo : (int64_t)0x7FFFFFFFFFFFFFFFll;        // outside the run: never interior
+        e.D = inside ? rec_base[n] + (int64_t)bcount[n] - lo - ss : 0;
         e.E = g.pos_base[n] - ss;
-        e.node = n;
+        e.node = (int32_t)n;
         e.af = (float)g.allele_freq[n];
-        ne[j] = e;                      // indexed by rank among non-empty nodes: what the bitmap popcount yields
+        ne[g.node_rank[n]] = e;         // indexed by rank among non-empty nodes: what the bitmap popcount yields
     }
 }
 
@@ -639,7 +643,7 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 
 __global__ __launch_bounds__(256) void k_emit_interior_flat(DevGraph g, FindArgs a, const NodeEmit *__restrict__ ne,
                                                             OutFlat out, int64_t word_begin, int64_t word_end,
-                                                            int64_t p_end) {
+                                                            int64_t p_begin, int64_t p_end) {
     __shared__ uint4 s_ne[4][NE_CAP * 2];
     __shared__ uint64_t s_seq[4][SEQ_W];
     const int lane = threadIdx.x & 63;
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(256) void k_emit_interior_flat(DevGraph g, FindArgs
                 const int64_t glo = (int64_t)(((uint64_t)ea.y << 32) | ea.x);
                 const int64_t D = (int64_t)(((uint64_t)ea.w << 32) | ea.z);
                 const int64_t E = (int64_t)(((uint64_t)eb.y << 32) | eb.x);
-                if (p >= glo && p < p_end) {
+                if (p >= glo && p >= p_begin && p < p_end) {
                     const int64_t P = p - (k - 1);                       // >= 0 for an interior position
                     const int si = (int)((P >> 5) - sb);
                     const int sh = (int)(P & 31) * 2;
@@ -713,7 +717,7 @@ __global__ __launch_bounds__(256) void k_emit_interior_flat(DevGraph g, FindArgs
 template <int FMT>
 __global__ __launch_bounds__(256) void k_emit_interior(DevGraph g, FindArgs a, const NodeEmit *__restrict__ ne,
                                                        typename OutSel<FMT>::T out, int64_t word_begin,
-                                                       int64_t word_end, int64_t p_end) {
+                                                       int64_t word_end, int64_t p_begin, int64_t p_end) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -725,7 +729,7 @@ __global__ __launch_bounds__(256) void k_emit_interior(DevGraph g, FindArgs a, c
         const int64_t p = w * 64 + lane;
         const uint32_t j = rank + (uint32_t)__popcll(mask & lane_mask) - 1u;
         const NodeEmit e = ne[j];
-        if (p < e.glo || p >= p_end) continue;
+        if (p < e.glo || p < p_begin || p >= p_end) continue;
         const uint64_t h = gki_extract(g.seq2, p - (k - 1), k);
         if (FMT == 0) {
             put(out, p + e.D, h, e.node, e.node, 0, p + e.E, (double)e.af);
@@ -762,7 +766,7 @@ struct gki_finder {
     int *d_err; int64_t *d_totals; unsigned long long *d_bsum; 
     FindArgs args;
     int64_t n_records, n_boundary_records, n_interior_records;
-    int64_t word_begin, word_end, p_end;
+    int64_t word_begin, word_end, p_begin, p_end;
     bool counted;
     hipEvent_t ev[8];    // pairs: 0/1 count-boundary, 2/3 emit-interior, 4/5 emit-boundary, 6/7 scan + per-node constants
     hipEvent_t ev_ready, ev_join;
@@ -778,7 +782,7 @@ static int launch_boundary_fmt(gki_finder *f, const DevGraph &d, const FindArgs 
         dbg_set = true;
     }
     static const int bnd_blocks = getenv("GKI_BND_BLOCKS") ? atoi(getenv("GKI_BND_BLOCKS")) : 0;   // tuning knob
-    int gb = stream_grid(d.n_nodes, 256);
+    int gb = stream_grid(a.n1 - a.n0, 256);
     if (bnd_blocks > 0 && gb > bnd_blocks) gb = bnd_blocks;
     const dim3 grid(gb), block(256);
     if (a.one_node) {
@@ -806,16 +810,16 @@ static int launch_interior(gki_finder *f, const DevGraph &d, const FindArgs &a, 
     hipStream_t s = f->stream;
     if (out.hash && out.node && out.ref_offset && out.af)
         hipLaunchKernelGGL(k_emit_interior_flat, dim3(blocks), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end,
-                           f->p_end);
+                           f->p_begin, f->p_end);
     else
         hipLaunchKernelGGL(k_emit_interior<0>, dim3(blocks), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end,
-                           f->p_end);
+                           f->p_begin, f->p_end);
     HIP_TRY(hipGetLastError());
     return GKI_OK;
 }
 static int launch_interior(gki_finder *f, const DevGraph &d, const FindArgs &a, OutV2 out, unsigned blocks) {
     hipLaunchKernelGGL(k_emit_interior<1>, dim3(blocks), dim3(256), 0, f->stream, d, a, f->ne, out, f->word_begin, f->word_end,
-                       f->p_end);
+                       f->p_begin, f->p_end);
     HIP_TRY(hipGetLastError());
     return GKI_OK;
 }
@@ -916,28 +920,38 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
     a.one_node = p->one_node_per_kmer ? 1 : 0;
     a.has_lossy = p->h_lossy_crit ? 1 : 0;
     a.node_begin = p->node_begin; a.off_begin = p->off_begin; a.node_end = p->node_end; a.off_end = p->off_end;
+    a.n0 = p->node_begin < d.n_nodes ? p->node_begin : d.n_nodes;
+    a.n1 = p->node_end < d.n_nodes ? p->node_end + 1 : d.n_nodes;
     f->args = a;
+    const int64_t n_run = a.n1 - a.n0;
     if (a.has_lossy) HIP_TRY(hipMemcpyAsync(f->lossy, p->h_lossy_crit, (size_t)d.n_nodes * 2, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(f->d_err, 0, 4, s));
     HIP_TRY(hipMemsetAsync(f->d_bsum, 0, 8, s));
 
     HIP_TRY(hipEventRecord(f->ev[0], s));
-    if (a.has_lossy)
-        hipLaunchKernelGGL(k_count_boundary<true>, dim3(stream_grid(d.n_nodes, 256)), dim3(256), 0, s, d, a, f->lossy,
-                           f->bcount, f->total, f->d_err);
-    else
-        hipLaunchKernelGGL(k_count_boundary<false>, dim3(stream_grid(d.n_nodes, 256)), dim3(256), 0, s, d, a, f->lossy,
-                           f->bcount, f->total, f->d_err);
-    HIP_TRY(hipGetLastError());
+    if (n_run > 0) {
+        if (a.has_lossy)
+            hipLaunchKernelGGL(k_count_boundary<true>, dim3(stream_grid(n_run, 256)), dim3(256), 0, s, d, a, f->lossy,
+                               f->bcount, f->total, f->d_err);
+        else
+            hipLaunchKernelGGL(k_count_boundary<false>, dim3(stream_grid(n_run, 256)), dim3(256), 0, s, d, a, f->lossy,
+                               f->bcount, f->total, f->d_err);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(f->ev[1], s));
     HIP_TRY(hipEventRecord(f->ev[6], s));
-    GKI_TRY(gki_scan_u32_to_i64(f->total, d.n_nodes, f->rec_base, f->scan_tmp, f->scan_tmp_bytes, s));
-    hipLaunchKernelGGL(k_node_emit, dim3(stream_grid(d.n_nonempty, 256)), dim3(256), 0, s, d, a, f->lossy, f->bcount,
-                       f->rec_base, f->ne);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_sum_u32, dim3(stream_grid(d.n_nodes, 256)), dim3(256), 0, s, f->bcount, d.n_nodes, f->d_bsum);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, s, f->rec_base, d.n_nodes, f->d_err, f->d_totals);
+    // records of nodes [n0, n1) only: rec_base[n0 + i] = exclusive prefix inside the run, rec_base[n1] = total
+    GKI_TRY(gki_scan_u32_to_i64(f->total + a.n0, n_run, f->rec_base + a.n0, f->scan_tmp, f->scan_tmp_bytes, s));
+    if (n_run > 0) {
+        hipLaunchKernelGGL(k_node_emit, dim3(stream_grid(n_run, 256)), dim3(256), 0, s, d, a, f->lossy, f->bcount,
+                           f->rec_base, f->ne);
+        HIP_TRY(hipGetLastError());
+    }
+    if (n_run > 0) {
+        hipLaunchKernelGGL(k_sum_u32, dim3(stream_grid(n_run, 256)), dim3(256), 0, s, f->bcount + a.n0, n_run, f->d_bsum);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, s, f->rec_base, a.n1, f->d_err, f->d_totals);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(f->ev[7], s));
     int64_t tot[2];
@@ -963,6 +977,7 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
     }
     f->word_begin = p0 >> 6;
     f->word_end = ceil_div(p1, 64);
+    f->p_begin = p0;
     f->p_end = p1;
     f->ev_valid[0] = true; f->ev_valid[3] = true;
     f->counted = true;

@@ -100,13 +100,13 @@ int graph_create_common(gki_graph **out, int64_t n_nodes, const int32_t *h_node_
     d.n_nodes = n_nodes; d.n_bases = n_bases; d.n_words64 = ceil_div(n_bases, 64);
 
     std::vector<int64_t> seq_start((size_t)n_nodes + 1);
-    std::vector<int32_t> nonempty;
+    std::vector<int32_t> nonempty, node_rank((size_t)n_nodes, 0);
     nonempty.reserve((size_t)n_nodes);
     seq_start[0] = 0;
     for (int64_t n = 0; n < n_nodes; n++) {
         if (h_node_size[n] < 0) { delete g; return gki_set_error(GKI_ERR_BAD_ARG, "negative node size"); }
         seq_start[n + 1] = seq_start[n] + h_node_size[n];
-        if (h_node_size[n] > 0) nonempty.push_back((int32_t)n);
+        if (h_node_size[n] > 0) { node_rank[(size_t)n] = (int32_t)nonempty.size(); nonempty.push_back((int32_t)n); }
     }
     if (seq_start[n_nodes] != n_bases) { delete g; return gki_set_error(GKI_ERR_BAD_ARG, "sum(node_size) != n_bases"); }
     d.n_nonempty = (int64_t)nonempty.size();
@@ -121,6 +121,7 @@ int graph_create_common(gki_graph **out, int64_t n_nodes, const int32_t *h_node_
     GKI_TRY(upload(g, h_allele_freq, n_nodes, &d.allele_freq));
     GKI_TRY(upload(g, h_position_base ? h_position_base : seq_start.data(), n_nodes, &d.pos_base));
     GKI_TRY(upload(g, nonempty.data(), d.n_nonempty, &d.nonempty));
+    GKI_TRY(upload(g, node_rank.data(), n_nodes, &d.node_rank));
     if (seq_on_device) {
         d.seq = (const uint8_t *)d_seq;
         g->owns_seq = false;
