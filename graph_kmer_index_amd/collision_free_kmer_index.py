@@ -265,6 +265,34 @@ class CollisionFreeKmerIndex:
         return cls(data["hashes_to_index"], data["n_kmers"], data["nodes"], data["ref_offsets"], data["kmers"],
                    data["modulo"], data["frequencies"], af)
 
+    def set_frequencies_using_other_index(self, other, multiplier=1, min_frequency=1):
+        """:246-265 -- every record gets max(min_frequency, other.get_frequency(kmer) * multiplier), where
+        get_frequency adds the hit of the reverse complement (k=31, :336-352).  Two batched probes of `other`."""
+        kmers = np.asarray(self._kmers)
+        uniq, inverse = np.unique(kmers, return_inverse=True)
+
+        def first_hit_frequency(queries):
+            hs, pos, _ = other._device_index().lookup_positions(queries, max_hits=1000000000000000)
+            f = np.zeros(len(queries), dtype=np.int64)
+            has = np.diff(hs) > 0
+            f[has] = np.asarray(other._frequencies)[pos[hs[:-1][has]]]
+            return f
+
+        from .kmer_hashing import kmer_hashes_to_reverse_complement_hash
+        freq = first_hit_frequency(uniq) + first_hit_frequency(kmer_hashes_to_reverse_complement_hash(uniq, 31))
+        value = np.maximum(min_frequency, freq * multiplier)
+        self._frequencies = np.asarray(self._frequencies).copy()
+        self._frequencies[:] = value[inverse].astype(self._frequencies.dtype)
+        self._invalidate_device()
+
+    def convert_kmers_to_complement(self, k=31, skip_frequencies=True):
+        """:470-490 -- rebuild the index on the complement (not reversed) hashes."""
+        from .kmer_hashing import kmer_hashes_to_complement_hashes
+        new_kmers = kmer_hashes_to_complement_hashes(np.asarray(self._kmers), k)
+        return CollisionFreeKmerIndex.from_flat_kmers(
+            FlatKmers(new_kmers, self._nodes, self._ref_offsets, self._allele_frequencies), modulo=self._modulo,
+            skip_frequencies=skip_frequencies)
+
     def set_frequencies(self, skip=False):
         """:267-293 -- rebuilds the frequency column on device from the current payload."""
         n = len(self._kmers)

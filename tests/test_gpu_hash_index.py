@@ -195,3 +195,32 @@ def test_index_from_finder_output_float64_af():
         assert getattr(idx, name).dtype == o[name].dtype, name
         assert np.array_equal(getattr(idx, name), o[name]), name
     assert idx.get_frequency(int(fl._hashes[0])) >= 1
+
+
+def test_set_frequencies_using_other_index_and_complement():
+    rng = np.random.default_rng(8)
+    k = 31
+    pool = rng.integers(0, 4 ** k, size=300, dtype=np.uint64)
+    rc = oracle.reverse_complement(pool, k)
+    other_kmers = np.concatenate([pool[:200], rc[100:250], pool[:50]])
+    other = CollisionFreeKmerIndex.from_flat_kmers(
+        FlatKmers(other_kmers, np.arange(len(other_kmers), dtype=np.uint32),
+                  rng.integers(0, 5, size=len(other_kmers)).astype(np.uint64), np.ones(len(other_kmers), np.float32)),
+        modulo=1009)
+    mine_kmers = np.concatenate([pool, pool[:30]])
+    mine = CollisionFreeKmerIndex.from_flat_kmers(
+        FlatKmers(mine_kmers, np.arange(len(mine_kmers), dtype=np.uint32), np.zeros(len(mine_kmers), np.uint64),
+                  np.ones(len(mine_kmers), np.float32)), modulo=257)
+    mine.set_frequencies_using_other_index(other, multiplier=2, min_frequency=1)
+    for i in range(0, len(mine._kmers), 7):
+        km = int(mine._kmers[i])
+        f = 0
+        for q in (km, int(oracle.reverse_complement(np.array([km], np.uint64), k)[0])):
+            r = other.get(q, max_hits=10 ** 15)
+            if r[0] is not None:
+                f += int(r[2][0])
+        assert int(mine._frequencies[i]) == max(1, 2 * f)
+        assert other.get_frequency(km) == f
+    comp = mine.convert_kmers_to_complement(k=k)
+    assert sorted(np.asarray(comp._kmers).tolist()) == sorted(oracle.complement(mine_kmers, k).tolist())
+    assert comp._modulo == mine._modulo
