@@ -23,12 +23,15 @@ namespace {
 
 constexpr int MAXN = GKI_MAX_WINDOW_NODES;
 
-struct NodeEmit {       // per-node constants of the interior kernel, 32 B
+struct NodeEmit {       // per-node constants of the interior kernels, 48 B (12 dwords)
     int64_t glo;        // global base index of the first interior position of this node in this run
     int64_t D;          // record index of interior position p is p + D
     int64_t E;          // position id of base p is p + E
     int32_t node;       // node id
     float af;           // allele frequency as float32 (flat_kmers.py:90)
+    int32_t cnt;        // interior positions of this node in this run: [glo, glo + cnt)
+    int32_t pad0;
+    int64_t pad1;
 };
 
 struct FindArgs {
@@ -610,6 +613,10 @@ __global__ __launch_bounds__(256) void k_node_emit(DevGraph g, FindArgs a, const
         e.E = g.pos_base[n] - ss;
         e.node = (int32_t)n;
         e.af = (float)g.allele_freq[n];
+        int64_t hi = size;
+        if (n == a.node_end && a.off_end < hi) hi = a.off_end;
+        e.cnt = (inside && hi > lo) ? (int32_t)(hi - lo) : 0;
+        e.pad0 = 0; e.pad1 = 0;
         ne[g.node_rank[n]] = e;         // indexed by rank among non-empty nodes: what the bitmap popcount yields
     }
 }
@@ -644,7 +651,7 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
 __global__ __launch_bounds__(256) void k_emit_interior_flat(DevGraph g, FindArgs a, const NodeEmit *__restrict__ ne,
                                                             OutFlat out, int64_t word_begin, int64_t word_end,
                                                             int64_t p_begin, int64_t p_end) {
-    __shared__ uint4 s_ne[4][NE_CAP * 2];
+    __shared__ uint4 s_ne[4][NE_CAP * 3];
     __shared__ uint64_t s_seq[4][SEQ_W];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -684,14 +691,14 @@ __global__ __launch_bounds__(256) void k_emit_interior_flat(DevGraph g, FindArgs
             if (u1 > nw) u1 = nw;
             if (u1 <= u0) u1 = u0 + 1;
             const uint32_t n_rec = (uint32_t)__builtin_amdgcn_readlane((int)last_j_v, u1 - 1) - jbase + 1u;
-            for (uint32_t t = lane; t < 2u * n_rec; t += 64) my_ne[t] = ne4[2 * (int64_t)jbase + t];
+            for (uint32_t t = lane; t < 3u * n_rec; t += 64) my_ne[t] = ne4[3 * (int64_t)jbase + t];
             // ---- stage 3: words of the chunk, registers + LDS only
             for (int u = u0; u < u1; u++) {
                 const uint64_t mask = readlane64(mask_v, u);
                 const uint32_t rank = (uint32_t)__builtin_amdgcn_readlane((int)rank_v, u);
                 const int64_t p = (sw0 + u) * 64 + lane;
                 const uint32_t jj = rank + (uint32_t)__popcll(mask & lane_mask) - 1u - jbase;
-                const uint4 ea = my_ne[2 * jj], eb = my_ne[2 * jj + 1];
+                const uint4 ea = my_ne[3 * jj], eb = my_ne[3 * jj + 1];
                 const int64_t glo = (int64_t)(((uint64_t)ea.y << 32) | ea.x);
                 const int64_t D = (int64_t)(((uint64_t)ea.w << 32) | ea.z);
                 const int64_t E = (int64_t)(((uint64_t)eb.y << 32) | eb.x);
@@ -709,6 +716,87 @@ __global__ __launch_bounds__(256) void k_emit_interior_flat(DevGraph g, FindArgs
                 }
             }
             u0 = u1;
+        }
+    }
+}
+
+// Run-aligned variant.  The word-driven kernel above starts every wave store at record index p + D, which is
+// not a multiple of 8/16 records once bubbles have shifted D, so each 512-byte store touches 9 cache lines
+// instead of 8 (the store microbenchmark loses 13 % to exactly that).  Here the lanes are mapped to OUTPUT
+// records instead: the wave walks the node runs of its 4096-base window (from the per-node table in LDS, all
+// values wave-uniform) and covers each run [glo + D, glo + cnt + D) with 64-record groups that start at a
+// multiple of 16 records, i.e. on a cache-line boundary of all four columns.
+template <int SWT>
+__global__ __launch_bounds__(256) void k_emit_interior_runs(DevGraph g, FindArgs a, const NodeEmit *__restrict__ ne,
+                                                            OutFlat out, int64_t word_begin, int64_t word_end,
+                                                            int64_t p_begin, int64_t p_end) {
+    __shared__ uint32_t s_ne[4][NE_CAP * 12];
+    __shared__ uint64_t s_seq[4][2 * SWT + 8];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wib;
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const int k = a.k;
+    const uint64_t kmask = (1ull << (2 * k)) - 1ull;
+    const int64_t n_seq_words = ((g.n_bases + 31) >> 5) + 2;
+    const uint32_t *ne32 = reinterpret_cast<const uint32_t *>(ne);
+    uint32_t *my_ne = s_ne[wib];
+    uint64_t *my_seq = s_seq[wib];
+    for (int64_t sw0 = word_begin + wave * SWT; sw0 < word_end; sw0 += n_waves * SWT) {
+        const int nw = (int)((word_end - sw0) < SWT ? (word_end - sw0) : SWT);
+        int64_t win_lo = sw0 * 64, win_hi = (sw0 + nw) * 64;
+        if (win_lo < p_begin) win_lo = p_begin;
+        if (win_hi > p_end) win_hi = p_end;
+        // ---- stage 1: node ranks at both ends of the window (uniform), 2-bit window -> LDS
+        const uint64_t m0 = g.start_mask[sw0];
+        const int64_t jbase = (int64_t)g.start_rank[sw0] + (int64_t)(m0 & 1ull) - 1;
+        const int64_t jlast = (int64_t)g.start_rank[sw0 + nw] - 1;       // last node starting before the window's end
+        const int64_t sb = 2 * sw0 - 2 > 0 ? 2 * sw0 - 2 : 0;            // first staged 2-bit word
+#pragma unroll
+        for (int t = 0; t < (2 * SWT + 8 + 63) / 64; t++) {
+            const int i = t * 64 + lane;
+            if (i < 2 * SWT + 8) {
+                int64_t gw = sb + i;
+                my_seq[i] = g.seq2[gw < n_seq_words ? gw : n_seq_words - 1];
+            }
+        }
+        for (int64_t jc = jbase; jc <= jlast; jc += NE_CAP) {
+            // ---- stage 2: this chunk of the per-node table -> LDS (12 dwords per node, coalesced)
+            const int n_rec = (int)((jlast - jc + 1) < NE_CAP ? (jlast - jc + 1) : NE_CAP);
+            for (int t = lane; t < 12 * n_rec; t += 64) my_ne[t] = ne32[12 * jc + t];
+            // ---- stage 3: node runs; everything about the run is wave-uniform
+            for (int r = 0; r < n_rec; r++) {
+                const uint32_t *e = my_ne + 12 * r;
+                const int cnt = __builtin_amdgcn_readfirstlane((int)e[8]);
+                if (cnt <= 0) continue;
+                const int64_t glo = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)e[1]) << 32) |
+                                              (uint32_t)__builtin_amdgcn_readfirstlane((int)e[0]));
+                int64_t lo_p = glo > win_lo ? glo : win_lo;
+                int64_t hi_p = glo + cnt < win_hi ? glo + cnt : win_hi;
+                if (lo_p >= hi_p) continue;
+                const int64_t D = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)e[3]) << 32) |
+                                            (uint32_t)__builtin_amdgcn_readfirstlane((int)e[2]));
+                const int64_t E = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)e[5]) << 32) |
+                                            (uint32_t)__builtin_amdgcn_readfirstlane((int)e[4]));
+                const uint32_t node = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[6]);
+                const float af = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)e[7]));
+                const int64_t a_idx = lo_p + D, b_idx = hi_p + D;
+                for (int64_t g0 = a_idx & ~15ll; g0 < b_idx; g0 += 64) {
+                    const int64_t idx = g0 + lane;
+                    if (idx >= a_idx && idx < b_idx) {
+                        const int64_t p = idx - D;
+                        const int64_t P = p - (k - 1);                   // >= 0 for an interior position
+                        const int si = (int)((P >> 5) - sb);
+                        const int sh = (int)(P & 31) * 2;
+                        const uint64_t lo = my_seq[si], hi = my_seq[si + 1];
+                        const uint64_t h = ((lo >> sh) | ((hi << 1) << (63 - sh))) & kmask;
+                        out.hash[idx] = h;
+                        out.node[idx] = node;
+                        out.ref_offset[idx] = (uint64_t)(p + E);
+                        out.af[idx] = af;
+                    }
+                }
+            }
         }
     }
 }
@@ -808,9 +896,25 @@ static int launch_boundary(gki_finder *f, const DevGraph &d, const FindArgs &a, 
 
 static int launch_interior(gki_finder *f, const DevGraph &d, const FindArgs &a, OutFlat out, unsigned blocks) {
     hipStream_t s = f->stream;
-    if (out.hash && out.node && out.ref_offset && out.af)
-        hipLaunchKernelGGL(k_emit_interior_flat, dim3(blocks), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end,
-                           f->p_begin, f->p_end);
+    static const bool word_driven = getenv("GKI_INTERIOR_WORDS") != nullptr;       // A/B knob: the older word-driven kernel
+    if (out.hash && out.node && out.ref_offset && out.af) {
+        if (word_driven)
+            hipLaunchKernelGGL(k_emit_interior_flat, dim3(blocks), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end,
+                               f->p_begin, f->p_end);
+        else {
+            static const int swt = getenv("GKI_SW") ? atoi(getenv("GKI_SW")) : 64;       // A/B knob: bases per wave trip / 64
+            static const int rb = getenv("GKI_RUN_BLOCKS") ? atoi(getenv("GKI_RUN_BLOCKS")) : 256 * 5;
+            const int64_t n_words = f->word_end - f->word_begin;
+            unsigned gb = (unsigned)ceil_div(ceil_div(n_words, swt), 4);
+            if (gb > (unsigned)rb) gb = (unsigned)rb;
+            if (swt == 128)
+                hipLaunchKernelGGL(k_emit_interior_runs<128>, dim3(gb), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end, f->p_begin, f->p_end);
+            else if (swt == 256)
+                hipLaunchKernelGGL(k_emit_interior_runs<256>, dim3(gb), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end, f->p_begin, f->p_end);
+            else     // 29 KB of LDS per block: 5 blocks per CU are resident
+                hipLaunchKernelGGL(k_emit_interior_runs<64>, dim3(gb), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end, f->p_begin, f->p_end);
+        }
+    }
     else
         hipLaunchKernelGGL(k_emit_interior<0>, dim3(blocks), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end,
                            f->p_begin, f->p_end);
@@ -881,6 +985,7 @@ int gki_finder_create(gki_graph *g, gki_finder **out) {
     HIP_TRY(hipMalloc((void **)&f->total, (size_t)n * 4));
     HIP_TRY(hipMalloc((void **)&f->rec_base, (size_t)(n + 1) * 8));
     HIP_TRY(hipMalloc((void **)&f->ne, (size_t)(g->d.n_nonempty + 1) * sizeof(NodeEmit)));
+    HIP_TRY(hipMemset(f->ne, 0, (size_t)(g->d.n_nonempty + 1) * sizeof(NodeEmit)));   // cnt = 0: a record never refreshed emits nothing
     HIP_TRY(hipMalloc((void **)&f->lossy, (size_t)n * 2));
     HIP_TRY(hipMalloc((void **)&f->d_err, 4));
     HIP_TRY(hipMalloc((void **)&f->d_totals, 2 * 8));
