@@ -271,3 +271,56 @@ def test_only_follow_nodes_from_position():
             f.find_only_kmers_starting_at_position(pred, off)
             exp = oracle.find_from_position(g, k, pred, off, False, M, only_store_nodes={node}, only_follow_nodes={node})
             assert_same_records(finder_cols(f), exp, exact_order=True)
+
+
+def test_edge_cases_small_and_degenerate_graphs():
+    cases = [
+        ({0: "ACGT"}, {}, [0], 5),                      # k longer than the graph: nothing
+        ({0: "ACGT"}, {}, [0], 4),                      # exactly one k-mer
+        ({0: "ACGTACGTAC"}, {}, [0], 1),                # k = 1
+        ({0: "AC", 1: "G", 2: "T", 3: "AC"}, {0: [1, 2], 1: [3], 2: [3]}, [0, 1, 3], 2),
+        ({3: "ACGTTGCA", 7: "A", 9: "C", 12: "GGTTAACC"}, {3: [7, 9], 7: [12], 9: [12]}, [3, 7, 12], 6),   # sparse ids
+        ({0: "ACGTACGTACGTACGTACGTACGTACGTACGTACG", 1: "T", 2: "", 3: "ACGTACGTACGTACGTACGTACGTACGTACGTACGT"},
+         {0: [1, 2], 1: [3], 2: [3]}, [0, 1, 3], 31),   # k = 31 across a deletion
+    ]
+    for seqs, edges, lin, k in cases:
+        g = GraphArrays.from_dicts(seqs, edges, lin)
+        for one in (False, True):
+            for M in (0, 1, 4):
+                f = DenseKmerFinder(g, k, only_save_one_node_per_kmer=one, max_variant_nodes=M)
+                f.find()
+                assert_same_records(finder_cols(f), oracle.find(g, k, None, one, M))
+                d = f.find_flat_on_device()
+                f.synchronize()
+                assert d.n == len(f.get_found_kmers_and_nodes()[0])
+
+
+def test_many_empty_nodes_in_a_row():
+    # chains of deletions: windows cross many empty nodes; beyond GKI_MAX_WINDOW_NODES the library refuses loudly
+    def chain(n_empty):
+        seqs, edges, lin = {0: "ACGTACGT"}, {}, [0]
+        prev = 0
+        for i in range(n_empty):
+            a, b = 2 * i + 1, 2 * i + 2          # a: 1-bp ref allele, b: empty alt
+            seqs[a], seqs[b] = "C", ""
+            edges[prev] = [a, b]
+            # join node
+            prev_join = 1000 + i
+            seqs[prev_join] = "G"
+            edges[a] = [prev_join]
+            edges[b] = [prev_join]
+            lin += [a, prev_join]
+            prev = prev_join
+        seqs[5000] = "TTTTTTTTTT"
+        edges[prev] = [5000]
+        lin.append(5000)
+        return GraphArrays.from_dicts(seqs, edges, lin)
+    g = chain(6)
+    f = DenseKmerFinder(g, 8, max_variant_nodes=100)
+    f.find()
+    assert_same_records(finder_cols(f), oracle.find(g, 8, None, False, 100))
+    from graph_kmer_index_amd import _lib
+    g = chain(40)
+    f = DenseKmerFinder(g, 31, max_variant_nodes=100)
+    with pytest.raises(_lib.GkiError):
+        f.find()
