@@ -38,7 +38,7 @@ def pmc_traffic(n_ref_bases, n_sites, k):
         w = d["workload"]
         if (w["n_ref_bases"], w["n_snp_bubbles"], w["k"]) != (n_ref_bases, n_sites, k):
             return None, None
-        return d["k_emit_interior_flat_traffic_bytes_per_launch"], "profiles/r01_pmc_3gbp.json"
+        return d["dominant_kernel_traffic_bytes_per_launch"], "profiles/r01_pmc_3gbp.json"
     except (OSError, KeyError, ValueError):
         return None, None
 
@@ -185,7 +185,7 @@ def main():
                        "n_ref_bases": G, "n_snp_bubbles": int(S), "k": k, "max_variant_nodes": args.max_variant_nodes,
                        "only_save_one_node_per_kmer": True, "records_per_step": n_total, "n_nodes": int(g.n_nodes),
                        "sharding": "critical-path ranges balanced by bases, whole graph resident on every GPU"},
-            "roofline": {"bound": "hbm", "kernel": "k_emit_interior", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_emit_interior_runs", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_record": BYTES_PER_RECORD, "records_per_launch": int(n_interior),
                          "avg_launch_ms": avg_int_ms},
