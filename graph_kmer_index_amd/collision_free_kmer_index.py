@@ -68,6 +68,21 @@ class DeviceIndex:
             b.free()
         return out
 
+    def count_nodes(self, queries, n_nodes, max_hits=10, counts=None):
+        """Fused probe + node histogram (gki_index_count_nodes).  queries: NumPy array or DeviceArray of uint64.
+        Returns a DeviceArray uint32[n_nodes] (accumulates into `counts` when given)."""
+        lib = _lib.load()
+        if counts is None:
+            counts = _lib.DeviceArray(max(int(n_nodes), 1), np.uint32)
+            counts.zero()
+        own = not isinstance(queries, _lib.DeviceArray)
+        dq = _lib.DeviceArray.from_host(np.ascontiguousarray(np.asarray(queries)).astype(np.uint64)) if own else queries
+        view = self.view()
+        _lib.check(lib.gki_index_count_nodes(C.byref(view), dq.ptr, dq.n, int(min(max_hits, 2 ** 62)), counts.ptr, int(n_nodes)))
+        if own:
+            dq.free()
+        return counts
+
     def free(self):
         for a in (self.hashes_to_index, self.n_kmers, self.kmers, self.nodes, self.ref_offsets,
                   self.allele_frequencies, self.frequencies):
@@ -196,9 +211,12 @@ class CollisionFreeKmerIndex:
         return np.diff(hs) > 0
 
     def map_kmers(self, kmers, n_nodes):
-        """kmer_mapper.map_kmers_to_graph_index equivalent (:210-212): node hit counts."""
-        pos = self._device_index().lookup_positions(kmers, max_hits=2 ** 62)[1]
-        return np.bincount(np.asarray(self._nodes)[pos].astype(np.int64), minlength=n_nodes)
+        """kmer_mapper.map_kmers_to_graph_index equivalent (:210-212): node hit counts, probe and histogram fused
+        on the device."""
+        counts = self._device_index().count_nodes(kmers, n_nodes, max_hits=2 ** 62)
+        out = counts.to_host(n_nodes)
+        counts.free()
+        return out
 
     # ------------------------------------------------------------------ probes
     def get(self, kmer, max_hits=10):

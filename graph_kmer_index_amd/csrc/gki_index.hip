@@ -306,6 +306,26 @@ __global__ __launch_bounds__(256) void k_lookup(IndexDev ix, const uint64_t *__r
     }
 }
 
+// kmer_mapper-style node counting fused with the probe (collision_free_kmer_index.py:210-212 map_kmers,
+// CounterKmerIndex.get_node_counts :39-40): counts[node] += 1 for every hit of every query.
+__global__ __launch_bounds__(256) void k_count_nodes(IndexDev ix, const uint64_t *__restrict__ queries, int64_t q, int64_t max_hits,
+                                                     unsigned int *__restrict__ counts, int64_t n_counts) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += stride) {
+        const uint64_t km = queries[i];
+        const uint64_t b = km % ix.modulo;
+        const int64_t s = ix.h2i[b];
+        const int64_t m = ix.nk[b];
+        bool first = true;
+        for (int64_t j = s; j < s + m; j++) {
+            if (ix.kmers[j] != km) continue;
+            if (first) { if (ix.freq && (int64_t)ix.freq[j] > max_hits) break; first = false; }
+            const uint32_t node = ix.nodes[j];
+            if ((int64_t)node < n_counts) atomicAdd(&counts[node], 1u);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -419,6 +439,17 @@ static IndexDev view_of(const gki_index_view *ix) {
     d.refs = (const uint64_t *)ix->d_ref_offsets; d.freq = (const uint16_t *)ix->d_frequencies;
     d.af = (const float *)ix->d_af32; d.modulo = ix->modulo;
     return d;
+}
+
+int gki_index_count_nodes(const gki_index_view *ix, const void *d_queries, int64_t q, int64_t max_hits, void *d_counts,
+                          int64_t n_counts) {
+    if (ix->modulo == 0) return gki_set_error(GKI_ERR_BAD_ARG, "modulo is 0");
+    if (q <= 0) return GKI_OK;
+    hipLaunchKernelGGL(k_count_nodes, dim3(stream_grid(q, 256)), dim3(256), 0, 0, view_of(ix), (const uint64_t *)d_queries, q,
+                       max_hits, (unsigned int *)d_counts, n_counts);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(0));
+    return GKI_OK;
 }
 
 int gki_index_lookup_count(const gki_index_view *ix, const void *d_queries, int64_t q, int64_t max_hits, void *d_hit_start,

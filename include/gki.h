@@ -190,6 +190,11 @@ typedef struct {
 } gki_index_view;
 int gki_index_lookup_count(const gki_index_view *ix, const void *d_queries, int64_t q, int64_t max_hits,
                            void *d_hit_start, int64_t *n_hits);
+/* Node counting fused with the probe: d_counts[node] += 1 (uint32[n_counts], caller-zeroed or accumulated across
+ * batches) for every hit of every query -- what kmer_mapper's map_kmers_to_graph_index gives KAGE
+ * (collision_free_kmer_index.py:210-212) and CounterKmerIndex.get_node_counts (:39-40). */
+int gki_index_count_nodes(const gki_index_view *ix, const void *d_queries, int64_t q, int64_t max_hits,
+                          void *d_counts, int64_t n_counts);
 int gki_index_lookup_emit(const gki_index_view *ix, const void *d_queries, int64_t q, int64_t max_hits,
                           const void *d_hit_start, void *d_hit_nodes, void *d_hit_ref_offsets,
                           void *d_hit_query, void *d_hit_frequencies, void *d_hit_af32, void *d_hit_position);

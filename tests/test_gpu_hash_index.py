@@ -224,3 +224,20 @@ def test_set_frequencies_using_other_index_and_complement():
     comp = mine.convert_kmers_to_complement(k=k)
     assert sorted(np.asarray(comp._kmers).tolist()) == sorted(oracle.complement(mine_kmers, k).tolist())
     assert comp._modulo == mine._modulo
+
+
+def test_map_kmers_fused_node_counts():
+    rng = np.random.default_rng(12)
+    n = 50000
+    pool = rng.integers(0, 4 ** 31, size=4000, dtype=np.uint64)
+    kmers = pool[rng.integers(0, len(pool), size=n)]
+    nodes = rng.integers(0, 3000, size=n).astype(np.uint32)
+    idx = CollisionFreeKmerIndex.from_flat_kmers(FlatKmers(kmers, nodes, np.arange(n, dtype=np.uint64),
+                                                           np.ones(n, np.float32)), modulo=100003)
+    queries = np.concatenate([pool[:1500], pool[:700], rng.integers(0, 4 ** 31, size=900, dtype=np.uint64)])
+    got = idx.map_kmers(queries, 3000)
+    # expectation from the batched probe (itself checked against the oracle above)
+    hit_nodes = idx.get_nodes_from_multiple_kmers(queries, max_hits=2 ** 62)
+    exp = np.bincount(hit_nodes.astype(np.int64), minlength=3000)
+    assert got.dtype == np.uint32 and np.array_equal(got, exp)
+    assert idx.has_kmers(queries).sum() == 2200
