@@ -88,3 +88,39 @@ def overlapping_bubble_graph(rng, n_var=4, min_ref=2, max_ref=8):
         edges[src] = edges[src] + [new]
         edges[new] = [dst]
     return seqs, edges, linear, None
+
+
+def nested_bubble_graph(rng, n_var=4, min_ref=2, max_ref=10, p_nest=0.6):
+    """Bubbles whose alt allele may itself contain a bubble (a variant inside an insertion):
+    R -> {ref allele | Z1 -> {za | zb} -> Z2} -> R'.  Nodes inside the alt allele have no linear-ref predecessor."""
+    seqs, edges, linear = {}, {}, []
+    nid = 0
+
+    def add(seq, is_lin):
+        nonlocal nid
+        seqs[nid] = seq
+        if is_lin:
+            linear.append(nid)
+        nid += 1
+        return nid - 1
+
+    tail = add(_rand_seq(rng, int(rng.integers(min_ref, max_ref + 1))), True)
+    for _ in range(n_var):
+        ref_a = add(_rand_seq(rng, int(rng.integers(1, 4))), True)
+        if rng.random() < p_nest:
+            z1 = add(_rand_seq(rng, int(rng.integers(1, 6))), False)
+            za = add(_rand_seq(rng, int(rng.integers(0, 3))), False)
+            zb = add(_rand_seq(rng, int(rng.integers(1, 3))), False)
+            z2 = add(_rand_seq(rng, int(rng.integers(1, 6))), False)
+            edges[z1] = [za, zb]
+            edges[za] = [z2]
+            edges[zb] = [z2]
+            alt_in, alt_out = z1, z2
+        else:
+            alt_in = alt_out = add(_rand_seq(rng, int(rng.integers(1, 3))), False)
+        edges[tail] = [ref_a, alt_in]
+        head = add(_rand_seq(rng, int(rng.integers(min_ref, max_ref + 1))), True)
+        edges[ref_a] = [head]
+        edges[alt_out] = [head]
+        tail = head
+    return seqs, edges, linear, None

@@ -187,3 +187,24 @@ def test_synthetic_generators_are_prefix_stable_and_wellformed():
     assert lin.n_nodes == 4 and int(lin.seq_start[-1]) == 100000
     from graph_kmer_index_amd.graph import random_codes
     assert np.array_equal(random_codes(1000, 5), random_codes(5000, 5)[:1000])
+
+
+def test_nested_variant_graphs_are_refused():
+    """On graphs with a variant inside an alternative allele the order-free rule "<= max_variant_nodes variant nodes
+    in the window" is NOT the reference's rule (the forced history through the enclosing allele counts too: ~1 % of
+    random nested graphs differ at max_variant_nodes=3), so such graphs are refused rather than answered wrongly."""
+    from graphgen import nested_bubble_graph
+    rng = np.random.default_rng(3)
+    refused = 0
+    for _ in range(30):
+        seqs, edges, lin, _ = nested_bubble_graph(rng, n_var=4, p_nest=0.7)
+        g = GraphArrays.from_dicts(seqs, edges, lin)
+        nested = any(len(g.get_reverse_edges_hashtable()[n]) > 0 and
+                     not any(g.is_ref[p] for p in g.get_reverse_edges_hashtable()[n]) for n in range(g.n_nodes) if g.exists[n])
+        if nested:
+            with pytest.raises(NotImplementedError):
+                check_supported_graph(g, 5)
+            refused += 1
+        else:
+            check_supported_graph(g, 5)
+    assert refused > 10
