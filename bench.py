@@ -167,7 +167,7 @@ def main():
 
     checks = None
     if args.verify:
-        checks = verify(out, g, k)
+        checks = verify(out, g, k, n_interior)
 
     if rank == 0:
         ms_step = 1000.0 * elapsed / args.steps
@@ -202,27 +202,29 @@ def main():
         dist.destroy_process_group()
 
 
-def verify(out, g, k):
-    """Size-independent properties of the full-size output (tests/ compare small sizes with the oracle)."""
+def verify(out, g, k, n_interior):
+    """Size-independent properties of the full-size output (tests/ compare small sizes with the oracle).
+    Layout: n_interior records whose window lies inside one node (by position), then the boundary records (by
+    end node)."""
     import numpy as np
     n = out.n
     step = max(1, n // 2_000_000)
     h = out.hashes.to_host(n)[::step]
-    ro = out.ref_offsets.to_host(n)[::step]
+    ro = out.ref_offsets.to_host(n)[::step].astype(np.int64)         # default position id == global base index
     nodes = out.nodes.to_host(n)[::step]
-    pos_all = ro.astype(np.int64)
-    ok_sorted = bool(np.all(np.diff(np.searchsorted(g.seq_start, pos_all, side="right")) >= 0))   # end-node order
+    n_int_s = (n_interior + step - 1) // step                          # sampled records that are interior ones
+    node_of = np.searchsorted(g.seq_start, ro, side="right") - 1
+    ok_sorted = bool(np.all(np.diff(ro[:n_int_s]) > 0)) and bool(np.all(np.diff(node_of[n_int_s:]) >= 0))
     ok_range = bool(h.max() < 4 ** k)
-    # the hash of a record equals the k bases read backwards from its end position whenever the end node is long
-    # enough to contain the window (interior records)
-    pos = ro.astype(np.int64)                                         # default position id == global base index
-    node_of = np.searchsorted(g.seq_start, pos, side="right") - 1
-    inside = (pos - g.seq_start[node_of]) >= k - 1
-    idx = np.nonzero(inside)[0][:200000]
-    win = pos[idx][:, None] - (k - 1) + np.arange(k)[None, :]
+    off = ro - g.seq_start[node_of]
+    ok_split = bool(np.all(off[:n_int_s] >= k - 1)) and bool(np.all(off[n_int_s:] < k - 1))
+    # the hash of an interior record equals the k bases read backwards from its end position
+    idx = np.arange(0, n_int_s, max(1, n_int_s // 200000))
+    win = ro[idx][:, None] - (k - 1) + np.arange(k)[None, :]
     expect = (g.seq[win].astype(np.uint64) << (2 * np.arange(k, dtype=np.uint64))[None, :]).sum(axis=1)
     ok_hash = bool(np.array_equal(expect, h[idx])) and bool(np.array_equal(nodes[idx], node_of[idx].astype(np.uint32)))
-    return {"sampled": int(len(h)), "end_nodes_sorted": ok_sorted, "hash_lt_4^k": ok_range,
+    return {"sampled": int(len(h)), "interior_by_position_then_boundary_by_node": ok_sorted,
+            "interior_offsets_ge_k-1_boundary_lt_k-1": ok_split, "hash_lt_4^k": ok_range,
             "interior_hash_recomputed": ok_hash}
 
 

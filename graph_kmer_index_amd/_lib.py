@@ -20,7 +20,7 @@ class GkiError(RuntimeError):
 
 class FindParams(C.Structure):
     _fields_ = [("k", C.c_int32), ("max_variant_nodes", C.c_int32), ("one_node_per_kmer", C.c_int32),
-                ("reserved", C.c_int32), ("node_begin", C.c_int64), ("off_begin", C.c_int64),
+                ("layout", C.c_int32), ("node_begin", C.c_int64), ("off_begin", C.c_int64),
                 ("node_end", C.c_int64), ("off_end", C.c_int64), ("h_lossy_crit", C.c_void_p)]
 
 

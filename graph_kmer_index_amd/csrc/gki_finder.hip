@@ -38,6 +38,8 @@ struct FindArgs {
     int32_t k, M, one_node, has_lossy;
     int64_t node_begin, off_begin, node_end, off_end;
     int64_t n0, n1;          // nodes [n0, n1) are the only ones this run touches (per-shard cost, not per-graph)
+    int32_t split, pad;      // output layout: 0 = by end node (boundary block, then interior run, per node);
+                             // 1 = all interior records (by position) first, then all boundary records (by node)
 };
 
 struct OutFlat { uint64_t *hash; uint32_t *node; uint64_t *ref_offset; float *af; };
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
             ic = hi2 > lo ? (uint32_t)(hi2 - lo) : 0u;
         }
         bcount[n] = count;
-        total[n] = count + ic;
+        total[n] = a.split ? ic : count + ic;
     }
 }
 
@@ -269,6 +271,7 @@ template <bool HAS_LOSSY, int FMT>
 __global__ __launch_bounds__(256) void k_emit_boundary(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
                                                        const uint32_t *__restrict__ bcount,
                                                        const int64_t *__restrict__ rec_base,
+                                                       const int64_t *__restrict__ bnd_shift,
                                                        typename OutSel<FMT>::T out, int *__restrict__ err) {
     __shared__ int32_t s_nodes[4][MAXN];
     WalkStack st;
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary(DevGraph g, FindArgs a, c
         if (n < a.n1 && bcount[n] > 0) {
             const int32_t size = g.node_size[n];
             const int32_t bl = bnd_len_of(g, a, lossy, n, size);
-            idx = rec_base[n];
+            idx = rec_base[n] + *bnd_shift;
             pos0 = g.pos_base[n];
             o_lo = (n == a.node_begin) ? (int)(a.off_begin < bl ? a.off_begin : bl) : 0;
             const int o_hi = (n == a.node_end) ? (int)(a.off_end < bl ? a.off_end : bl) : bl;
@@ -469,6 +472,7 @@ template <bool HAS_LOSSY, int FMT>
 __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
                                                            const uint32_t *__restrict__ bcount,
                                                            const int64_t *__restrict__ rec_base,
+                                                           const int64_t *__restrict__ bnd_shift,
                                                            typename OutSel<FMT>::T out, int *__restrict__ err) {
     __shared__ EvQueue<FMT> s_q[4];
     LevelEmit below[MAXN];
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
         if (n < a.n1 && bcount[n] > 0) {
             const NodeWalk wn = g.walk[n];
             const int32_t bl = bnd_len_of(g, a, lossy, n, wn.size);
-            idx = rec_base[n];
+            idx = rec_base[n] + *bnd_shift;
             pos0 = g.pos_base[n];
             o_lo = (n == a.node_begin) ? (int)(a.off_begin < bl ? a.off_begin : bl) : 0;
             const int o_hi = (n == a.node_end) ? (int)(a.off_end < bl ? a.off_end : bl) : bl;
@@ -609,7 +613,7 @@ __global__ __launch_bounds__(256) void k_node_emit(DevGraph g, FindArgs a, const
         const int64_t ss = g.seq_start[n];
         NodeEmit e;
         e.glo = inside ? ss + lo : (int64_t)0x7FFFFFFFFFFFFFFFll;        // outside the run: never interior
-        e.D = inside ? rec_base[n] + (int64_t)bcount[n] - lo - ss : 0;
+        e.D = inside ? rec_base[n] + (a.split ? 0 : (int64_t)bcount[n]) - lo - ss : 0;
         e.E = g.pos_base[n] - ss;
         e.node = (int32_t)n;
         e.af = (float)g.allele_freq[n];
@@ -726,11 +730,11 @@ __global__ __launch_bounds__(256) void k_emit_interior_flat(DevGraph g, FindArgs
 // records instead: the wave walks the node runs of its 4096-base window (from the per-node table in LDS, all
 // values wave-uniform) and covers each run [glo + D, glo + cnt + D) with 64-record groups that start at a
 // multiple of 16 records, i.e. on a cache-line boundary of all four columns.
-template <int SWT>
+template <int SWT, int CAP>
 __global__ __launch_bounds__(256) void k_emit_interior_runs(DevGraph g, FindArgs a, const NodeEmit *__restrict__ ne,
                                                             OutFlat out, int64_t word_begin, int64_t word_end,
                                                             int64_t p_begin, int64_t p_end) {
-    __shared__ uint32_t s_ne[4][NE_CAP * 12];
+    __shared__ uint32_t s_ne[4][CAP * 12];
     __shared__ uint64_t s_seq[4][2 * SWT + 8];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -760,9 +764,9 @@ __global__ __launch_bounds__(256) void k_emit_interior_runs(DevGraph g, FindArgs
                 my_seq[i] = g.seq2[gw < n_seq_words ? gw : n_seq_words - 1];
             }
         }
-        for (int64_t jc = jbase; jc <= jlast; jc += NE_CAP) {
+        for (int64_t jc = jbase; jc <= jlast; jc += CAP) {
             // ---- stage 2: this chunk of the per-node table -> LDS (12 dwords per node, coalesced)
-            const int n_rec = (int)((jlast - jc + 1) < NE_CAP ? (jlast - jc + 1) : NE_CAP);
+            const int n_rec = (int)((jlast - jc + 1) < CAP ? (jlast - jc + 1) : CAP);
             for (int t = lane; t < 12 * n_rec; t += 64) my_ne[t] = ne32[12 * jc + t];
             // ---- stage 3: node runs; everything about the run is wave-uniform
             for (int r = 0; r < n_rec; r++) {
@@ -828,9 +832,14 @@ __global__ __launch_bounds__(256) void k_emit_interior(DevGraph g, FindArgs a, c
     }
 }
 
-__global__ void k_totals(const int64_t *rec_base, int64_t n_nodes, const int *err, int64_t *out2) {
-    out2[0] = rec_base[n_nodes];
-    out2[1] = *err;
+// out4 = {total records, error flag, boundary records (split layout only), 0}; out4[3] doubles as the zero shift
+__global__ void k_totals(const int64_t *rec_base, const int64_t *bnd_base, int64_t n1, int split, const int *err, int64_t *out4) {
+    const int64_t a = rec_base[n1];
+    const int64_t b = split ? bnd_base[n1] : 0;
+    out4[0] = a + b;
+    out4[1] = *err;
+    out4[2] = b;
+    out4[3] = 0;
 }
 
 __global__ __launch_bounds__(256) void k_sum_u32(const uint32_t *__restrict__ x, int64_t n, unsigned long long *__restrict__ out) {
@@ -847,7 +856,7 @@ struct gki_finder {
     gki_graph *g;
     hipStream_t stream, stream2;
     uint32_t *bcount, *total;
-    int64_t *rec_base;
+    int64_t *rec_base, *bnd_base;     // by-node layout: rec_base only; split layout: interior bases / boundary bases
     NodeEmit *ne;
     uint16_t *lossy;
     void *scan_tmp; int64_t scan_tmp_bytes;
@@ -873,12 +882,15 @@ static int launch_boundary_fmt(gki_finder *f, const DevGraph &d, const FindArgs 
     int gb = stream_grid(a.n1 - a.n0, 256);
     if (bnd_blocks > 0 && gb > bnd_blocks) gb = bnd_blocks;
     const dim3 grid(gb), block(256);
+    // split layout: boundary block of node n starts at (number of interior records) + bnd_base[n]
+    const int64_t *base = a.split ? f->bnd_base : f->rec_base;
+    const int64_t *shift = a.split ? f->rec_base + a.n1 : f->d_totals + 3;
     if (a.one_node) {
-        if (a.has_lossy) hipLaunchKernelGGL((k_emit_boundary_one<true, FMT>), grid, block, 0, s2, d, a, f->lossy, f->bcount, f->rec_base, out, f->d_err);
-        else hipLaunchKernelGGL((k_emit_boundary_one<false, FMT>), grid, block, 0, s2, d, a, f->lossy, f->bcount, f->rec_base, out, f->d_err);
+        if (a.has_lossy) hipLaunchKernelGGL((k_emit_boundary_one<true, FMT>), grid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
+        else hipLaunchKernelGGL((k_emit_boundary_one<false, FMT>), grid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
     } else {
-        if (a.has_lossy) hipLaunchKernelGGL((k_emit_boundary<true, FMT>), grid, block, 0, s2, d, a, f->lossy, f->bcount, f->rec_base, out, f->d_err);
-        else hipLaunchKernelGGL((k_emit_boundary<false, FMT>), grid, block, 0, s2, d, a, f->lossy, f->bcount, f->rec_base, out, f->d_err);
+        if (a.has_lossy) hipLaunchKernelGGL((k_emit_boundary<true, FMT>), grid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
+        else hipLaunchKernelGGL((k_emit_boundary<false, FMT>), grid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
     }
     HIP_TRY(hipGetLastError());
     return GKI_OK;
@@ -907,12 +919,15 @@ static int launch_interior(gki_finder *f, const DevGraph &d, const FindArgs &a, 
             const int64_t n_words = f->word_end - f->word_begin;
             unsigned gb = (unsigned)ceil_div(ceil_div(n_words, swt), 4);
             if (gb > (unsigned)rb) gb = (unsigned)rb;
+            static const int cap = getenv("GKI_NE_CAP") ? atoi(getenv("GKI_NE_CAP")) : 128;
             if (swt == 128)
-                hipLaunchKernelGGL(k_emit_interior_runs<128>, dim3(gb), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end, f->p_begin, f->p_end);
-            else if (swt == 256)
-                hipLaunchKernelGGL(k_emit_interior_runs<256>, dim3(gb), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end, f->p_begin, f->p_end);
+                hipLaunchKernelGGL((k_emit_interior_runs<128, 128>), dim3(gb), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end, f->p_begin, f->p_end);
+            else if (cap == 64)      // 16.7 KB of LDS per block: 8 blocks per CU
+                hipLaunchKernelGGL((k_emit_interior_runs<64, 64>), dim3(gb), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end, f->p_begin, f->p_end);
+            else if (cap == 32)
+                hipLaunchKernelGGL((k_emit_interior_runs<64, 32>), dim3(gb), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end, f->p_begin, f->p_end);
             else     // 29 KB of LDS per block: 5 blocks per CU are resident
-                hipLaunchKernelGGL(k_emit_interior_runs<64>, dim3(gb), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end, f->p_begin, f->p_end);
+                hipLaunchKernelGGL((k_emit_interior_runs<64, 128>), dim3(gb), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end, f->p_begin, f->p_end);
         }
     }
     else
@@ -984,11 +999,13 @@ int gki_finder_create(gki_graph *g, gki_finder **out) {
     HIP_TRY(hipMalloc((void **)&f->bcount, (size_t)n * 4));
     HIP_TRY(hipMalloc((void **)&f->total, (size_t)n * 4));
     HIP_TRY(hipMalloc((void **)&f->rec_base, (size_t)(n + 1) * 8));
+    HIP_TRY(hipMalloc((void **)&f->bnd_base, (size_t)(n + 1) * 8));
     HIP_TRY(hipMalloc((void **)&f->ne, (size_t)(g->d.n_nonempty + 1) * sizeof(NodeEmit)));
     HIP_TRY(hipMemset(f->ne, 0, (size_t)(g->d.n_nonempty + 1) * sizeof(NodeEmit)));   // cnt = 0: a record never refreshed emits nothing
     HIP_TRY(hipMalloc((void **)&f->lossy, (size_t)n * 2));
     HIP_TRY(hipMalloc((void **)&f->d_err, 4));
-    HIP_TRY(hipMalloc((void **)&f->d_totals, 2 * 8));
+    HIP_TRY(hipMalloc((void **)&f->d_totals, 4 * 8));
+    HIP_TRY(hipMemset(f->d_totals, 0, 4 * 8));
     HIP_TRY(hipMalloc((void **)&f->d_bsum, 8));
     f->scan_tmp_bytes = gki_scan_tmp_bytes(n);
     HIP_TRY(hipMalloc(&f->scan_tmp, (size_t)f->scan_tmp_bytes));
@@ -1000,7 +1017,7 @@ int gki_finder_destroy(gki_finder *f) {
     if (!f) return GKI_OK;
     (void)hipStreamSynchronize(f->stream);
     (void)hipStreamSynchronize(f->stream2);
-    void *ptrs[] = {f->bcount, f->total, f->rec_base, f->ne, f->lossy, f->scan_tmp, f->d_err, f->d_totals, f->d_bsum};
+    void *ptrs[] = {f->bcount, f->total, f->rec_base, f->bnd_base, f->ne, f->lossy, f->scan_tmp, f->d_err, f->d_totals, f->d_bsum};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 8; i++) (void)hipEventDestroy(f->ev[i]);
     (void)hipEventDestroy(f->ev_ready);
@@ -1027,6 +1044,7 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
     a.node_begin = p->node_begin; a.off_begin = p->off_begin; a.node_end = p->node_end; a.off_end = p->off_end;
     a.n0 = p->node_begin < d.n_nodes ? p->node_begin : d.n_nodes;
     a.n1 = p->node_end < d.n_nodes ? p->node_end + 1 : d.n_nodes;
+    a.split = p->layout == GKI_LAYOUT_SPLIT ? 1 : 0; a.pad = 0;
     f->args = a;
     const int64_t n_run = a.n1 - a.n0;
     if (a.has_lossy) HIP_TRY(hipMemcpyAsync(f->lossy, p->h_lossy_crit, (size_t)d.n_nodes * 2, hipMemcpyHostToDevice, s));
@@ -1047,25 +1065,28 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
     HIP_TRY(hipEventRecord(f->ev[6], s));
     // records of nodes [n0, n1) only: rec_base[n0 + i] = exclusive prefix inside the run, rec_base[n1] = total
     GKI_TRY(gki_scan_u32_to_i64(f->total + a.n0, n_run, f->rec_base + a.n0, f->scan_tmp, f->scan_tmp_bytes, s));
+    if (a.split)
+        GKI_TRY(gki_scan_u32_to_i64(f->bcount + a.n0, n_run, f->bnd_base + a.n0, f->scan_tmp, f->scan_tmp_bytes, s));
     if (n_run > 0) {
         hipLaunchKernelGGL(k_node_emit, dim3(stream_grid(n_run, 256)), dim3(256), 0, s, d, a, f->lossy, f->bcount,
                            f->rec_base, f->ne);
         HIP_TRY(hipGetLastError());
     }
-    if (n_run > 0) {
+    if (n_run > 0 && !a.split) {
         hipLaunchKernelGGL(k_sum_u32, dim3(stream_grid(n_run, 256)), dim3(256), 0, s, f->bcount + a.n0, n_run, f->d_bsum);
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, s, f->rec_base, a.n1, f->d_err, f->d_totals);
+    hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, s, f->rec_base, f->bnd_base, a.n1, a.split, f->d_err, f->d_totals);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(f->ev[7], s));
-    int64_t tot[2];
+    int64_t tot[4];
     unsigned long long bsum = 0;
-    HIP_TRY(hipMemcpyAsync(tot, f->d_totals, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(tot, f->d_totals, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&bsum, f->d_bsum, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (tot[1] != 0)
         return gki_set_error((int)tot[1], "a k-window crosses more than %d nodes (too many empty nodes in a row)", MAXN - 2);
+    if (a.split) bsum = (unsigned long long)tot[2];
     f->n_records = tot[0];
     f->n_boundary_records = (int64_t)bsum;
     f->n_interior_records = tot[0] - (int64_t)bsum;

@@ -175,10 +175,11 @@ class DenseKmerFinder:
             return None
         return p
 
-    def _count(self):
+    def _count(self, layout=0):
         p = self._params()
         if p is None:
             return 0
+        p.layout = layout
         n = C.c_int64(0)
         _lib.check(_lib.load().gki_finder_count(self._finder_handle(), C.byref(p), C.byref(n)))
         return n.value
@@ -214,12 +215,14 @@ class DenseKmerFinder:
             kmers, start_nodes, start_offsets, nodes, af = (c[keep] for c in (kmers, start_nodes, start_offsets, nodes, af))
         self._cols = dict(kmers=kmers, start_nodes=start_nodes, start_offsets=start_offsets, nodes=nodes, af=af)
 
-    def find_flat_on_device(self, out=None):
+    def find_flat_on_device(self, out=None, split_layout=True):
         """find() + get_flat_kmers(v="1") + FlatKmers.from_multiple_flat_kmers dtypes, columns left in
-        HBM (the CLI `index` path, command_line_interface.py:559-614).  Returns DeviceFlatKmers."""
+        HBM (the CLI `index` path, command_line_interface.py:559-614).  Returns DeviceFlatKmers.
+        split_layout: records whose window lies inside one node first, then the others (GKI_LAYOUT_SPLIT) -- the
+        same multiset, written as two dense streams; False gives find()'s by-node order."""
         if self._whitelist is not None or self._only_store_nodes is not None:
             raise NotImplementedError("whitelist / only_store_nodes filters are applied by find() on the host")
-        n = self._count()
+        n = self._count(layout=1 if split_layout else 0)
         if out is None or out.hashes.n < n:
             out = DeviceFlatKmers.allocate(n)
         out.n = n

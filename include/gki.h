@@ -114,11 +114,17 @@ int gki_critical_paths(int64_t n_nodes, const int32_t *h_node_size,
  * Output = the reference's record multiset, ordered by end node; inside a node first the windows
  * that reach into predecessors (walk order over the predecessor lists, offset ascending inside one
  * step, nodes of a window ascending), then the offsets whose window lies inside the node. */
+/* Record order.  BY_NODE: by end node; inside a node first the windows that reach into predecessors, then the
+ * offsets whose window lies inside the node (on a linear graph this is the reference's order).  SPLIT: all
+ * inside-the-node records first (by position), then all others (by end node) -- the same multiset in two dense
+ * streams, which is what the writes like best; meant for consumers that sort anyway (the index build). */
+#define GKI_LAYOUT_BY_NODE 0
+#define GKI_LAYOUT_SPLIT 1
 typedef struct {
     int32_t k;                    /* 1..31 */
     int32_t max_variant_nodes;    /* kmer_finder.py:42 */
     int32_t one_node_per_kmer;    /* only_save_one_node_per_kmer :145-146 */
-    int32_t reserved;
+    int32_t layout;               /* GKI_LAYOUT_BY_NODE or GKI_LAYOUT_SPLIT: order of the records in the output */
     /* end positions processed: (node_begin, off_begin) inclusive .. (node_end, off_end) exclusive,
      * in (node id, offset) order -- the chunking of command_line_interface.py:588-601.  Whole
      * graph: node_begin = 0, off_begin = 0, node_end = n_nodes, off_end = 0. */

@@ -139,19 +139,28 @@ def test_flat_layout_on_device_matches_v2_columns():
     f = DenseKmerFinder(g, 31, only_save_one_node_per_kmer=True, max_variant_nodes=5)
     f.find()
     v2 = finder_cols(f)
-    d = f.find_flat_on_device()
-    f.synchronize()
-    flat = d.to_flat_kmers()
-    assert flat._hashes.dtype == np.uint64 and flat._nodes.dtype == np.uint32
-    assert flat._ref_offsets.dtype == np.uint64 and flat._allele_frequencies.dtype == np.float32
-    assert np.array_equal(flat._hashes, v2["kmers"].astype(np.uint64))
-    assert np.array_equal(flat._nodes, v2["nodes"].astype(np.uint32))
     pos = g.position_id_base()[v2["start_nodes"]] + v2["start_offsets"]
-    assert np.array_equal(flat._ref_offsets, pos.astype(np.uint64))
-    assert np.array_equal(flat._allele_frequencies, v2["allele_frequencies"].astype(np.float32))
-    # get_flat_kmers(v="1") agrees with the device layout
     fl1 = f.get_flat_kmers(v="1")
-    assert np.array_equal(np.asarray(fl1._ref_offsets).astype(np.uint64), flat._ref_offsets)
+    assert np.array_equal(np.asarray(fl1._ref_offsets), pos)
+    want = (v2["kmers"].astype(np.uint64), v2["nodes"].astype(np.uint32), pos.astype(np.uint64),
+            v2["allele_frequencies"].astype(np.float32))
+    for split in (False, True):
+        d = f.find_flat_on_device(split_layout=split)
+        f.synchronize()
+        flat = d.to_flat_kmers()
+        assert flat._hashes.dtype == np.uint64 and flat._nodes.dtype == np.uint32
+        assert flat._ref_offsets.dtype == np.uint64 and flat._allele_frequencies.dtype == np.float32
+        got = (flat._hashes, flat._nodes, flat._ref_offsets, flat._allele_frequencies)
+        if split:      # same records; interior ones (by position) first, then the boundary ones
+            og = np.lexsort((got[3], got[1], got[0], got[2]))
+            ow = np.lexsort((want[3], want[1], want[0], want[2]))
+            for a_, b_ in zip(got, want):
+                assert np.array_equal(a_[og], b_[ow])
+            n_int = f.interior_records()
+            assert np.all(np.diff(flat._ref_offsets[:n_int].astype(np.int64)) > 0)
+        else:          # by-node layout: identical order to find()
+            for a_, b_ in zip(got, want):
+                assert np.array_equal(a_, b_)
 
 
 def test_chunked_find_partitions_the_records():
