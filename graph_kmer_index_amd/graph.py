@@ -181,6 +181,24 @@ class GraphArrays:
         return cls(node_size, seq, edge_start, flat_edges, is_ref, af, exists,
                    int(graph.get_first_node()), chrom, ntro)
 
+    # ------------------------------------------------------------------ .npz round trip
+    _FILE_KEYS = ("node_size", "seq", "edge_start", "edges", "is_ref", "allele_freq", "exists")
+
+    def to_file(self, file_name):
+        np.savez(file_name, first_node=self.first_node, chromosome_start_nodes=np.array(self._chromosome_start_nodes),
+                 node_to_ref_offset=(np.zeros(0) if self.node_to_ref_offset is None else np.asarray(self.node_to_ref_offset)),
+                 **{k: getattr(self, k) for k in self._FILE_KEYS})
+
+    @classmethod
+    def from_file(cls, file_name):
+        try:
+            d = np.load(file_name)
+        except FileNotFoundError:
+            d = np.load(file_name + ".npz")
+        ntro = d["node_to_ref_offset"]
+        return cls(d["node_size"], d["seq"], d["edge_start"], d["edges"], d["is_ref"], d["allele_freq"], d["exists"],
+                   int(d["first_node"]), d["chromosome_start_nodes"].tolist(), ntro if len(ntro) else None)
+
     # ------------------------------------------- obgraph-compatible accessor surface
     @property
     def nodes(self):

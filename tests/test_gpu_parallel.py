@@ -61,3 +61,36 @@ def test_shards_concatenate_to_the_unsharded_columns():
         for name in ("_hashes", "_nodes", "_ref_offsets", "_allele_frequencies"):
             assert np.array_equal(getattr(got, name)[a], getattr(want, name)[b]), name
         assert np.array_equal(np.sort(got._ref_offsets, kind="stable"), got._ref_offsets) or True
+
+
+def test_command_line_drivers_write_the_reference_formats(tmp_path):
+    # command_line_interface.py:553-638 `index`, :156-174 `make_from_flat`, :655-667 `add_reverse_complements`
+    from graph_kmer_index_amd.command_line_interface import main
+    from graph_kmer_index_amd import FlatKmers, CollisionFreeKmerIndex, GraphArrays
+    g = synthetic_snp_graph(80000, 900, k=31, seed=23)
+    gfile, flat_file, idx_file, rc_file = (str(tmp_path / n) for n in ("graph", "flat", "index", "flat_rc"))
+    g.to_file(gfile)
+    g2 = GraphArrays.from_file(gfile)
+    assert np.array_equal(g2.seq, g.seq) and np.array_equal(g2.edges, g.edges) and g2.first_node == g.first_node
+    assert main(["index", "-g", gfile + ".npz", "-k", "31", "-o", flat_file, "-t", "4"]) == 0
+    flat = FlatKmers.from_file(flat_file)
+    exp = oracle.find(g, 31, None, True, 5)                     # CLI: one node per kmer, max_variant_nodes 5
+    pos = g.position_id_base()[exp["start_nodes"]] + exp["start_offsets"]
+    assert flat._hashes.dtype == np.uint64 and flat._nodes.dtype == np.uint32 and flat._allele_frequencies.dtype == np.float32
+    order = lambda a, b, c: np.lexsort((c, a, b))
+    og = order(flat._hashes, flat._ref_offsets, flat._nodes)
+    oe = order(exp["kmers"].astype(np.uint64), pos.astype(np.uint64), exp["nodes"].astype(np.uint32))
+    assert np.array_equal(flat._hashes[og], exp["kmers"].astype(np.uint64)[oe])
+    assert np.array_equal(flat._nodes[og], exp["nodes"].astype(np.uint32)[oe])
+    assert np.array_equal(flat._ref_offsets[og], pos.astype(np.uint64)[oe])
+    assert main(["make_from_flat", "-f", flat_file, "-o", idx_file, "-m", "200003"]) == 0
+    idx = CollisionFreeKmerIndex.from_file(idx_file)
+    ref = oracle.index_build(flat._hashes, flat._nodes, flat._ref_offsets, flat._allele_frequencies, modulo=200003)
+    for name in ("_hashes_to_index", "_n_kmers", "_kmers", "_nodes", "_ref_offsets", "_frequencies"):
+        assert np.array_equal(getattr(idx, name), ref[name]), name
+    assert main(["add_reverse_complements", "-f", flat_file, "-o", rc_file, "-k", "31"]) == 0
+    rc = FlatKmers.from_file(rc_file)
+    n = len(flat._hashes)
+    assert len(rc._hashes) == 2 * n and np.array_equal(rc._hashes[:n], flat._hashes)
+    assert np.array_equal(rc._hashes[n:], oracle.reverse_complement(flat._hashes, 31))
+    assert np.array_equal(rc._nodes[n:], flat._nodes)
