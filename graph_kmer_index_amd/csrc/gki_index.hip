@@ -6,7 +6,7 @@
 //   radix passes       stable LSD radix sort of (bucket, index) pairs, 8 bits per pass, only the
 //                      bits modulo-1 occupies; per pass: tile histograms -> scan -> ranked scatter with an
 //                      in-LDS reorder so every digit's run leaves the CU as one contiguous store
-//   k_gather_payload   the four payload columns permuted once by the sorted index
+//   k_pack_rows / k_gather_rows   the payload packed into 32-byte rows, permuted once by the sorted index
 //   k_directory / k_frequencies_*   bucket heads, lengths, distinct-ref_offset counts
 // Inside a bucket records keep their input order (stable sort), which is also what the oracle's
 // stable restatement produces, so the build is comparable element by element.
@@ -133,18 +133,34 @@ __global__ __launch_bounds__(RB) void k_radix_scatter(const uint32_t *__restrict
     }
 }
 
-__global__ __launch_bounds__(256) void k_gather_payload(const uint32_t *__restrict__ idx, int64_t n,
-                                                        const uint64_t *__restrict__ kmers, const uint32_t *__restrict__ nodes,
-                                                        const uint64_t *__restrict__ refs, const float *__restrict__ af,
-                                                        uint64_t *__restrict__ o_kmers, uint32_t *__restrict__ o_nodes,
-                                                        uint64_t *__restrict__ o_refs, float *__restrict__ o_af) {
+// Payload permutation.  Gathering four columns by a random index costs four random 64-byte sectors per record
+// (measured: 30 ms of a 50 ms build at 3.2e8 records).  The columns are first packed into 32-byte rows (one
+// streaming pass), so the random access is one sector per record; the permuted rows are unpacked into the output
+// columns with coalesced stores.
+struct Row { uint64_t kmer, ref; uint32_t node; float af; uint64_t pad; };     // 32 B
+
+__global__ __launch_bounds__(256) void k_pack_rows(const uint64_t *__restrict__ kmers, const uint32_t *__restrict__ nodes,
+                                                   const uint64_t *__restrict__ refs, const float *__restrict__ af, int64_t n,
+                                                   uint4 *__restrict__ rows) {
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t j = idx[i];
-        o_kmers[i] = kmers[j];
-        o_nodes[i] = nodes[j];
-        o_refs[i] = refs[j];
-        o_af[i] = af[j];
+        const uint64_t k = kmers[i], r = refs[i];
+        rows[2 * i] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), (uint32_t)r, (uint32_t)(r >> 32));
+        rows[2 * i + 1] = make_uint4(nodes[i], __float_as_uint(af[i]), 0u, 0u);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gather_rows(const uint32_t *__restrict__ idx, int64_t n, const uint4 *__restrict__ rows,
+                                                     uint64_t *__restrict__ o_kmers, uint32_t *__restrict__ o_nodes,
+                                                     uint64_t *__restrict__ o_refs, float *__restrict__ o_af) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t j = idx[i];
+        const uint4 a = rows[2 * j], b = rows[2 * j + 1];
+        o_kmers[i] = ((uint64_t)a.y << 32) | a.x;
+        o_refs[i] = ((uint64_t)a.w << 32) | a.z;
+        o_nodes[i] = b.x;
+        o_af[i] = __uint_as_float(b.y);
     }
 }
 
@@ -345,6 +361,7 @@ int gki_index_build(const void *d_kmers, const void *d_nodes, const void *d_ref_
     HIP_TRY(hipMemsetAsync(d_out_frequencies, 0, (size_t)n * 2, s));               // :270
     const int64_t n_tiles = ceil_div(n, RTILE);
     uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *hist = nullptr, *offs = nullptr;
+    uint4 *rows = nullptr;
     void *tmp = nullptr;
     const int64_t hist_n = (int64_t)RBINS * n_tiles;
     const int64_t tmp_bytes = gki_scan_tmp_bytes(hist_n);
@@ -375,8 +392,11 @@ int gki_index_build(const void *d_kmers, const void *d_nodes, const void *d_ref_
             HIP_G(hipGetLastError());
             cur = 1 - cur;
         }
-        hipLaunchKernelGGL(k_gather_payload, dim3(stream_grid(n, 256)), dim3(256), 0, s, vals[cur], n, (const uint64_t *)d_kmers,
-                           (const uint32_t *)d_nodes, (const uint64_t *)d_ref_offsets, (const float *)d_af32,
+        HIP_G(hipMalloc((void **)&rows, (size_t)n * 32));
+        hipLaunchKernelGGL(k_pack_rows, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const uint64_t *)d_kmers,
+                           (const uint32_t *)d_nodes, (const uint64_t *)d_ref_offsets, (const float *)d_af32, n, rows);
+        HIP_G(hipGetLastError());
+        hipLaunchKernelGGL(k_gather_rows, dim3(stream_grid(n, 256)), dim3(256), 0, s, vals[cur], n, (const uint4 *)rows,
                            (uint64_t *)d_out_kmers, (uint32_t *)d_out_nodes, (uint64_t *)d_out_ref_offsets, (float *)d_out_af32);
         HIP_G(hipGetLastError());
         if (d_out_permutation) HIP_G(hipMemcpyAsync(d_out_permutation, vals[cur], (size_t)n * 4, hipMemcpyDeviceToDevice, s));
@@ -426,7 +446,7 @@ int gki_index_build(const void *d_kmers, const void *d_nodes, const void *d_ref_
     }
 done:
     for (int i = 0; i < 2; i++) { (void)hipFree(keys[i]); (void)hipFree(vals[i]); }
-    (void)hipFree(hist); (void)hipFree(offs); (void)hipFree(tmp);
+    (void)hipFree(hist); (void)hipFree(offs); (void)hipFree(tmp); (void)hipFree(rows);
 #undef HIP_G
 #undef CLEANUP_RETURN
     return rc;
