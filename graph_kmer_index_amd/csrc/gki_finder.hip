@@ -426,38 +426,59 @@ struct EvQueue {
     int64_t idx[EVQ], pos0[EVQ];
     double maf[EVQ];
     int32_t mn[EVQ], n[EVQ];
-    uint32_t pre[EVQ + 1];
+    uint32_t key[EVQ];           // (idx - min idx) << 8 | slot, sorted: the steps in output order
     uint8_t from[EVQ], cnt[EVQ];
 };
 
 __device__ int g_dbg_skip_expand = 0;     // diagnostics only (GKI_DBG_SKIP_EXPAND): phase A alone
 
+// Expansion writes the queued steps in OUTPUT order.  Steps arrive in walk order, i.e. interleaved across the 64
+// nodes of the wave; written that way every cache line of the wave's output block is touched several microseconds
+// apart, and at ~5 TB/s of writes a 4-MB L2 turns over in ~6 us, so lines left half-written were flushed twice
+// (PMC: 11.4 GB written for 7.4 GB of records).  Sorting the <= 128 steps by their first record slot (bitonic sort
+// of packed keys in LDS) makes consecutive lanes write consecutive records.
 template <int FMT>
 __device__ __forceinline__ void expand_queue(EvQueue<FMT> &q, int n_ev, typename OutSel<FMT>::T out, int k, uint64_t kmask,
                                              int lane) {
-    if (g_dbg_skip_expand) return;
-    // exclusive prefix of the step sizes
-    uint32_t run = 0;
+    if (g_dbg_skip_expand == 1) return;
+    static_assert(EVQ == 128, "two steps per lane");
+    // smallest first-record slot of the queue
+    int64_t mn_idx = INT64_MAX;
 #pragma unroll
-    for (int b = 0; b < EVQ / 64; b++) {
+    for (int b = 0; b < 2; b++) { const int e = b * 64 + lane; if (e < n_ev && q.idx[e] < mn_idx) mn_idx = q.idx[e]; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { const int64_t o = __shfl_xor(mn_idx, d, 64); mn_idx = o < mn_idx ? o : mn_idx; }
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
         const int e = b * 64 + lane;
-        const uint32_t c = e < n_ev ? q.cnt[e] : 0u;
-        uint32_t inc = c;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
-        q.pre[e] = run + inc - c;
-        run += __shfl(inc, 63, 64);
+        q.key[e] = e < n_ev ? (((uint32_t)(q.idx[e] - mn_idx) << 8) | (uint32_t)e) : 0xFFFFFFFFu;
     }
-    const uint32_t total = run;
-    if (lane == 0) q.pre[n_ev] = total;
-    for (uint32_t t = lane; t < total; t += 64) {
-        int lo = 0, hi = n_ev;                   // largest e with pre[e] <= t
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (q.pre[mid] <= t) lo = mid; else hi = mid; }
-        const int e = lo;
-        const uint32_t r = t - q.pre[e];
-        const int o = q.from[e] + (int)r;
-        const uint64_t h = ((q.ctx[e] >> (2 * o)) | (q.own[e] << (2 * (k - 1 - o)))) & kmask;
-        put(out, q.idx[e] + r, h, q.mn[e], q.n[e], o, q.pos0[e] + o, q.maf[e]);
+    // bitonic sort of 128 keys, one compare-exchange per lane and step (a wave executes in lockstep; LDS ops of one
+    // wave are ordered)
+    for (int size = 2; size <= (g_dbg_skip_expand == 2 ? 0 : EVQ); size <<= 1) {
+        for (int str = size >> 1; str > 0; str >>= 1) {
+            const int lo = ((lane / str) * (str << 1)) + (lane % str);
+            const int hi = lo + str;
+            const bool up = (lo & size) == 0;
+            const uint32_t a = q.key[lo], c = q.key[hi];
+            if ((c < a) == up) { q.key[lo] = c; q.key[hi] = a; }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // Two steps per trip, one per half-wave (a step has at most k-1 <= 30 records): lane l of a half writes record l
+    // of its step.  A lane-per-record mapping (prefix sum + binary search) was tried first; it issues 5x more
+    // instructions per record and the kernel is issue-bound, not bandwidth-bound (PMC: 9.3 GB written in 4.5 ms).
+    const int half = lane >> 5, l = lane & 31;
+    for (int i = 0; i < n_ev; i += 2) {
+        const int pos = i + half;
+        if (pos < n_ev) {
+            const int e = (int)(q.key[pos] & 0xFFu);
+            if (l < (int)q.cnt[e]) {
+                const int o = q.from[e] + l;
+                const uint64_t h = ((q.ctx[e] >> (2 * o)) | (q.own[e] << (2 * (k - 1 - o)))) & kmask;
+                put(out, q.idx[e] + l, h, q.mn[e], q.n[e], o, q.pos0[e] + o, q.maf[e]);
+            }
+        }
     }
 }
 
@@ -874,7 +895,7 @@ template <int FMT>
 static int launch_boundary_fmt(gki_finder *f, const DevGraph &d, const FindArgs &a, typename OutSel<FMT>::T out, hipStream_t s2) {
     static bool dbg_set = false;
     if (!dbg_set) {
-        int v = getenv("GKI_DBG_SKIP_EXPAND") ? 1 : 0;
+        int v = getenv("GKI_DBG_SKIP_EXPAND") ? atoi(getenv("GKI_DBG_SKIP_EXPAND")) : 0;   // 1: no expansion, 2: no sort
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_skip_expand), &v, sizeof(int)));
         dbg_set = true;
     }
