@@ -96,86 +96,11 @@ __device__ __forceinline__ int32_t bnd_len_of(const DevGraph &g, const FindArgs 
 }
 
 // ------------------------------------------------------------------------------------ boundary walk
-// One lane per node: depth-first over predecessor lists with an explicit stack.  The Emitter hooks:
-//   own_window(o)                 the window of offset o lies inside the node itself (o >= k-1; E1 nodes only)
-//   begin(hi)                     offsets [.., hi) need context bases
-//   step(L, q, s, c, from, to)    stepping onto q = nd[L-1] (size s) with c context bases collected before it
-//                                 completes the windows of offsets [from, to); nd[0..L) are their nodes
-//   push_empty / push_full        the walk descends below an empty node / below q taking all its bases
-struct WalkStack {
-    int32_t nd[MAXN], cur[MAXN], end[MAXN];
+// One lane per node: depth-first over predecessor lists with an explicit stack.  Stepping onto predecessor q
+// (size s) with c context bases collected before it completes the windows of offsets o with c < k-1-o <= c+s.
+struct WalkStack {               // whole stack in (scratch) arrays: used by the all-nodes emit kernel, which needs
+    int32_t nd[MAXN], cur[MAXN], end[MAXN];   // the node list of every window
     uint8_t cum[MAXN], vc[MAXN];
-};
-
-template <bool HAS_LOSSY, typename Emitter>
-__device__ __forceinline__ void walk_node(const DevGraph &g, const FindArgs &a, const uint16_t *__restrict__ lossy,
-                                          int32_t n, int32_t bl, WalkStack &st, int *err, Emitter &em) {
-    const int k = a.k;
-    const int o_lo = (n == a.node_begin) ? (int)(a.off_begin < bl ? a.off_begin : bl) : 0;
-    const int o_hi = (n == a.node_end) ? (int)(a.off_end < bl ? a.off_end : bl) : bl;
-    if (o_lo >= o_hi) return;
-    const int v0 = g.is_ref[n] ? 0 : 1;
-    if (v0 > a.M) return;
-    const int cn = HAS_LOSSY ? lossy_of(lossy, n) : -1;
-    // windows inside the node (only nodes whose boundary reaches past k-1: lossy restarts)
-    for (int o = o_lo > k - 1 ? o_lo : k - 1; o < o_hi; o++) {
-        if (HAS_LOSSY && cn >= 0 && o + 1 - k <= cn - 1 && cn <= o) continue;
-        em.own_window(o);
-    }
-    int hi = o_hi < k - 1 ? o_hi : k - 1;
-    if (HAS_LOSSY && cn >= 1 && cn < hi) hi = cn;          // offsets >= c would span (c-1, c)
-    if (o_lo >= hi) return;
-    st.nd[0] = n; st.cur[0] = (int32_t)g.rev_start[n]; st.end[0] = (int32_t)g.rev_start[n + 1];
-    st.cum[0] = 0; st.vc[0] = (uint8_t)v0;
-    em.begin(hi);
-    int L = 1;
-    while (L > 0) {
-        const int j = L - 1;
-        const int32_t e = st.cur[j];
-        if (e >= st.end[j]) { L--; continue; }
-        st.cur[j] = e + 1;
-        const int32_t q = g.rev_edges[e];
-        const int vq = st.vc[j] + (g.is_ref[q] ? 0 : 1);
-        if (vq > a.M) continue;                          // kmer_finder.py:391-403 in order-free form
-        if (L >= MAXN - 1) { *err = GKI_ERR_WINDOW_TOO_DEEP; continue; }
-        const int s = g.node_size[q];
-        const int c = st.cum[j];
-        st.nd[L] = q; st.vc[L] = (uint8_t)vq;
-        if (s == 0) {                                    // empty node: in the node set, adds no base (:261-265)
-            st.cum[L] = (uint8_t)c; st.cur[L] = (int32_t)g.rev_start[q]; st.end[L] = (int32_t)g.rev_start[q + 1];
-            em.push_empty(L);
-            L++;
-            continue;
-        }
-        // offsets completing inside q: c < k-1-o <= c+s
-        int from = k - 1 - c - s; if (from < o_lo) from = o_lo;
-        int to = k - 1 - c; if (to > hi) to = hi;
-        const int cq = HAS_LOSSY ? lossy_of(lossy, q) : -1;
-        if (HAS_LOSSY && cq >= 0) {
-            // a window taking t = k-1-o-c bases of q covers its offsets s-t .. s-1: forbidden when s-t <= cq-1,
-            // i.e. o <= k-1-c-s+cq-1
-            const int min_ok = k - 1 - c - s + cq;
-            if (from < min_ok) from = min_ok;
-        }
-        if (from < to) em.step(L + 1, q, s, c, from, to);
-        const bool deeper = (k - 1 - c - s > o_lo) && !(HAS_LOSSY && cq >= 1);
-        if (deeper) {
-            st.cum[L] = (uint8_t)(c + s); st.cur[L] = (int32_t)g.rev_start[q]; st.end[L] = (int32_t)g.rev_start[q + 1];
-            em.push_full(L, q, s, c);
-            L++;
-        }
-    }
-}
-
-struct CountEmitter {
-    uint32_t count; bool one;
-    __device__ __forceinline__ void own_window(int) { count += 1; }
-    __device__ __forceinline__ void begin(int) {}
-    __device__ __forceinline__ void push_empty(int) {}
-    __device__ __forceinline__ void push_full(int, int32_t, int, int) {}
-    __device__ __forceinline__ void step(int L, int32_t, int, int, int from, int to) {
-        count += (uint32_t)(to - from) * (one ? 1u : (uint32_t)L);
-    }
 };
 
 // The walk used by the count pass and by the one-node emit pass keeps the TOP of the stack in registers and only
@@ -647,110 +572,23 @@ __global__ __launch_bounds__(256) void k_node_emit(DevGraph g, FindArgs a, const
 }
 
 // ------------------------------------------------------------------------------------ interior stream
-// Lane l of a wave owns base p = 64*w + l of a 64-base word w: rank of its node = rank[w] +
-// popcount(mask[w] bits <= l) - 1, per-node constants from one 32-B record, hash = 2k-bit field of the
-// 2-bit stream, four coalesced column stores.
-//
-// FlatKmers variant: LDS-staged.  Measured on MI355X: while the chip is saturated with the 24 B/record
-// output stream a dependent global load takes several microseconds, and on gfx950 vmcnt retires loads
-// and stores in order, so a load issued after a store waits for that store.  A version that did
-// mask/rank -> per-node-record gather -> store for every 64-base word ran at 2.6 TB/s; dropping only the
-// gather gave 4.5 TB/s.  So a wave now takes SW = 64 consecutive words (4096 bases) at a time:
-//   1. one coalesced load of the 64 bitmap words and ranks (lane u <-> word u), three coalesced loads of
-//      the 2-bit sequence window into LDS;
-//   2. per chunk of words whose nodes fit NE_CAP records: coalesced copy of that slice of the per-node
-//      table into LDS;
-//   3. a loop over the words that touches only registers (v_readlane of mask/rank) and LDS, and issues
-//      the four coalesced column stores back to back with no global load in between.
-constexpr int SW = 64;
-constexpr int NE_CAP = 128;
-constexpr int SEQ_W = 2 * SW + 8;
+// Offsets >= bnd_len of a node have exactly one window, inside the node: record index of interior position p of
+// node n is p + D[n], its hash a 2k-bit field of the 2-bit stream.  The owner of base p is
+// rank[p/64] + popcount(mask[p/64] & bits <= p%64) - 1 in the list of non-empty nodes.
+constexpr int SW = 64;                  // 64-base words per wave trip of the interior kernels (4096 bases)
 constexpr int INTERIOR_MAX_BLOCKS = 256 * 7;
 
-__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
-    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
-    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-__global__ __launch_bounds__(256) void k_emit_interior_flat(DevGraph g, FindArgs a, const NodeEmit *__restrict__ ne,
-                                                            OutFlat out, int64_t word_begin, int64_t word_end,
-                                                            int64_t p_begin, int64_t p_end) {
-    __shared__ uint4 s_ne[4][NE_CAP * 3];
-    __shared__ uint64_t s_seq[4][SEQ_W];
-    const int lane = threadIdx.x & 63;
-    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t wave = (int64_t)blockIdx.x * 4 + wib;
-    const int64_t n_waves = (int64_t)gridDim.x * 4;
-    const int k = a.k;
-    const uint64_t kmask = (1ull << (2 * k)) - 1ull;
-    const uint64_t lane_mask = ~0ull >> (63 - lane);       // bits 0..lane
-    const int64_t n_seq_words = ((g.n_bases + 31) >> 5) + 2;
-    const uint4 *ne4 = reinterpret_cast<const uint4 *>(ne);
-    uint4 *my_ne = s_ne[wib];
-    uint64_t *my_seq = s_seq[wib];
-    for (int64_t sw0 = word_begin + wave * SW; sw0 < word_end; sw0 += n_waves * SW) {
-        const int nw = (int)((word_end - sw0) < SW ? (word_end - sw0) : SW);
-        // ---- stage 1: bitmap words, ranks, 2-bit window
-        const int64_t wl = sw0 + (lane < nw ? lane : nw - 1);
-        const uint64_t mask_v = g.start_mask[wl];
-        const uint32_t rank_v = g.start_rank[wl];
-        const int64_t sb = 2 * sw0 - 2 > 0 ? 2 * sw0 - 2 : 0;          // first staged 2-bit word
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const int i = t * 64 + lane;
-            if (i < SEQ_W) {
-                int64_t gw = sb + i;
-                my_seq[i] = g.seq2[gw < n_seq_words ? gw : n_seq_words - 1];
-            }
-        }
-        const uint32_t last_j_v = rank_v + (uint32_t)__popcll(mask_v) - 1u;      // last node (rank) touching word `lane`
-        int u0 = 0;
-        while (u0 < nw) {
-            // ---- stage 2: per-node records of words [u0, u1)
-            const uint64_t m0 = readlane64(mask_v, u0);
-            const uint32_t jbase = (uint32_t)__builtin_amdgcn_readlane((int)rank_v, u0) + (uint32_t)(m0 & 1ull) - 1u;
-            const uint64_t fits = __ballot(lane >= u0 && lane < nw && (last_j_v - jbase) < (uint32_t)NE_CAP) >> u0;
-            // run of fitting words starting at u0; ctz(0) is undefined, and the loop must always advance
-            int u1 = (~fits == 0ull) ? nw : u0 + (int)__builtin_ctzll(~fits);
-            if (u1 > nw) u1 = nw;
-            if (u1 <= u0) u1 = u0 + 1;
-            const uint32_t n_rec = (uint32_t)__builtin_amdgcn_readlane((int)last_j_v, u1 - 1) - jbase + 1u;
-            for (uint32_t t = lane; t < 3u * n_rec; t += 64) my_ne[t] = ne4[3 * (int64_t)jbase + t];
-            // ---- stage 3: words of the chunk, registers + LDS only
-            for (int u = u0; u < u1; u++) {
-                const uint64_t mask = readlane64(mask_v, u);
-                const uint32_t rank = (uint32_t)__builtin_amdgcn_readlane((int)rank_v, u);
-                const int64_t p = (sw0 + u) * 64 + lane;
-                const uint32_t jj = rank + (uint32_t)__popcll(mask & lane_mask) - 1u - jbase;
-                const uint4 ea = my_ne[3 * jj], eb = my_ne[3 * jj + 1];
-                const int64_t glo = (int64_t)(((uint64_t)ea.y << 32) | ea.x);
-                const int64_t D = (int64_t)(((uint64_t)ea.w << 32) | ea.z);
-                const int64_t E = (int64_t)(((uint64_t)eb.y << 32) | eb.x);
-                if (p >= glo && p >= p_begin && p < p_end) {
-                    const int64_t P = p - (k - 1);                       // >= 0 for an interior position
-                    const int si = (int)((P >> 5) - sb);
-                    const int sh = (int)(P & 31) * 2;
-                    const uint64_t lo = my_seq[si], hi = my_seq[si + 1];
-                    const uint64_t h = ((lo >> sh) | ((hi << 1) << (63 - sh))) & kmask;
-                    const int64_t idx = p + D;
-                    out.hash[idx] = h;
-                    out.node[idx] = eb.z;
-                    out.ref_offset[idx] = (uint64_t)(p + E);
-                    out.af[idx] = __uint_as_float(eb.w);
-                }
-            }
-            u0 = u1;
-        }
-    }
-}
-
-// Run-aligned variant.  The word-driven kernel above starts every wave store at record index p + D, which is
-// not a multiple of 8/16 records once bubbles have shifted D, so each 512-byte store touches 9 cache lines
-// instead of 8 (the store microbenchmark loses 13 % to exactly that).  Here the lanes are mapped to OUTPUT
-// records instead: the wave walks the node runs of its 4096-base window (from the per-node table in LDS, all
-// values wave-uniform) and covers each run [glo + D, glo + cnt + D) with 64-record groups that start at a
-// multiple of 16 records, i.e. on a cache-line boundary of all four columns.
+// FlatKmers variant (all four columns), LDS-staged and run-aligned.  History, all measured on MI355X:
+//  v1  per 64-base word: mask/rank -> per-lane gather of the node record -> four stores: 2.6-2.9 TB/s.  On gfx950
+//      vmcnt retires loads AND stores in order and under a saturated write stream a dependent global load takes
+//      microseconds; dropping only that gather gave 4.5 TB/s, dropping all loads 5.3 TB/s.
+//  v3  bitmap words, ranks, the 2-bit window and the node-record slice staged in LDS per 4096-base window, no
+//      global load in the inner loop: 3.9-4.5 TB/s.  But a store starting at record p + D touches 9 cache lines
+//      instead of 8 once bubbles have shifted D (the store microbenchmark loses 13 % to exactly that).
+//  v4  (this kernel) lanes are mapped to OUTPUT records instead: the wave walks the node runs of its 4096-base
+//      window (from the per-node table in LDS, all values wave-uniform) and covers each run
+//      [glo + D, glo + cnt + D) with 64-record groups that start at a multiple of 16 records, i.e. on a cache-line
+//      boundary of all four columns: -6 %.  With the split output layout (no holes between runs) 6.1 TB/s.
 template <int SWT, int CAP>
 __global__ __launch_bounds__(256) void k_emit_interior_runs(DevGraph g, FindArgs a, const NodeEmit *__restrict__ ne,
                                                             OutFlat out, int64_t word_begin, int64_t word_end,
@@ -929,12 +767,8 @@ static int launch_boundary(gki_finder *f, const DevGraph &d, const FindArgs &a, 
 
 static int launch_interior(gki_finder *f, const DevGraph &d, const FindArgs &a, OutFlat out, unsigned blocks) {
     hipStream_t s = f->stream;
-    static const bool word_driven = getenv("GKI_INTERIOR_WORDS") != nullptr;       // A/B knob: the older word-driven kernel
     if (out.hash && out.node && out.ref_offset && out.af) {
-        if (word_driven)
-            hipLaunchKernelGGL(k_emit_interior_flat, dim3(blocks), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end,
-                               f->p_begin, f->p_end);
-        else {
+        {
             static const int swt = getenv("GKI_SW") ? atoi(getenv("GKI_SW")) : 64;       // A/B knob: bases per wave trip / 64
             static const int rb = getenv("GKI_RUN_BLOCKS") ? atoi(getenv("GKI_RUN_BLOCKS")) : 256 * 5;
             const int64_t n_words = f->word_end - f->word_begin;
