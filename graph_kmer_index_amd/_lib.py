@@ -64,6 +64,7 @@ SYMBOLS = {
     "gki_forward_count": (_I32, [_P, _I32, _I32, _I32, _P, _P, _P, _I64, _P, C.POINTER(_I64)]),
     "gki_forward_emit": (_I32, [_P, _I32, _I32, _I32, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P]),
     "gki_index_build": (_I32, [_P, _P, _P, _P, _I64, _U64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gki_reverse_index_build": (_I32, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
     "gki_index_lookup_count": (_I32, [C.POINTER(IndexView), _P, _I64, _I64, _P, C.POINTER(_I64)]),
     "gki_index_count_nodes": (_I32, [C.POINTER(IndexView), _P, _I64, _I64, _P, _I64]),
     "gki_index_lookup_emit": (_I32, [C.POINTER(IndexView), _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),

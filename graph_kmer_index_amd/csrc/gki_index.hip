@@ -342,6 +342,75 @@ __global__ __launch_bounds__(256) void k_count_nodes(IndexDev ix, const uint64_t
     }
 }
 
+
+static int key_bits(uint64_t max_key) {
+    int bits = 0;
+    while (bits < 32 && (max_key >> bits) != 0) bits++;
+    return bits;
+}
+
+// Stable LSD sort of (key, value) pairs on the low `bits` bits of the key; ping-pongs between the two
+// buffers of each pair, *cur_out = index of the buffers holding the result.
+static int radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], int64_t n, int bits, uint32_t *hist, uint32_t *offs,
+                            void *tmp, int64_t tmp_bytes, hipStream_t s, int *cur_out) {
+    const int64_t n_tiles = ceil_div(n, RTILE);
+    const int64_t hist_n = (int64_t)RBINS * n_tiles;
+    int cur = 0;
+    for (int shift = 0; shift < bits; shift += 8) {
+        hipLaunchKernelGGL(k_radix_hist, dim3((unsigned)n_tiles), dim3(RB), 0, s, keys[cur], n, shift, hist, n_tiles);
+        HIP_TRY(hipGetLastError());
+        GKI_TRY(gki_scan_u32_to_u32(hist, hist_n, offs, tmp, tmp_bytes, s));
+        hipLaunchKernelGGL(k_radix_scatter, dim3((unsigned)n_tiles), dim3(RB), 0, s, keys[cur], vals[cur], n, shift, offs,
+                           n_tiles, keys[1 - cur], vals[1 - cur]);
+        HIP_TRY(hipGetLastError());
+        cur = 1 - cur;
+    }
+    *cur_out = cur;
+    return GKI_OK;
+}
+
+// ------------------------------------------------------------------------------------ reverse index
+// ReverseKmerIndex.from_flat_kmers (reverse_kmer_index.py:47-60): records stably sorted by node,
+// nodes_to_index_positions[node] = first record (uint32), nodes_to_n_hashes[node] = run length (uint16, wraps
+// like the NumPy assignment at :56).
+__global__ __launch_bounds__(256) void k_node_keys(const uint32_t *__restrict__ nodes, int64_t n, uint32_t *__restrict__ keys,
+                                                   uint32_t *__restrict__ idx) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { keys[i] = nodes[i]; idx[i] = (uint32_t)i; }
+}
+
+__global__ __launch_bounds__(256) void k_node_directory(const uint32_t *__restrict__ keys, int64_t n,
+                                                        uint32_t *__restrict__ first, uint16_t *__restrict__ count) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t b = keys[i];
+        if (i > 0 && keys[i - 1] == b) continue;
+        int64_t e = i + 1;
+        while (e < n && keys[e] == b) e++;
+        first[b] = (uint32_t)i;
+        count[b] = (uint16_t)(e - i);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pack_pairs(const uint64_t *__restrict__ a, const uint64_t *__restrict__ b, int64_t n,
+                                                    uint4 *__restrict__ rows) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t x = a[i], y = b[i];
+        rows[i] = make_uint4((uint32_t)x, (uint32_t)(x >> 32), (uint32_t)y, (uint32_t)(y >> 32));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gather_pairs(const uint32_t *__restrict__ idx, int64_t n, const uint4 *__restrict__ rows,
+                                                      uint64_t *__restrict__ o_a, uint64_t *__restrict__ o_b) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint4 r = rows[idx[i]];
+        o_a[i] = ((uint64_t)r.y << 32) | r.x;
+        o_b[i] = ((uint64_t)r.w << 32) | r.z;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -379,18 +448,10 @@ int gki_index_build(const void *d_kmers, const void *d_nodes, const void *d_ref_
         hipLaunchKernelGGL(k_bucket_keys, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const uint64_t *)d_kmers, n, modulo,
                            keys[0], vals[0]);
         HIP_G(hipGetLastError());
-        int bits = 0;
-        while (bits < 32 && ((modulo - 1) >> bits) != 0) bits++;
         int cur = 0;
-        for (int shift = 0; shift < bits; shift += 8) {
-            hipLaunchKernelGGL(k_radix_hist, dim3((unsigned)n_tiles), dim3(RB), 0, s, keys[cur], n, shift, hist, n_tiles);
-            HIP_G(hipGetLastError());
-            int r = gki_scan_u32_to_u32(hist, hist_n, offs, tmp, tmp_bytes, s);
+        {
+            int r = radix_sort_pairs(keys, vals, n, key_bits(modulo - 1), hist, offs, tmp, tmp_bytes, s, &cur);
             if (r != GKI_OK) CLEANUP_RETURN(r);
-            hipLaunchKernelGGL(k_radix_scatter, dim3((unsigned)n_tiles), dim3(RB), 0, s, keys[cur], vals[cur], n, shift, offs,
-                               n_tiles, keys[1 - cur], vals[1 - cur]);
-            HIP_G(hipGetLastError());
-            cur = 1 - cur;
         }
         HIP_G(hipMalloc((void **)&rows, (size_t)n * 32));
         hipLaunchKernelGGL(k_pack_rows, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const uint64_t *)d_kmers,
@@ -449,6 +510,53 @@ done:
     (void)hipFree(hist); (void)hipFree(offs); (void)hipFree(tmp); (void)hipFree(rows);
 #undef HIP_G
 #undef CLEANUP_RETURN
+    return rc;
+}
+
+int gki_reverse_index_build(const void *d_nodes, const void *d_kmers, const void *d_ref_offsets, int64_t n, int64_t n_nodes,
+                            void *d_index_positions, void *d_n_hashes, void *d_out_kmers, void *d_out_ref_offsets) {
+    if (n_nodes <= 0 || n_nodes > (1ll << 32)) return gki_set_error(GKI_ERR_BAD_ARG, "n_nodes must be in 1..2^32");
+    if (n >= (1ll << 32)) return gki_set_error(GKI_ERR_OVERFLOW, "%lld records do not fit the uint32 directory", (long long)n);
+    hipStream_t s = 0;
+    HIP_TRY(hipMemsetAsync(d_index_positions, 0, (size_t)n_nodes * 4, s));      // reverse_kmer_index.py:53
+    HIP_TRY(hipMemsetAsync(d_n_hashes, 0, (size_t)n_nodes * 2, s));             // :54
+    if (n <= 0) { HIP_TRY(hipStreamSynchronize(s)); return GKI_OK; }
+    const int64_t hist_n = (int64_t)RBINS * ceil_div(n, RTILE);
+    const int64_t tmp_bytes = gki_scan_tmp_bytes(hist_n);
+    uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *hist = nullptr, *offs = nullptr;
+    uint4 *rows = nullptr;
+    void *tmp = nullptr;
+    int rc = GKI_OK;
+#define HIP_G(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = gki_set_error(GKI_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); goto done; } } while (0)
+    {
+        for (int i = 0; i < 2; i++) {
+            HIP_G(hipMalloc((void **)&keys[i], (size_t)n * 4));
+            HIP_G(hipMalloc((void **)&vals[i], (size_t)n * 4));
+        }
+        HIP_G(hipMalloc((void **)&hist, (size_t)hist_n * 4));
+        HIP_G(hipMalloc((void **)&offs, (size_t)(hist_n + 1) * 4));
+        HIP_G(hipMalloc(&tmp, (size_t)tmp_bytes));
+        HIP_G(hipMalloc((void **)&rows, (size_t)n * 16));
+        hipLaunchKernelGGL(k_node_keys, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const uint32_t *)d_nodes, n, keys[0], vals[0]);
+        HIP_G(hipGetLastError());
+        int cur = 0;
+        rc = radix_sort_pairs(keys, vals, n, key_bits((uint64_t)n_nodes - 1), hist, offs, tmp, tmp_bytes, s, &cur);
+        if (rc != GKI_OK) goto done;
+        hipLaunchKernelGGL(k_pack_pairs, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const uint64_t *)d_kmers,
+                           (const uint64_t *)d_ref_offsets, n, rows);
+        HIP_G(hipGetLastError());
+        hipLaunchKernelGGL(k_gather_pairs, dim3(stream_grid(n, 256)), dim3(256), 0, s, vals[cur], n, (const uint4 *)rows,
+                           (uint64_t *)d_out_kmers, (uint64_t *)d_out_ref_offsets);
+        HIP_G(hipGetLastError());
+        hipLaunchKernelGGL(k_node_directory, dim3(stream_grid(n, 256)), dim3(256), 0, s, keys[cur], n,
+                           (uint32_t *)d_index_positions, (uint16_t *)d_n_hashes);
+        HIP_G(hipGetLastError());
+        HIP_G(hipStreamSynchronize(s));
+    }
+done:
+    for (int i = 0; i < 2; i++) { (void)hipFree(keys[i]); (void)hipFree(vals[i]); }
+    (void)hipFree(hist); (void)hipFree(offs); (void)hipFree(tmp); (void)hipFree(rows);
+#undef HIP_G
     return rc;
 }
 

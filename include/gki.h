@@ -182,6 +182,16 @@ int gki_index_build(const void *d_kmers, const void *d_nodes, const void *d_ref_
                     void *d_out_kmers, void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32,
                     void *d_out_frequencies, void *d_out_permutation);
 
+/* ---------------------------------------------------------------- ReverseKmerIndex
+ * Replaces ReverseKmerIndex.from_flat_kmers (reverse_kmer_index.py:47-60): records stably sorted by
+ * node.  Inputs: device columns nodes uint32[n], kmers uint64[n], ref_offsets uint64[n]; n_nodes =
+ * max node id + 1.  Outputs (device, sized by the caller): index_positions uint32[n_nodes] (first
+ * record of the node, 0 if none), n_hashes uint16[n_nodes] (records of the node, modulo 2^16 as the
+ * NumPy assignment at :56 stores it), and the permuted kmers / ref_offsets uint64[n]. */
+int gki_reverse_index_build(const void *d_nodes, const void *d_kmers, const void *d_ref_offsets, int64_t n,
+                            int64_t n_nodes, void *d_index_positions, void *d_n_hashes, void *d_out_kmers,
+                            void *d_out_ref_offsets);
+
 /* Probe: replaces a loop of CollisionFreeKmerIndex.get (:303-315) over q queries
  * (get_nodes_and_ref_offsets_from_multiple_kmers :354-376).  count -> emit.
  * d_hit_start int64[q+1]: hits of query i are [hit_start[i], hit_start[i+1]) in bucket order;

@@ -3,7 +3,7 @@ import os
 import numpy as np
 import pytest
 
-from graph_kmer_index_amd import (CollisionFreeKmerIndex, FlatKmers, ReadKmers, _lib, sequence_to_kmer_hash,
+from graph_kmer_index_amd import (ReverseKmerIndex, CollisionFreeKmerIndex, FlatKmers, ReadKmers, _lib, sequence_to_kmer_hash,
                                   kmer_hash_to_sequence)
 from graph_kmer_index_amd.kmer_hashing import (kmer_hashes_to_reverse_complement_hash, kmer_hashes_to_complement_hashes,
                                                kmer_hash_to_reverse_complement_hash, power_array)
@@ -241,3 +241,62 @@ def test_map_kmers_fused_node_counts():
     exp = np.bincount(hit_nodes.astype(np.int64), minlength=3000)
     assert got.dtype == np.uint32 and np.array_equal(got, exp)
     assert idx.has_kmers(queries).sum() == 2200
+
+
+# ------------------------------------------------------------------ ReverseKmerIndex (reverse_kmer_index.py:47-83)
+def _reverse_index_numpy(nodes, kmers, refs):
+    """the reference's from_flat_kmers with a stable argsort"""
+    order = np.argsort(nodes, kind="stable")
+    snodes = nodes[order].astype(np.int64)
+    first = np.flatnonzero(np.ediff1d(snodes, to_begin=1))
+    uniq = snodes[first]
+    index = np.zeros(int(nodes.max()) + 1, np.uint32)
+    counts = np.zeros(int(nodes.max()) + 1, np.uint16)
+    index[uniq] = first
+    counts[uniq] = np.ediff1d(first, to_end=len(nodes) - first[-1]).astype(np.uint16)
+    return index, counts, kmers[order], refs[order]
+
+
+def test_reverse_index_reference_known_answer(tmp_path):
+    # tests/test_reverse_kmer_index.py:6-22 of the reference
+    flat = FlatKmers(np.array([10, 3, 11, 4]), np.array([5, 3, 5, 8]), np.array([1, 2, 3, 4]))
+    r = ReverseKmerIndex.from_flat_kmers(flat)
+    assert list(r.get_node_kmers(5)) == [10, 11]
+    assert list(r.get_node_kmers(3)) == [3]
+    assert list(r.get_node_kmers(8)) == [4]
+    assert list(r.get_node_kmers(4)) == [] and r.get_node_kmers_and_ref_positions(0) == [[], []]
+    km, rp = r.get_node_kmers_and_ref_positions(5)
+    assert list(km) == [10, 11] and list(rp) == [1, 3]
+    assert r.nodes_to_index_positions.dtype == np.uint32 and r.nodes_to_n_hashes.dtype == np.uint16
+    assert r.hashes.dtype == flat._hashes.dtype
+    r.to_file(str(tmp_path / "rev"))
+    r2 = ReverseKmerIndex.from_file(str(tmp_path / "rev"))
+    for name in ReverseKmerIndex.properties:
+        assert np.array_equal(getattr(r, name), getattr(r2, name))
+    with pytest.raises(IndexError):
+        r.get_node_kmers_and_ref_positions(9)
+
+
+@pytest.mark.parametrize("n,n_nodes,seed", [(1, 1, 0), (5000, 70, 1), (300000, 100000, 2), (200000, 3, 3)])
+def test_reverse_index_random_vs_numpy(n, n_nodes, seed):
+    rng = np.random.default_rng(seed)
+    nodes = rng.integers(0, n_nodes, size=n).astype(np.uint32)
+    kmers = rng.integers(0, 4 ** 31, size=n, dtype=np.uint64)
+    refs = rng.integers(0, 2 ** 40, size=n, dtype=np.uint64)
+    r = ReverseKmerIndex.from_flat_kmers(FlatKmers(kmers, nodes, refs))
+    index, counts, skm, srf = _reverse_index_numpy(nodes, kmers, refs)        # (200000, 3): counts wrap at 2^16
+    assert np.array_equal(r.nodes_to_index_positions, index)
+    assert np.array_equal(r.nodes_to_n_hashes, counts)
+    assert np.array_equal(r.hashes, skm) and np.array_equal(r.ref_positions, srf)
+
+
+def test_reverse_index_from_device_flat_kmers():
+    from graph_kmer_index_amd import DeviceFlatKmers
+    rng = np.random.default_rng(5)
+    n = 40000
+    flat = FlatKmers(rng.integers(0, 4 ** 31, size=n, dtype=np.uint64), rng.integers(0, 999, size=n).astype(np.uint32),
+                     rng.integers(0, 10 ** 9, size=n, dtype=np.uint64), np.ones(n, np.float32))
+    a = ReverseKmerIndex.from_flat_kmers(DeviceFlatKmers.from_flat_kmers(flat))
+    b = ReverseKmerIndex.from_flat_kmers(flat)
+    for name in ReverseKmerIndex.properties:
+        assert np.array_equal(getattr(a, name), getattr(b, name))
