@@ -68,6 +68,10 @@ SYMBOLS = {
     "gki_index_lookup_count": (_I32, [C.POINTER(IndexView), _P, _I64, _I64, _P, C.POINTER(_I64)]),
     "gki_index_count_nodes": (_I32, [C.POINTER(IndexView), _P, _I64, _I64, _P, _I64]),
     "gki_index_lookup_emit": (_I32, [C.POINTER(IndexView), _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
+    "gki_probe_create": (_I32, [C.POINTER(IndexView), C.POINTER(_P)]),
+    "gki_probe_destroy": (_I32, [_P]),
+    "gki_probe_count_nodes": (_I32, [_P, _P, _I64, _I64, _P, _I64, C.POINTER(_I64)]),
+    "gki_probe_reads_count_nodes": (_I32, [_P, _P, _P, _I64, _I32, _I32, _I64, _P, _I64, C.POINTER(_I64), C.POINTER(_I64)]),
     "gki_comm_get_unique_id": (_I32, [_P]),
     "gki_comm_create": (_I32, [C.POINTER(_P), _I32, _I32, _P]),
     "gki_comm_destroy": (_I32, [_P]),

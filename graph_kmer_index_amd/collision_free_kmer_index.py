@@ -21,6 +21,7 @@ class DeviceIndex:
     def __init__(self, n, modulo, hashes_to_index, n_kmers, kmers, nodes, ref_offsets, af, frequencies):
         self.n, self.modulo = int(n), int(modulo)
         self.permutation = None
+        self._probe = None
         self.hashes_to_index, self.n_kmers, self.kmers, self.nodes = hashes_to_index, n_kmers, kmers, nodes
         self.ref_offsets, self.allele_frequencies, self.frequencies = ref_offsets, af, frequencies
 
@@ -68,22 +69,78 @@ class DeviceIndex:
             b.free()
         return out
 
-    def count_nodes(self, queries, n_nodes, max_hits=10, counts=None):
-        """Fused probe + node histogram (gki_index_count_nodes).  queries: NumPy array or DeviceArray of uint64.
-        Returns a DeviceArray uint32[n_nodes] (accumulates into `counts` when given)."""
+    def probe_table(self):
+        """The probe-table re-layout of this index in HBM (gki_probe_create), built on first use."""
+        if self._probe is None:
+            p = C.c_void_p()
+            view = self.view()
+            _lib.check(_lib.load().gki_probe_create(C.byref(view), C.byref(p)))
+            self._probe = p
+        return self._probe
+
+    def count_nodes(self, queries, n_nodes, max_hits=10, counts=None, use_probe_table=True, return_hits=False):
+        """Fused probe + node histogram.  queries: NumPy array or DeviceArray of uint64.  Returns a DeviceArray
+        uint32[n_nodes] (accumulates into `counts` when given).  use_probe_table=False probes the reference-layout
+        arrays directly (gki_index_count_nodes) instead of the probe table (gki_probe_count_nodes)."""
         lib = _lib.load()
         if counts is None:
             counts = _lib.DeviceArray(max(int(n_nodes), 1), np.uint32)
             counts.zero()
         own = not isinstance(queries, _lib.DeviceArray)
         dq = _lib.DeviceArray.from_host(np.ascontiguousarray(np.asarray(queries)).astype(np.uint64)) if own else queries
-        view = self.view()
-        _lib.check(lib.gki_index_count_nodes(C.byref(view), dq.ptr, dq.n, int(min(max_hits, 2 ** 62)), counts.ptr, int(n_nodes)))
+        mh = int(min(max_hits, 2 ** 62))
+        n_hits = C.c_int64(-1)
+        if use_probe_table:
+            _lib.check(lib.gki_probe_count_nodes(self.probe_table(), dq.ptr, dq.n, mh, counts.ptr, int(n_nodes),
+                                                 C.byref(n_hits)))
+        else:
+            view = self.view()
+            _lib.check(lib.gki_index_count_nodes(C.byref(view), dq.ptr, dq.n, mh, counts.ptr, int(n_nodes)))
         if own:
             dq.free()
-        return counts
+        return (counts, n_hits.value) if return_hits else counts
+
+    def count_nodes_from_reads(self, letters, read_start, k, n_nodes, strands=3, max_hits=10, counts=None):
+        """Read hashing fused with the probe (gki_probe_reads_count_nodes): letters = ASCII uint8 of all reads
+        (NumPy or DeviceArray), read_start int64[n_reads+1]; strands bit 0 forward, bit 1 reverse complement.
+        Returns (counts DeviceArray uint32[n_nodes], k-mers probed, hits)."""
+        lib = _lib.load()
+        if counts is None:
+            counts = _lib.DeviceArray(max(int(n_nodes), 1), np.uint32)
+            counts.zero()
+        owned = []
+
+        def dev(a, dtype):
+            if isinstance(a, _lib.DeviceArray):
+                return a
+            a = np.ascontiguousarray(a, dtype=dtype)
+            d = _lib.DeviceArray.from_host(a if a.size else np.zeros(1, dtype))
+            owned.append(d)
+            return d
+        n_reads = len(read_start) - 1
+        d_letters, d_start = dev(letters, np.uint8), dev(read_start, np.int64)
+        n_kmers, n_hits = C.c_int64(0), C.c_int64(0)
+        try:
+            _lib.check(lib.gki_probe_reads_count_nodes(self.probe_table(), d_letters.ptr, d_start.ptr, n_reads, int(k),
+                                                       int(strands), int(min(max_hits, 2 ** 62)), counts.ptr, int(n_nodes),
+                                                       C.byref(n_kmers), C.byref(n_hits)))
+        finally:
+            for d in owned:
+                d.free()
+        return counts, n_kmers.value, n_hits.value
+
+    def __del__(self):
+        try:
+            if self._probe is not None:
+                _lib.load().gki_probe_destroy(self._probe)
+                self._probe = None
+        except Exception:
+            pass
 
     def free(self):
+        if self._probe is not None:
+            _lib.load().gki_probe_destroy(self._probe)
+            self._probe = None
         for a in (self.hashes_to_index, self.n_kmers, self.kmers, self.nodes, self.ref_offsets,
                   self.allele_frequencies, self.frequencies):
             a.free()
@@ -214,6 +271,22 @@ class CollisionFreeKmerIndex:
         """kmer_mapper.map_kmers_to_graph_index equivalent (:210-212): node hit counts, probe and histogram fused
         on the device."""
         counts = self._device_index().count_nodes(kmers, n_nodes, max_hits=2 ** 62)
+        out = counts.to_host(n_nodes)
+        counts.free()
+        return out
+
+    def map_reads(self, reads, k, n_nodes, max_hits=2 ** 62, include_reverse_complement=True):
+        """ReadKmers (read_kmers.py:21-26) + map_kmers in one device pass: node hit counts of all k-mers of `reads`
+        (list of str/bytes, or (uint8 letters, int64 read_start)) and, by default, of their reverse complements."""
+        if isinstance(reads, tuple):
+            letters, read_start = reads
+        else:
+            enc = [r.encode("ascii") if isinstance(r, str) else bytes(r) for r in reads]
+            read_start = np.zeros(len(enc) + 1, dtype=np.int64)
+            np.cumsum([len(e) for e in enc], out=read_start[1:])
+            letters = np.frombuffer(b"".join(enc), dtype=np.uint8)
+        counts, _, _ = self._device_index().count_nodes_from_reads(letters, read_start, k, n_nodes,
+                                                                   3 if include_reverse_complement else 1, max_hits)
         out = counts.to_host(n_nodes)
         counts.free()
         return out

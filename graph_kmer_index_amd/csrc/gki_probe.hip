@@ -1,0 +1,251 @@
+// Probe table: a device-only re-layout of a CollisionFreeKmerIndex for the read-side hot loop
+// (hash read k-mers -> CollisionFreeKmerIndex.get -> node counts; collision_free_kmer_index.py:210-212, 303-315).
+//
+// A probe is bound by the number of random 64-byte sectors it touches, not by bytes.  The reference layout costs a
+// hit five of them (hashes_to_index, n_kmers, kmers, nodes, frequencies).  The probe table costs
+//   * one sector per query:  dir[bucket] = {first record, record count (16 bit, saturating), 16-bit fingerprint set
+//     of the bucket's k-mers} -- an empty bucket or a fingerprint miss ends the query here;
+//   * one more per candidate bucket: rows[j] = {kmer, node, frequency} in 16 bytes, consecutive inside the bucket.
+// Node counts are accumulated with atomics on a uint32[n_nodes] histogram (60 MB at 1.5e7 nodes: cache resident).
+//
+// k_probe_reads fuses read hashing into the probe: one wave per read, 64 letters per step turned into bit planes
+// with __ballot as in k_hash_reads; the reverse-complement k-mer of every window comes from the same planes, so the
+// read is loaded once for both strands and no k-mer array is ever materialised.
+#include "gki_common.h"
+
+struct gki_probe {
+    uint2 *dir = nullptr;            // [modulo]
+    uint4 *rows = nullptr;           // [n]
+    const uint32_t *n_kmers = nullptr;   // the index's own array (borrowed): exact length of saturated buckets
+    unsigned long long *counters = nullptr;   // [2] device: hits, k-mers probed
+    uint64_t modulo = 0;
+    int64_t n = 0;
+};
+
+namespace {
+
+constexpr uint32_t CNT_SAT = 0xFFFFu;
+constexpr int FP_SCAN_MAX = 64;      // buckets longer than this get an all-ones fingerprint set
+
+__device__ __forceinline__ uint32_t fp_bit(uint64_t kmer) {
+    const uint32_t x = (uint32_t)(kmer >> 32) * 0x9E3779B1u ^ (uint32_t)kmer * 0x85EBCA77u;
+    return 1u << (x >> 28);
+}
+
+__global__ __launch_bounds__(256) void k_probe_dir(const int32_t *__restrict__ h2i, const uint32_t *__restrict__ nk,
+                                                   const uint64_t *__restrict__ kmers, uint64_t modulo,
+                                                   uint2 *__restrict__ dir) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < (int64_t)modulo; b += stride) {
+        const uint32_t m = nk[b];
+        const uint32_t s = (uint32_t)h2i[b];
+        uint32_t fp = 0;
+        if (m > FP_SCAN_MAX) fp = 0xFFFFu;
+        else for (uint32_t j = 0; j < m; j++) fp |= fp_bit(kmers[(int64_t)s + j]);
+        dir[b] = make_uint2(s, (m < CNT_SAT ? m : CNT_SAT) | (fp << 16));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_probe_rows(const uint64_t *__restrict__ kmers, const uint32_t *__restrict__ nodes,
+                                                    const uint16_t *__restrict__ freq, int64_t n, uint4 *__restrict__ rows) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t k = kmers[i];
+        rows[i] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), nodes[i], freq ? (uint32_t)freq[i] : 0u);
+    }
+}
+
+struct ProbeDev {
+    const uint2 *dir; const uint4 *rows; const uint32_t *nk; uint64_t modulo;
+};
+
+// CollisionFreeKmerIndex.get for one k-mer, counting instead of returning (:303-315 + map_kmers :210-212).
+// Returns the number of hits counted.
+__device__ __forceinline__ uint32_t probe_one(const ProbeDev &t, uint64_t km, int64_t max_hits,
+                                              unsigned int *__restrict__ counts, int64_t n_counts) {
+    const uint64_t b = km % t.modulo;                                   // :304
+    const uint2 d = t.dir[b];
+    const uint32_t c16 = d.y & 0xFFFFu;
+    if (c16 == 0u || ((d.y >> 16) & fp_bit(km)) == 0u) return 0u;
+    const int64_t m = c16 == CNT_SAT ? (int64_t)t.nk[b] : (int64_t)c16;
+    const int64_t s = d.x;
+    uint32_t hits = 0;
+    for (int64_t j = s; j < s + m; j++) {
+        const uint4 r = t.rows[j];
+        if ((((uint64_t)r.y << 32) | r.x) != km) continue;              // :309
+        if (hits == 0u && (int64_t)r.w > max_hits) break;               // :312 (frequency of the first match)
+        if ((int64_t)r.z < n_counts) atomicAdd(&counts[r.z], 1u);
+        hits++;
+    }
+    return hits;
+}
+
+__device__ __forceinline__ void wave_add(unsigned long long *dst, uint64_t v) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_down(v, s, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, (unsigned long long)v);
+}
+
+__global__ __launch_bounds__(256) void k_probe_kmers(ProbeDev t, const uint64_t *__restrict__ queries, int64_t q,
+                                                     int64_t max_hits, unsigned int *__restrict__ counts, int64_t n_counts,
+                                                     unsigned long long *__restrict__ counters) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint64_t hits = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += stride)
+        hits += probe_one(t, queries[i], max_hits, counts, n_counts);
+    wave_add(&counters[0], hits);
+}
+
+// 31 low bits -> even bit positions (Morton spread)
+__device__ __forceinline__ uint64_t spread31(uint64_t x) {
+    x &= 0x7FFFFFFFull;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
+}
+
+__device__ __forceinline__ uint64_t funnel(uint64_t cur, uint64_t next, int lane) {
+    return (cur >> lane) | ((next << 1) << (63 - lane));
+}
+
+// One wave per read.  Forward k-mer of window j: bases j..j+k-1, first base least significant (read_kmers.py:70).
+// Reverse strand (read_kmers.py:23-26): the k-mers of str(Seq(read).reverse_complement()) are, window by window,
+// the reverse complements of the forward windows, with non-ACGT letters hashing as 0 on both strands
+// (Bio.Seq maps N to N): code' = acgt ? 3 - code : 0, window reversed.
+__global__ __launch_bounds__(256) void k_probe_reads(ProbeDev t, const uint8_t *__restrict__ reads,
+                                                     const int64_t *__restrict__ read_start, int64_t n_reads, int k,
+                                                     int strands, int64_t max_hits, unsigned int *__restrict__ counts,
+                                                     int64_t n_counts, unsigned long long *__restrict__ counters) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t kmask = (1ull << k) - 1ull;
+    uint64_t hits = 0, probed = 0;
+    for (int64_t r = wave; r < n_reads; r += n_waves) {
+        const int64_t s = read_start[r];
+        const int64_t len = read_start[r + 1] - s;
+        if (len < k) continue;
+        const int64_t n_out = len - k + 1;
+        uint64_t lo_cur = 0, hi_cur = 0, ok_cur = 0;
+        for (int64_t c = 0; c * 64 < len + 64; c++) {
+            const int64_t i = c * 64 + lane;
+            unsigned code = 0;
+            bool acgt = false;
+            if (i < len) {
+                const unsigned ch = reads[s + i] | 0x20u;
+                code = ch == 'c' ? 1u : ch == 'g' ? 2u : ch == 't' ? 3u : 0u;
+                acgt = ch == 'a' || code != 0u;
+            }
+            const uint64_t lo_next = __ballot(code & 1u);
+            const uint64_t hi_next = __ballot(code & 2u);
+            const uint64_t ok_next = __ballot(acgt);
+            if (c > 0) {
+                const int64_t j = (c - 1) * 64 + lane;
+                if (j < n_out) {
+                    const uint64_t l = funnel(lo_cur, lo_next, lane) & kmask;
+                    const uint64_t h = funnel(hi_cur, hi_next, lane) & kmask;
+                    if (strands & 1) {
+                        hits += probe_one(t, spread31(l) | (spread31(h) << 1), max_hits, counts, n_counts);
+                        probed++;
+                    }
+                    if (strands & 2) {
+                        const uint64_t a = funnel(ok_cur, ok_next, lane) & kmask;
+                        const uint64_t rl = __brevll(a & ~l) >> (64 - k);
+                        const uint64_t rh = __brevll(a & ~h) >> (64 - k);
+                        hits += probe_one(t, spread31(rl) | (spread31(rh) << 1), max_hits, counts, n_counts);
+                        probed++;
+                    }
+                }
+            }
+            lo_cur = lo_next; hi_cur = hi_next; ok_cur = ok_next;
+        }
+    }
+    wave_add(&counters[0], hits);
+    wave_add(&counters[1], probed);
+}
+
+static ProbeDev dev_of(const gki_probe *p) {
+    ProbeDev d; d.dir = p->dir; d.rows = p->rows; d.nk = p->n_kmers; d.modulo = p->modulo;
+    return d;
+}
+
+static int read_counters(gki_probe *p, int64_t *n_hits, int64_t *n_kmers) {
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(hipMemcpy(h, p->counters, sizeof(h), hipMemcpyDeviceToHost));     // synchronises with stream 0
+    if (n_hits) *n_hits = (int64_t)h[0];
+    if (n_kmers) *n_kmers = (int64_t)h[1];
+    return GKI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gki_probe_create(const gki_index_view *ix, gki_probe **out) {
+    *out = nullptr;
+    if (ix->modulo == 0 || ix->modulo > 0xFFFFFFFFull) return gki_set_error(GKI_ERR_BAD_ARG, "modulo must be in 1..2^32-1");
+    if (ix->n < 0 || ix->n >= (1ll << 32)) return gki_set_error(GKI_ERR_BAD_ARG, "record count must be below 2^32");
+    gki_probe *p = new gki_probe();
+    p->modulo = ix->modulo; p->n = ix->n; p->n_kmers = (const uint32_t *)ix->d_n_kmers;
+    hipError_t e = hipMalloc((void **)&p->dir, (size_t)ix->modulo * sizeof(uint2));
+    if (e == hipSuccess) e = hipMalloc((void **)&p->rows, (size_t)(ix->n > 0 ? ix->n : 1) * sizeof(uint4));
+    if (e == hipSuccess) e = hipMalloc((void **)&p->counters, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) {
+        if (ix->n > 0)
+            hipLaunchKernelGGL(k_probe_rows, dim3(stream_grid(ix->n, 256)), dim3(256), 0, 0, (const uint64_t *)ix->d_kmers,
+                               (const uint32_t *)ix->d_nodes, (const uint16_t *)ix->d_frequencies, ix->n, p->rows);
+        hipLaunchKernelGGL(k_probe_dir, dim3(stream_grid((int64_t)ix->modulo, 256)), dim3(256), 0, 0,
+                           (const int32_t *)ix->d_hashes_to_index, (const uint32_t *)ix->d_n_kmers,
+                           (const uint64_t *)ix->d_kmers, ix->modulo, p->dir);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(0);
+    }
+    if (e != hipSuccess) {
+        (void)hipFree(p->dir); (void)hipFree(p->rows); (void)hipFree(p->counters);
+        delete p;
+        return gki_set_error(GKI_ERR_HIP, "gki_probe_create: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return GKI_OK;
+}
+
+int gki_probe_destroy(gki_probe *p) {
+    if (!p) return GKI_OK;
+    (void)hipFree(p->dir); (void)hipFree(p->rows); (void)hipFree(p->counters);
+    delete p;
+    return GKI_OK;
+}
+
+int gki_probe_count_nodes(gki_probe *p, const void *d_queries, int64_t q, int64_t max_hits, void *d_counts, int64_t n_counts,
+                          int64_t *n_hits) {
+    if (n_hits) *n_hits = 0;
+    if (q <= 0) return GKI_OK;
+    HIP_TRY(hipMemsetAsync(p->counters, 0, 2 * sizeof(unsigned long long), 0));
+    hipLaunchKernelGGL(k_probe_kmers, dim3(stream_grid(q, 256)), dim3(256), 0, 0, dev_of(p), (const uint64_t *)d_queries, q,
+                       max_hits, (unsigned int *)d_counts, n_counts, p->counters);
+    HIP_TRY(hipGetLastError());
+    return read_counters(p, n_hits, nullptr);
+}
+
+int gki_probe_reads_count_nodes(gki_probe *p, const void *d_reads, const void *d_read_start, int64_t n_reads, int k,
+                                int strands, int64_t max_hits, void *d_counts, int64_t n_counts, int64_t *n_kmers,
+                                int64_t *n_hits) {
+    if (n_hits) *n_hits = 0;
+    if (n_kmers) *n_kmers = 0;
+    if (k < 1 || k > GKI_MAX_K) return gki_set_error(GKI_ERR_BAD_ARG, "k must be in 1..31");
+    if (strands < 1 || strands > 3) return gki_set_error(GKI_ERR_BAD_ARG, "strands must be 1 (forward), 2 (reverse) or 3 (both)");
+    if (n_reads <= 0) return GKI_OK;
+    HIP_TRY(hipMemsetAsync(p->counters, 0, 2 * sizeof(unsigned long long), 0));
+    int64_t blocks = ceil_div(n_reads, 4);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(k_probe_reads, dim3((unsigned)blocks), dim3(256), 0, 0, dev_of(p), (const uint8_t *)d_reads,
+                       (const int64_t *)d_read_start, n_reads, k, strands, max_hits, (unsigned int *)d_counts, n_counts,
+                       p->counters);
+    HIP_TRY(hipGetLastError());
+    return read_counters(p, n_hits, n_kmers);
+}
+
+}  // extern "C"

@@ -215,6 +215,24 @@ int gki_index_lookup_emit(const gki_index_view *ix, const void *d_queries, int64
                           const void *d_hit_start, void *d_hit_nodes, void *d_hit_ref_offsets,
                           void *d_hit_query, void *d_hit_frequencies, void *d_hit_af32, void *d_hit_position);
 
+/* ---------------------------------------------------------------- probe table (read-side hot loop)
+ * A device-only re-layout of an index for counting: dir uint2[modulo] = {first record, count (16 bit, saturating)
+ * | 16-bit fingerprint set << 16}, rows uint4[n] = {kmer, node, frequency}: one random 64-byte sector per query,
+ * one more per candidate bucket (the reference layout touches five arrays per hit).  Costs modulo*8 + n*16 bytes
+ * of HBM.  The view's d_n_kmers must outlive the probe (read for buckets of >= 65535 records).
+ * gki_probe_count_nodes       = gki_index_count_nodes on the table; *n_hits (nullable) = hits counted.
+ * gki_probe_reads_count_nodes = ReadKmers hashing (read_kmers.py:21-26,70) fused with the probe: reads are ASCII
+ *   letters uint8[] with int64 read_start[n_reads+1]; strands bit 0 = forward k-mers, bit 1 = k-mers of the
+ *   reverse-complemented read; no k-mer array is materialised.  *n_kmers (nullable) = k-mers probed. */
+typedef struct gki_probe gki_probe;
+int gki_probe_create(const gki_index_view *ix, gki_probe **out);
+int gki_probe_destroy(gki_probe *p);
+int gki_probe_count_nodes(gki_probe *p, const void *d_queries, int64_t q, int64_t max_hits, void *d_counts,
+                          int64_t n_counts, int64_t *n_hits);
+int gki_probe_reads_count_nodes(gki_probe *p, const void *d_reads, const void *d_read_start, int64_t n_reads, int k,
+                                int strands, int64_t max_hits, void *d_counts, int64_t n_counts, int64_t *n_kmers,
+                                int64_t *n_hits);
+
 /* ---------------------------------------------------------------- multi-GPU exchange (RCCL over xGMI)
  * One process per GPU.  The reference gathers its per-process FlatKmers by pickling them through a
  * process pool and concatenating (command_line_interface.py:607-614, flat_kmers.py:71-90); here every

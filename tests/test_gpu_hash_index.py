@@ -300,3 +300,84 @@ def test_reverse_index_from_device_flat_kmers():
     b = ReverseKmerIndex.from_flat_kmers(flat)
     for name in ReverseKmerIndex.properties:
         assert np.array_equal(getattr(a, name), getattr(b, name))
+
+
+# ------------------------------------------------------------------ probe table + fused read mapping
+def _oracle_node_counts(index, queries, n_nodes, max_hits):
+    exp = np.zeros(n_nodes, np.int64)
+    hits = 0
+    for q in queries:
+        nodes = oracle.index_get(index, int(q), max_hits)[0]
+        if nodes is not None:
+            np.add.at(exp, np.asarray(nodes, np.int64), 1)
+            hits += len(nodes)
+    return exp, hits
+
+
+@pytest.mark.parametrize("modulo,n,pool_size,skip_freq", [(100003, 60000, 5000, False), (3, 250000, 40, False),
+                                                         (257, 30000, 900, True), (452930477, 20000, 20000, False)])
+def test_probe_table_count_nodes_vs_oracle(modulo, n, pool_size, skip_freq):
+    # (3, 250000): three buckets of > 65535 records (saturated directory count, all-ones fingerprint set)
+    rng = np.random.default_rng(modulo % 1000)
+    pool = rng.integers(0, 4 ** 31, size=pool_size, dtype=np.int64)
+    kmers = pool[rng.integers(0, pool_size, size=n)]
+    nodes = rng.integers(0, 2000, size=n).astype(np.uint32)
+    refs = rng.integers(0, 50, size=n).astype(np.uint64)
+    af = np.ones(n, np.float32)
+    idx = CollisionFreeKmerIndex.from_flat_kmers(FlatKmers(kmers, nodes, refs, af), modulo=modulo, skip_frequencies=skip_freq)
+    orc = oracle.index_build(kmers, nodes, refs, af, modulo=modulo, skip_frequencies=skip_freq)
+    queries = np.concatenate([pool[:300], pool[:100], rng.integers(0, 4 ** 31, size=300, dtype=np.int64)]).astype(np.uint64)
+    dev = idx._device_index()
+    for max_hits in (2 ** 62, 10, 2):
+        exp, exp_hits = _oracle_node_counts(orc, queries[:120] if n > 100000 else queries, 2000, max_hits)
+        qs = queries[:120] if n > 100000 else queries
+        got, hits = dev.count_nodes(qs, 2000, max_hits=max_hits, return_hits=True)
+        ref_layout = dev.count_nodes(qs, 2000, max_hits=max_hits, use_probe_table=False)
+        assert hits == exp_hits
+        assert np.array_equal(got.to_host(2000), exp)
+        assert np.array_equal(ref_layout.to_host(2000), exp)
+    # nodes beyond n_counts are dropped, counts accumulate across calls
+    small = dev.count_nodes(queries, 100, max_hits=2 ** 62)
+    dev.count_nodes(queries, 100, max_hits=2 ** 62, counts=small)
+    full, _ = _oracle_node_counts(orc, queries[:120], 2000, 2 ** 62) if n > 100000 else _oracle_node_counts(orc, queries, 2000, 2 ** 62)
+    if n <= 100000:
+        assert np.array_equal(small.to_host(100), 2 * full[:100])
+
+
+@pytest.mark.parametrize("k", [5, 31])
+def test_map_reads_fused_vs_oracle(k):
+    rng = np.random.default_rng(40 + k)
+    genome = "".join("ACGT"[i] for i in rng.integers(0, 4, size=6000))
+    codes = oracle.letter_sequence_to_numeric(genome)
+    hashes = oracle.hash_sequence(codes, k).astype(np.int64)
+    n = len(hashes)
+    nodes = (np.arange(n) // 50).astype(np.uint32)
+    n_nodes = int(nodes.max()) + 1
+    refs = np.arange(n, dtype=np.uint64)
+    af = np.ones(n, np.float32)
+    modulo = 10007
+    idx = CollisionFreeKmerIndex.from_flat_kmers(FlatKmers(hashes, nodes, refs, af), modulo=modulo)
+    orc = oracle.index_build(hashes, nodes, refs, af, modulo=modulo)
+    comp = str.maketrans("ACGTacgt", "TGCAtgca")
+    reads = []
+    for _ in range(150):
+        a = int(rng.integers(0, len(genome) - 200))
+        r = list(genome[a:a + int(rng.integers(1, 200))])
+        for p in rng.integers(0, len(r), size=rng.integers(0, 3)):
+            r[p] = "NnacgtRY"[int(rng.integers(0, 8))]
+        s = "".join(r)
+        reads.append(s.translate(comp)[::-1] if rng.random() < 0.5 else s)
+    reads += ["", "A" * (k - 1), genome[100:100 + k], genome[:130].lower()]
+    for max_hits in (2 ** 62, 3):
+        fwd = np.concatenate([oracle.read_kmers(r, k) for r in reads])
+        rev = np.concatenate([oracle.read_kmers(r.translate(comp)[::-1], k) for r in reads])
+        e_f, h_f = _oracle_node_counts(orc, fwd, n_nodes, max_hits)
+        e_r, h_r = _oracle_node_counts(orc, rev, n_nodes, max_hits)
+        assert h_f > 0 and h_r > 0
+        assert np.array_equal(idx.map_reads(reads, k, n_nodes, max_hits=max_hits, include_reverse_complement=False), e_f)
+        assert np.array_equal(idx.map_reads(reads, k, n_nodes, max_hits=max_hits), e_f + e_r)
+        enc = "".join(reads).encode()
+        start = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
+        c, n_kmers, n_hits = idx._device_index().count_nodes_from_reads(np.frombuffer(enc, np.uint8), start, k, n_nodes,
+                                                                       strands=2, max_hits=max_hits)
+        assert np.array_equal(c.to_host(n_nodes), e_r) and n_kmers == len(rev) and n_hits == h_r
