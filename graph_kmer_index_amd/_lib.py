@@ -168,3 +168,18 @@ class DeviceArray:
             self.free()
         except Exception:
             pass
+
+    def view(self, offset, n):
+        """Non-owning window [offset, offset + n) of this buffer (keeps the parent alive)."""
+        if offset < 0 or n < 0 or offset + n > self.n:
+            raise ValueError("view out of range")
+        return DeviceView(self, int(offset), int(n))
+
+
+class DeviceView(DeviceArray):
+    def __init__(self, parent, offset, n):
+        self.parent, self.dtype, self.n = parent, parent.dtype, n
+        self.ptr = C.c_void_p(parent.ptr.value + offset * parent.dtype.itemsize)
+
+    def free(self):
+        self.ptr = None

@@ -56,15 +56,20 @@ __global__ __launch_bounds__(256) void k_probe_rows(const uint64_t *__restrict__
 }
 
 struct ProbeDev {
-    const uint2 *dir; const uint4 *rows; const uint32_t *nk; uint64_t modulo;
+    const uint2 *dir; const uint4 *rows; const uint32_t *nk; uint64_t modulo, inv;   // inv = floor((2^64 - 1) / modulo)
 };
 
-// CollisionFreeKmerIndex.get for one k-mer, counting instead of returning (:303-315 + map_kmers :210-212).
-// Returns the number of hits counted.
-__device__ __forceinline__ uint32_t probe_one(const ProbeDev &t, uint64_t km, int64_t max_hits,
-                                              unsigned int *__restrict__ counts, int64_t n_counts) {
-    const uint64_t b = km % t.modulo;                                   // :304
-    const uint2 d = t.dir[b];
+// kmer % modulo without the 64-bit division routine: q = mulhi(kmer, inv) is the quotient or one or two short.
+__device__ __forceinline__ uint64_t bucket_of(const ProbeDev &t, uint64_t km) {
+    uint64_t r = km - __umul64hi(km, t.inv) * t.modulo;
+    while (r >= t.modulo) r -= t.modulo;
+    return r;                                                           // collision_free_kmer_index.py:304
+}
+
+// CollisionFreeKmerIndex.get for one k-mer, counting instead of returning (:303-315 + map_kmers :210-212), in two
+// steps so that a lane can have the directory words of several k-mers in flight.  Returns the hits counted.
+__device__ __forceinline__ uint32_t probe_finish(const ProbeDev &t, uint64_t km, uint64_t b, uint2 d, int64_t max_hits,
+                                                 unsigned int *__restrict__ counts, int64_t n_counts) {
     const uint32_t c16 = d.y & 0xFFFFu;
     if (c16 == 0u || ((d.y >> 16) & fp_bit(km)) == 0u) return 0u;
     const int64_t m = c16 == CNT_SAT ? (int64_t)t.nk[b] : (int64_t)c16;
@@ -86,13 +91,29 @@ __device__ __forceinline__ void wave_add(unsigned long long *dst, uint64_t v) {
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, (unsigned long long)v);
 }
 
+constexpr int PROBE_UNROLL = 4;
+
 __global__ __launch_bounds__(256) void k_probe_kmers(ProbeDev t, const uint64_t *__restrict__ queries, int64_t q,
                                                      int64_t max_hits, unsigned int *__restrict__ counts, int64_t n_counts,
                                                      unsigned long long *__restrict__ counters) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     uint64_t hits = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += stride)
-        hits += probe_one(t, queries[i], max_hits, counts, n_counts);
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < q; i0 += stride * PROBE_UNROLL) {
+        uint64_t km[PROBE_UNROLL], b[PROBE_UNROLL];
+        uint2 d[PROBE_UNROLL];
+#pragma unroll
+        for (int u = 0; u < PROBE_UNROLL; u++) {
+            const int64_t i = i0 + u * stride;
+            km[u] = i < q ? queries[i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < PROBE_UNROLL; u++) {
+            b[u] = bucket_of(t, km[u]);
+            d[u] = (i0 + u * stride) < q ? t.dir[b[u]] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < PROBE_UNROLL; u++) hits += probe_finish(t, km[u], b[u], d[u], max_hits, counts, n_counts);
+    }
     wave_add(&counters[0], hits);
 }
 
@@ -124,44 +145,50 @@ __global__ __launch_bounds__(256) void k_probe_reads(ProbeDev t, const uint8_t *
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t kmask = (1ull << k) - 1ull;
     uint64_t hits = 0, probed = 0;
-    for (int64_t r = wave; r < n_reads; r += n_waves) {
-        const int64_t s = read_start[r];
-        const int64_t len = read_start[r + 1] - s;
-        if (len < k) continue;
-        const int64_t n_out = len - k + 1;
-        uint64_t lo_cur = 0, hi_cur = 0, ok_cur = 0;
-        for (int64_t c = 0; c * 64 < len + 64; c++) {
-            const int64_t i = c * 64 + lane;
-            unsigned code = 0;
-            bool acgt = false;
-            if (i < len) {
-                const unsigned ch = reads[s + i] | 0x20u;
-                code = ch == 'c' ? 1u : ch == 'g' ? 2u : ch == 't' ? 3u : 0u;
-                acgt = ch == 'a' || code != 0u;
-            }
-            const uint64_t lo_next = __ballot(code & 1u);
-            const uint64_t hi_next = __ballot(code & 2u);
-            const uint64_t ok_next = __ballot(acgt);
-            if (c > 0) {
+    // Letters are fetched one step ahead (the next 64 letters of this read, or the first 64 of the wave's next read)
+    // so that their latency hides behind the directory loads of the current step.
+    int64_t r = wave, s = 0, len = 0;
+    if (r < n_reads) { s = read_start[r]; len = read_start[r + 1] - s; }
+    unsigned ch_next = lane < len ? reads[s + lane] : 0u;
+    while (r < n_reads) {
+        const int64_t rn = r + n_waves;
+        int64_t sn = 0, lenn = 0;
+        if (rn < n_reads) { sn = read_start[rn]; lenn = read_start[rn + 1] - sn; }
+        if (len < k) {
+            ch_next = lane < lenn ? reads[sn + lane] : 0u;
+        } else {
+            const int64_t n_out = len - k + 1;
+            uint64_t lo_cur = 0, hi_cur = 0, ok_cur = 0;
+            for (int64_t c = 0; c == 0 || (c - 1) * 64 < n_out; c++) {
+                const unsigned ch = ch_next | 0x20u;                     // 0 (past the end) -> ' ': code 0, not ACGT
+                const bool last = c * 64 >= n_out;                       // no further step for this read
+                const int64_t i_next = (c + 1) * 64 + lane;
+                if (last) ch_next = lane < lenn ? reads[sn + lane] : 0u;
+                else ch_next = i_next < len ? reads[s + i_next] : 0u;
+                const unsigned code = ch == 'c' ? 1u : ch == 'g' ? 2u : ch == 't' ? 3u : 0u;
+                const bool acgt = ch == 'a' || code != 0u;
+                const uint64_t lo_next = __ballot(code & 1u);
+                const uint64_t hi_next = __ballot(code & 2u);
+                const uint64_t ok_next = __ballot(acgt);
                 const int64_t j = (c - 1) * 64 + lane;
-                if (j < n_out) {
+                if (c > 0 && j < n_out) {
                     const uint64_t l = funnel(lo_cur, lo_next, lane) & kmask;
                     const uint64_t h = funnel(hi_cur, hi_next, lane) & kmask;
-                    if (strands & 1) {
-                        hits += probe_one(t, spread31(l) | (spread31(h) << 1), max_hits, counts, n_counts);
-                        probed++;
-                    }
-                    if (strands & 2) {
-                        const uint64_t a = funnel(ok_cur, ok_next, lane) & kmask;
-                        const uint64_t rl = __brevll(a & ~l) >> (64 - k);
-                        const uint64_t rh = __brevll(a & ~h) >> (64 - k);
-                        hits += probe_one(t, spread31(rl) | (spread31(rh) << 1), max_hits, counts, n_counts);
-                        probed++;
-                    }
+                    const uint64_t a = funnel(ok_cur, ok_next, lane) & kmask;
+                    const uint64_t fw = spread31(l) | (spread31(h) << 1);
+                    const uint64_t rc = spread31(__brevll(a & ~l) >> (64 - k)) | (spread31(__brevll(a & ~h) >> (64 - k)) << 1);
+                    const uint64_t bf = bucket_of(t, fw), br = bucket_of(t, rc);
+                    const uint2 none = make_uint2(0u, 0u);
+                    const uint2 df = (strands & 1) ? t.dir[bf] : none;          // both directory words in flight
+                    const uint2 dr = (strands & 2) ? t.dir[br] : none;
+                    hits += probe_finish(t, fw, bf, df, max_hits, counts, n_counts);
+                    hits += probe_finish(t, rc, br, dr, max_hits, counts, n_counts);
+                    probed += (strands & 1) + ((strands >> 1) & 1);
                 }
+                lo_cur = lo_next; hi_cur = hi_next; ok_cur = ok_next;
             }
-            lo_cur = lo_next; hi_cur = hi_next; ok_cur = ok_next;
         }
+        r = rn; s = sn; len = lenn;
     }
     wave_add(&counters[0], hits);
     wave_add(&counters[1], probed);
@@ -169,6 +196,7 @@ __global__ __launch_bounds__(256) void k_probe_reads(ProbeDev t, const uint8_t *
 
 static ProbeDev dev_of(const gki_probe *p) {
     ProbeDev d; d.dir = p->dir; d.rows = p->rows; d.nk = p->n_kmers; d.modulo = p->modulo;
+    d.inv = ~0ull / p->modulo;
     return d;
 }
 

@@ -380,3 +380,15 @@ def synthetic_snp_graph(n_ref_bases, n_sites, k=31, seed=1234, max_node_len=3276
     ntro[lin] = np.concatenate([[0], np.cumsum(node_size[lin])[:-1]])
     return GraphArrays(node_size, seq, edge_start, edges, is_ref, af,
                        first_node=0, chromosome_start_nodes=[0], node_to_ref_offset=ntro)
+
+
+def synthetic_haplotype_sequence(graph, seed=99):
+    """Base codes along one random path of a `synthetic_snp_graph`: at every SNP bubble the ref or the alt allele
+    with probability 1/2 (read simulation for the lookup benchmarks)."""
+    alt_nodes = np.flatnonzero(graph.is_ref == 0)
+    alt_slot = graph.seq_start[alt_nodes]                    # the ref allele's base sits right before it
+    rng = np.random.default_rng([seed, 5])
+    drop = alt_slot - rng.integers(0, 2, size=len(alt_slot))
+    keep = np.ones(len(graph.seq), dtype=bool)
+    keep[drop] = False
+    return graph.seq[keep]

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from graph_kmer_index_amd import _lib, DenseKmerFinder, CriticalGraphPaths, DeviceGraph
 from graph_kmer_index_amd.collision_free_kmer_index import DeviceIndex
-from graph_kmer_index_amd.graph import synthetic_snp_graph
+from graph_kmer_index_amd.graph import synthetic_snp_graph, synthetic_haplotype_sequence
 
 
 def main():
@@ -37,11 +37,12 @@ def main():
             idx.free()
     res["index_build_s"] = dt
     res["index_build_records_per_s"] = n / dt
-    # reads: 90 % sampled from the reference sequence, 10 % random, forward strand letters
+    # reads: 90 % sampled from a random path of the graph, 10 % random, forward strand letters
     rng = np.random.default_rng(99)
     n_reads = int(args.reads)
-    starts = rng.integers(0, len(g.seq) - 150, size=n_reads)
-    letters = np.frombuffer(b"ACGT", dtype=np.uint8)[g.seq[(starts[:, None] + np.arange(150)[None, :]).ravel()]].copy()
+    path = synthetic_haplotype_sequence(g)
+    starts = rng.integers(0, len(path) - 150, size=n_reads)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)[path[(starts[:, None] + np.arange(150)[None, :]).ravel()]].copy()
     rnd = rng.random(n_reads) < 0.1
     letters.reshape(n_reads, 150)[rnd] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(int(rnd.sum()), 150))]
     read_start = (np.arange(n_reads + 1, dtype=np.int64) * 150)
