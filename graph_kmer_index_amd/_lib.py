@@ -43,6 +43,7 @@ SYMBOLS = {
     "gki_memset": (_I32, [_P, _I32, _I64]),
     "gki_device_synchronize": (_I32, []),
     "gki_mem_info": (_I32, [C.POINTER(_I64), C.POINTER(_I64)]),
+    "gki_column_checksum": (_I32, [_P, _I64, _I32, C.POINTER(_U64), C.POINTER(_U64)]),
     "gki_hash_sequence": (_I32, [_P, _I64, _I32, _P]),
     "gki_hash_reads": (_I32, [_P, _P, _I64, _I32, _I32, _P, _P, _I64, C.POINTER(_I64)]),
     "gki_reverse_complement": (_I32, [_P, _I64, _I32, _P]),
@@ -168,6 +169,12 @@ class DeviceArray:
             self.free()
         except Exception:
             pass
+
+    def checksum(self, n=None):
+        """(sum mod 2^64, xor) of the first n elements, computed on the device."""
+        s, x = _U64(0), _U64(0)
+        check(load().gki_column_checksum(self.ptr, self.n if n is None else int(n), self.dtype.itemsize, C.byref(s), C.byref(x)))
+        return s.value, x.value
 
     def view(self, offset, n):
         """Non-owning window [offset, offset + n) of this buffer (keeps the parent alive)."""

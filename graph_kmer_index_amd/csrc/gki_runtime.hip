@@ -12,6 +12,19 @@ int gki_set_error(int code, const char *fmt, ...) {
     return code;
 }
 
+namespace {
+// order-independent checksums of a column: sum mod 2^64 and xor of the zero-extended elements
+template <typename T>
+__global__ __launch_bounds__(256) void k_checksum(const T *__restrict__ v, int64_t n, unsigned long long *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint64_t s = 0, x = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { const uint64_t e = v[i]; s += e; x ^= e; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { s += __shfl_down(s, d, 64); x ^= __shfl_down(x, d, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], (unsigned long long)s); atomicXor(&out[1], (unsigned long long)x); }
+}
+}  // namespace
+
 extern "C" {
 
 const char *gki_last_error(void) { return gki_err_buf; }
@@ -57,6 +70,28 @@ int gki_mem_info(int64_t *free_bytes, int64_t *total_bytes) {
     size_t f = 0, t = 0;
     HIP_TRY(hipMemGetInfo(&f, &t));
     *free_bytes = (int64_t)f; *total_bytes = (int64_t)t;
+    return GKI_OK;
+}
+
+int gki_column_checksum(const void *d_column, int64_t n, int elem_bytes, uint64_t *sum, uint64_t *xor_fold) {
+    *sum = 0; *xor_fold = 0;
+    if (elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8) return gki_set_error(GKI_ERR_BAD_ARG, "elem_bytes must be 2, 4 or 8");
+    if (n <= 0) return GKI_OK;
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 16));
+    hipError_t e = hipMemsetAsync(d, 0, 16, 0);
+    if (e == hipSuccess) {
+        const dim3 grid(stream_grid(n, 256)), block(256);
+        if (elem_bytes == 8) hipLaunchKernelGGL(k_checksum<uint64_t>, grid, block, 0, 0, (const uint64_t *)d_column, n, d);
+        else if (elem_bytes == 4) hipLaunchKernelGGL(k_checksum<uint32_t>, grid, block, 0, 0, (const uint32_t *)d_column, n, d);
+        else hipLaunchKernelGGL(k_checksum<uint16_t>, grid, block, 0, 0, (const uint16_t *)d_column, n, d);
+        e = hipGetLastError();
+    }
+    unsigned long long h[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    HIP_TRY(e);
+    *sum = h[0]; *xor_fold = h[1];
     return GKI_OK;
 }
 

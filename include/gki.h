@@ -46,6 +46,9 @@ int gki_memset(void *d_dst, int value, int64_t bytes);
 int gki_device_synchronize(void);
 /* bytes free / total on the current device */
 int gki_mem_info(int64_t *free_bytes, int64_t *total_bytes);
+/* Order-independent checksums of a device column of n elements of 2, 4 or 8 bytes (zero-extended): sum mod 2^64 and
+ * xor.  Lets a caller check that two layouts / a set of shards hold the same multiset without copying it back. */
+int gki_column_checksum(const void *d_column, int64_t n, int elem_bytes, uint64_t *sum, uint64_t *xor_fold);
 
 /* ---------------------------------------------------------------- hashing (A1, A8, A10)
  * hash = sum_i base[i] * 4^i, first base least significant, a/n/m=0 c=1 g=2 t=3
