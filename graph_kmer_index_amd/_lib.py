@@ -27,7 +27,8 @@ class FindParams(C.Structure):
 class IndexView(C.Structure):
     _fields_ = [("d_hashes_to_index", C.c_void_p), ("d_n_kmers", C.c_void_p), ("d_kmers", C.c_void_p),
                 ("d_nodes", C.c_void_p), ("d_ref_offsets", C.c_void_p), ("d_frequencies", C.c_void_p),
-                ("d_af32", C.c_void_p), ("modulo", C.c_uint64), ("n", C.c_int64)]
+                ("d_af32", C.c_void_p), ("modulo", C.c_uint64), ("n", C.c_int64),
+                ("bucket_begin", C.c_uint64), ("n_buckets", C.c_uint64)]
 
 
 # every symbol include/gki.h declares: name -> (restype, argtypes)
@@ -40,6 +41,7 @@ SYMBOLS = {
     "gki_free": (_I32, [_P]),
     "gki_memcpy_h2d": (_I32, [_P, _P, _I64]),
     "gki_memcpy_d2h": (_I32, [_P, _P, _I64]),
+    "gki_memcpy_d2d": (_I32, [_P, _P, _I64]),
     "gki_memset": (_I32, [_P, _I32, _I64]),
     "gki_device_synchronize": (_I32, []),
     "gki_mem_info": (_I32, [C.POINTER(_I64), C.POINTER(_I64)]),
@@ -65,6 +67,8 @@ SYMBOLS = {
     "gki_forward_count": (_I32, [_P, _I32, _I32, _I32, _P, _P, _P, _I64, _P, C.POINTER(_I64)]),
     "gki_forward_emit": (_I32, [_P, _I32, _I32, _I32, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P]),
     "gki_index_build": (_I32, [_P, _P, _P, _P, _I64, _U64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gki_partition_by_bucket_range": (_I32, [_P, _P, _P, _P, _I64, _U64, _I32, _P, _P, _P, _P, C.POINTER(_I64)]),
+    "gki_index_build_range": (_I32, [_P, _P, _P, _P, _I64, _U64, _U64, _U64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gki_reverse_index_build": (_I32, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
     "gki_index_lookup_count": (_I32, [C.POINTER(IndexView), _P, _I64, _I64, _P, C.POINTER(_I64)]),
     "gki_index_count_nodes": (_I32, [C.POINTER(IndexView), _P, _I64, _I64, _P, _I64]),
@@ -76,6 +80,8 @@ SYMBOLS = {
     "gki_comm_get_unique_id": (_I32, [_P]),
     "gki_comm_create": (_I32, [C.POINTER(_P), _I32, _I32, _P]),
     "gki_comm_destroy": (_I32, [_P]),
+    "gki_comm_alltoall_flat": (_I32, [_P, C.POINTER(_I64), _P, _P, _P, _P, C.POINTER(_I64), _P, _P, _P, _P]),
+    "gki_comm_allreduce_u32": (_I32, [_P, _P, _I64]),
     "gki_comm_allgather_flat": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 

@@ -18,8 +18,11 @@ from .kmer_hashing import kmer_hash_to_reverse_complement_hash
 class DeviceIndex:
     """The seven index arrays resident in HBM."""
 
-    def __init__(self, n, modulo, hashes_to_index, n_kmers, kmers, nodes, ref_offsets, af, frequencies):
+    def __init__(self, n, modulo, hashes_to_index, n_kmers, kmers, nodes, ref_offsets, af, frequencies,
+                 bucket_begin=0, n_buckets=None):
         self.n, self.modulo = int(n), int(modulo)
+        # a bucket-range slice of a partitioned index holds the buckets [bucket_begin, bucket_begin + n_buckets) only
+        self.bucket_begin, self.n_buckets = int(bucket_begin), int(modulo if n_buckets is None else n_buckets)
         self.permutation = None
         self._probe = None
         self.hashes_to_index, self.n_kmers, self.kmers, self.nodes = hashes_to_index, n_kmers, kmers, nodes
@@ -28,23 +31,26 @@ class DeviceIndex:
     def view(self):
         return _lib.IndexView(self.hashes_to_index.ptr, self.n_kmers.ptr, self.kmers.ptr, self.nodes.ptr,
                               self.ref_offsets.ptr, self.frequencies.ptr, self.allele_frequencies.ptr,
-                              self.modulo, self.n)
+                              self.modulo, self.n, self.bucket_begin, self.n_buckets)
 
     @classmethod
-    def build(cls, dflat, modulo=452930477, skip_frequencies=False, want_permutation=False):
-        """gki_index_build on device-resident FlatKmers columns."""
+    def build(cls, dflat, modulo=452930477, skip_frequencies=False, want_permutation=False, bucket_begin=0, n_buckets=None):
+        """gki_index_build(_range) on device-resident FlatKmers columns.  With a bucket range, `dflat` must hold only
+        records of that range (one slice of `partition_by_bucket_range`)."""
         _lib.require_device()
         n = dflat.n
         na = max(n, 1)
-        out = cls(n, modulo, _lib.DeviceArray(modulo, np.int32), _lib.DeviceArray(modulo, np.uint32),
+        nb = int(modulo if n_buckets is None else n_buckets)
+        out = cls(n, modulo, _lib.DeviceArray(nb, np.int32), _lib.DeviceArray(nb, np.uint32),
                   _lib.DeviceArray(na, np.uint64), _lib.DeviceArray(na, np.uint32), _lib.DeviceArray(na, np.uint64),
-                  _lib.DeviceArray(na, np.float32), _lib.DeviceArray(na, np.uint16))
+                  _lib.DeviceArray(na, np.float32), _lib.DeviceArray(na, np.uint16), bucket_begin, nb)
         perm = _lib.DeviceArray(na, np.uint32) if want_permutation else None
         out.permutation = perm
-        _lib.check(_lib.load().gki_index_build(
+        _lib.check(_lib.load().gki_index_build_range(
             dflat.hashes.ptr, dflat.nodes.ptr, dflat.ref_offsets.ptr, dflat.allele_frequencies.ptr, n, int(modulo),
-            int(bool(skip_frequencies)), out.hashes_to_index.ptr, out.n_kmers.ptr, out.kmers.ptr, out.nodes.ptr,
-            out.ref_offsets.ptr, out.allele_frequencies.ptr, out.frequencies.ptr, None if perm is None else perm.ptr))
+            int(bucket_begin), nb, int(bool(skip_frequencies)), out.hashes_to_index.ptr, out.n_kmers.ptr, out.kmers.ptr,
+            out.nodes.ptr, out.ref_offsets.ptr, out.allele_frequencies.ptr, out.frequencies.ptr,
+            None if perm is None else perm.ptr))
         return out
 
     def lookup_positions(self, queries, max_hits=10):
@@ -144,6 +150,72 @@ class DeviceIndex:
         for a in (self.hashes_to_index, self.n_kmers, self.kmers, self.nodes, self.ref_offsets,
                   self.allele_frequencies, self.frequencies):
             a.free()
+
+
+def bucket_range(modulo, n_parts, part):
+    """Buckets [begin, end) owned by `part` (gki_partition_by_bucket_range)."""
+    return modulo * part // n_parts, modulo * (part + 1) // n_parts
+
+
+def partition_by_bucket_range(dflat, modulo, n_parts):
+    """Stable partition of device FlatKmers columns by owning part.  Returns (DeviceFlatKmers, part_start[n_parts+1])."""
+    _lib.require_device()
+    out = DeviceFlatKmers.allocate(dflat.n)
+    start = (C.c_int64 * (n_parts + 1))()
+    _lib.check(_lib.load().gki_partition_by_bucket_range(
+        dflat.hashes.ptr, dflat.nodes.ptr, dflat.ref_offsets.ptr, dflat.allele_frequencies.ptr, dflat.n, int(modulo),
+        int(n_parts), out.hashes.ptr, out.nodes.ptr, out.ref_offsets.ptr, out.allele_frequencies.ptr, start))
+    return out, [int(x) for x in start]
+
+
+class PartitionedDeviceIndex:
+    """A CollisionFreeKmerIndex cut into bucket-range slices, each a DeviceIndex with its own directory slice
+    (SURVEY.md 8f-1).  On one GPU the slices sit side by side (no 2^31 limit on the total); across GPUs each rank
+    keeps one slice (`parallel.build_index_partitioned`).  A k-mer outside a slice's range misses there without a
+    memory access, so counting over all slices equals counting on the monolithic index."""
+
+    def __init__(self, modulo, parts):
+        self.modulo, self.parts = int(modulo), list(parts)
+
+    @property
+    def n(self):
+        return sum(p.n for p in self.parts)
+
+    @classmethod
+    def build(cls, dflat, modulo=452930477, n_parts=8, skip_frequencies=False):
+        part, start = partition_by_bucket_range(dflat, modulo, n_parts)
+        parts = []
+        for p in range(n_parts):
+            lo, hi = bucket_range(modulo, n_parts, p)
+            a, b = start[p], start[p + 1]
+            sl = DeviceFlatKmers(b - a, part.hashes.view(a, b - a), part.nodes.view(a, b - a),
+                                 part.ref_offsets.view(a, b - a), part.allele_frequencies.view(a, b - a))
+            parts.append(DeviceIndex.build(sl, modulo, skip_frequencies, bucket_begin=lo, n_buckets=hi - lo))
+        part.free()
+        return cls(modulo, parts)
+
+    def count_nodes(self, queries, n_nodes, max_hits=10, counts=None):
+        own = not isinstance(queries, _lib.DeviceArray)
+        dq = _lib.DeviceArray.from_host(np.ascontiguousarray(np.asarray(queries)).astype(np.uint64)) if own else queries
+        for p in self.parts:
+            counts = p.count_nodes(dq, n_nodes, max_hits, counts)
+        if own:
+            dq.free()
+        return counts
+
+    def count_nodes_from_reads(self, letters, read_start, k, n_nodes, strands=3, max_hits=10, counts=None):
+        dl = letters if isinstance(letters, _lib.DeviceArray) else _lib.DeviceArray.from_host(np.ascontiguousarray(letters, np.uint8))
+        ds = read_start if isinstance(read_start, _lib.DeviceArray) else \
+            _lib.DeviceArray.from_host(np.ascontiguousarray(read_start, np.int64))
+        n_kmers = hits = 0
+        for p in self.parts:
+            counts, n_kmers, h = p.count_nodes_from_reads(dl, ds, k, n_nodes, strands, max_hits, counts)
+            hits += h
+        return counts, n_kmers, hits
+
+    def free(self):
+        for p in self.parts:
+            p.free()
 
 
 class CollisionFreeKmerIndex:

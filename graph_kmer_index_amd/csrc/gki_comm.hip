@@ -26,6 +26,7 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -42,7 +43,7 @@ int load_rccl() {
     if (!g_rccl.field) return gki_set_error(GKI_ERR_HIP, "librccl.so lacks %s", name);
     SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
     SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd")
-    SYM(GetErrorString, "ncclGetErrorString")
+    SYM(GetErrorString, "ncclGetErrorString") SYM(AllReduce, "ncclAllReduce")
 #undef SYM
     g_rccl.h = h;
     return GKI_OK;
@@ -120,6 +121,53 @@ int gki_comm_allgather_flat(gki_comm *c, const int64_t *h_counts, const void *d_
         NCCL_TRY(g_rccl.GroupEnd());
     }
     HIP_TRY(hipStreamSynchronize(s));
+    return GKI_OK;
+}
+
+int gki_comm_alltoall_flat(gki_comm *c, const int64_t *h_send_start, const void *d_hashes, const void *d_nodes,
+                           const void *d_ref_offsets, const void *d_af32, const int64_t *h_recv_start, void *d_out_hashes,
+                           void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32) {
+    const int W = c->world, me = c->rank;
+    for (int r = 0; r < W; r++)
+        if (h_send_start[r + 1] < h_send_start[r] || h_recv_start[r + 1] < h_recv_start[r])
+            return gki_set_error(GKI_ERR_BAD_ARG, "alltoall: slice tables must be non-decreasing");
+    if (h_send_start[me + 1] - h_send_start[me] != h_recv_start[me + 1] - h_recv_start[me])
+        return gki_set_error(GKI_ERR_BAD_ARG, "alltoall: own slice differs between the send and receive tables");
+    const void *in[4] = {d_hashes, d_nodes, d_ref_offsets, d_af32};
+    void *outp[4] = {d_out_hashes, d_out_nodes, d_out_ref_offsets, d_out_af32};
+    const size_t esz[4] = {8, 4, 8, 4};
+    hipStream_t s = c->stream;
+    const int64_t own = h_send_start[me + 1] - h_send_start[me];
+    for (int col = 0; col < 4; col++)
+        if (own > 0)
+            HIP_TRY(hipMemcpyAsync((char *)outp[col] + (size_t)h_recv_start[me] * esz[col],
+                                   (const char *)in[col] + (size_t)h_send_start[me] * esz[col], (size_t)own * esz[col],
+                                   hipMemcpyDeviceToDevice, s));
+    if (W > 1) {
+        // one point-to-point pair per peer and column; xGMI is fully connected, so all pairs move at once
+        NCCL_TRY(g_rccl.GroupStart());
+        for (int col = 0; col < 4; col++)
+            for (int r = 0; r < W; r++) {
+                if (r == me) continue;
+                const int64_t ns = h_send_start[r + 1] - h_send_start[r], nr = h_recv_start[r + 1] - h_recv_start[r];
+                if (ns > 0)
+                    NCCL_TRY(g_rccl.Send((const char *)in[col] + (size_t)h_send_start[r] * esz[col], (size_t)ns * esz[col], ncclUint8,
+                                         r, c->comm, s));
+                if (nr > 0)
+                    NCCL_TRY(g_rccl.Recv((char *)outp[col] + (size_t)h_recv_start[r] * esz[col], (size_t)nr * esz[col], ncclUint8, r,
+                                         c->comm, s));
+            }
+        NCCL_TRY(g_rccl.GroupEnd());
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return GKI_OK;
+}
+
+int gki_comm_allreduce_u32(gki_comm *c, void *d_buf, int64_t n) {
+    if (n <= 0) return GKI_OK;
+    HIP_TRY(hipDeviceSynchronize());                  // the counts were produced on other streams
+    if (c->world > 1) NCCL_TRY(g_rccl.AllReduce(d_buf, d_buf, (size_t)n, ncclUint32, ncclSum, c->comm, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return GKI_OK;
 }
 

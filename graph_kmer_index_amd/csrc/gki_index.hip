@@ -20,10 +20,30 @@ constexpr int RTILE = RB * RI;      // 4096 items per tile
 constexpr int RBINS = 256;
 
 __global__ __launch_bounds__(256) void k_bucket_keys(const uint64_t *__restrict__ kmers, int64_t n, uint64_t modulo,
-                                                     uint32_t *__restrict__ keys, uint32_t *__restrict__ idx) {
+                                                     uint64_t bucket_begin, uint64_t n_buckets,
+                                                     uint32_t *__restrict__ keys, uint32_t *__restrict__ idx,
+                                                     int *__restrict__ out_of_range) {
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        keys[i] = (uint32_t)(kmers[i] % modulo);       // collision_free_kmer_index.py:433
+        const uint64_t b = kmers[i] % modulo - bucket_begin;       // collision_free_kmer_index.py:433
+        if (b >= n_buckets) *out_of_range = 1;
+        keys[i] = b < n_buckets ? (uint32_t)b : 0u;
+        idx[i] = (uint32_t)i;
+    }
+}
+
+// bucket-range partition: part p owns the buckets [modulo*p/n_parts, modulo*(p+1)/n_parts)
+__device__ __host__ inline uint64_t part_begin(uint64_t modulo, int n_parts, int p) { return modulo * (uint64_t)p / (uint64_t)n_parts; }
+
+__global__ __launch_bounds__(256) void k_part_keys(const uint64_t *__restrict__ kmers, int64_t n, uint64_t modulo, int n_parts,
+                                                   uint32_t *__restrict__ keys, uint32_t *__restrict__ idx) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t b = kmers[i] % modulo;
+        int p = (int)(b * (uint64_t)n_parts / modulo);
+        while (p + 1 < n_parts && part_begin(modulo, n_parts, p + 1) <= b) p++;
+        while (p > 0 && part_begin(modulo, n_parts, p) > b) p--;
+        keys[i] = (uint32_t)p;
         idx[i] = (uint32_t)i;
     }
 }
@@ -164,16 +184,26 @@ __global__ __launch_bounds__(256) void k_gather_rows(const uint32_t *__restrict_
     }
 }
 
-// bucket heads -> directory (collision_free_kmer_index.py:444-457).  A head lane walks to the end of
-// its run; runs are short except for highly repeated k-mers.
+// end of the run of equal keys starting at i (keys sorted): a short walk, then a binary search -- a k-mer repeated
+// millions of times must not cost one lane millions of dependent loads
+__device__ __forceinline__ int64_t run_end(const uint32_t *__restrict__ keys, int64_t n, int64_t i, uint32_t b) {
+    int64_t e = i + 1;
+    const int64_t walk_to = i + 16 < n ? i + 16 : n;
+    while (e < walk_to && keys[e] == b) e++;
+    if (e < walk_to || e == n) return e;
+    int64_t lo = e, hi = n;                       // keys[lo-1] == b; first position with a larger key
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (keys[mid] == b) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// bucket heads -> directory (collision_free_kmer_index.py:444-457).  A head lane finds the end of its run.
 __global__ __launch_bounds__(256) void k_directory(const uint32_t *__restrict__ keys, int64_t n,
                                                    int32_t *__restrict__ hashes_to_index, uint32_t *__restrict__ n_kmers) {
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint32_t b = keys[i];
         if (i > 0 && keys[i - 1] == b) continue;
-        int64_t e = i + 1;
-        while (e < n && keys[e] == b) e++;
+        const int64_t e = run_end(keys, n, i, b);
         hashes_to_index[b] = (int32_t)i;
         n_kmers[b] = (uint32_t)(e - i);
     }
@@ -280,7 +310,7 @@ __global__ __launch_bounds__(256) void k_large_sizes(const uint32_t *__restrict_
 // ------------------------------------------------------------------------------------ probe
 struct IndexDev {
     const int32_t *h2i; const uint32_t *nk; const uint64_t *kmers; const uint32_t *nodes; const uint64_t *refs;
-    const uint16_t *freq; const float *af; uint64_t modulo;
+    const uint16_t *freq; const float *af; uint64_t modulo, bucket_begin, n_buckets;
 };
 
 // CollisionFreeKmerIndex.get (collision_free_kmer_index.py:303-315) for one query per lane.
@@ -293,9 +323,10 @@ __global__ __launch_bounds__(256) void k_lookup(IndexDev ix, const uint64_t *__r
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += stride) {
         const uint64_t km = queries[i];
-        const uint64_t b = km % ix.modulo;                            // :304
-        const int64_t s = ix.h2i[b];                                  // :305
-        const int64_t m = ix.nk[b];                                   // :306
+        const uint64_t b = km % ix.modulo - ix.bucket_begin;          // :304 (slice-relative)
+        const bool mine = b < ix.n_buckets;
+        const int64_t s = mine ? ix.h2i[b] : 0;                       // :305
+        const int64_t m = mine ? ix.nk[b] : 0;                        // :306
         if (!EMIT) {
             uint32_t c = 0;
             bool first = true, too_frequent = false;
@@ -329,7 +360,8 @@ __global__ __launch_bounds__(256) void k_count_nodes(IndexDev ix, const uint64_t
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += stride) {
         const uint64_t km = queries[i];
-        const uint64_t b = km % ix.modulo;
+        const uint64_t b = km % ix.modulo - ix.bucket_begin;
+        if (b >= ix.n_buckets) continue;
         const int64_t s = ix.h2i[b];
         const int64_t m = ix.nk[b];
         bool first = true;
@@ -369,6 +401,15 @@ static int radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], int64_t n, int
     return GKI_OK;
 }
 
+// first position of every part in the sorted part ids (lower bound); start[n_parts] = n
+__global__ void k_part_starts(const uint32_t *__restrict__ keys, int64_t n, int n_parts, int64_t *__restrict__ start) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > n_parts) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (keys[mid] < (uint32_t)p) lo = mid + 1; else hi = mid; }
+    start[p] = lo;
+}
+
 // ------------------------------------------------------------------------------------ reverse index
 // ReverseKmerIndex.from_flat_kmers (reverse_kmer_index.py:47-60): records stably sorted by node,
 // nodes_to_index_positions[node] = first record (uint32), nodes_to_n_hashes[node] = run length (uint16, wraps
@@ -385,8 +426,7 @@ __global__ __launch_bounds__(256) void k_node_directory(const uint32_t *__restri
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint32_t b = keys[i];
         if (i > 0 && keys[i - 1] == b) continue;
-        int64_t e = i + 1;
-        while (e < n && keys[e] == b) e++;
+        const int64_t e = run_end(keys, n, i, b);
         first[b] = (uint32_t)i;
         count[b] = (uint16_t)(e - i);
     }
@@ -415,17 +455,20 @@ __global__ __launch_bounds__(256) void k_gather_pairs(const uint32_t *__restrict
 
 extern "C" {
 
-int gki_index_build(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
-                    uint64_t modulo, int skip_frequencies, void *d_hashes_to_index, void *d_n_kmers, void *d_out_kmers,
-                    void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32, void *d_out_frequencies,
-                    void *d_out_permutation) {
+int gki_index_build_range(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
+                          uint64_t modulo, uint64_t bucket_begin, uint64_t n_buckets, int skip_frequencies,
+                          void *d_hashes_to_index, void *d_n_kmers, void *d_out_kmers, void *d_out_nodes,
+                          void *d_out_ref_offsets, void *d_out_af32, void *d_out_frequencies, void *d_out_permutation) {
     if (modulo == 0 || modulo > 0xFFFFFFFFull) return gki_set_error(GKI_ERR_BAD_ARG, "modulo must be in 1..2^32-1");
+    if (n_buckets == 0 || bucket_begin + n_buckets > modulo)
+        return gki_set_error(GKI_ERR_BAD_ARG, "bucket range [%llu, +%llu) outside [0, modulo)", (unsigned long long)bucket_begin,
+                             (unsigned long long)n_buckets);
     if (n >= (1ll << 31))
         return gki_set_error(GKI_ERR_OVERFLOW, "%lld records: the reference's directory is int32 "
                              "(collision_free_kmer_index.py:453); shard the build", (long long)n);
     hipStream_t s = 0;
-    HIP_TRY(hipMemsetAsync(d_hashes_to_index, 0, (size_t)modulo * 4, s));          // :453
-    HIP_TRY(hipMemsetAsync(d_n_kmers, 0, (size_t)modulo * 4, s));                  // :456
+    HIP_TRY(hipMemsetAsync(d_hashes_to_index, 0, (size_t)n_buckets * 4, s));       // :453
+    HIP_TRY(hipMemsetAsync(d_n_kmers, 0, (size_t)n_buckets * 4, s));               // :456
     if (n <= 0) { HIP_TRY(hipStreamSynchronize(s)); return GKI_OK; }
     HIP_TRY(hipMemsetAsync(d_out_frequencies, 0, (size_t)n * 2, s));               // :270
     const int64_t n_tiles = ceil_div(n, RTILE);
@@ -445,12 +488,21 @@ int gki_index_build(const void *d_kmers, const void *d_nodes, const void *d_ref_
         HIP_G(hipMalloc((void **)&hist, (size_t)hist_n * 4));
         HIP_G(hipMalloc((void **)&offs, (size_t)(hist_n + 1) * 4));
         HIP_G(hipMalloc(&tmp, (size_t)tmp_bytes));
+        int *bad = (int *)hist;                       // hist is not in use yet
+        HIP_G(hipMemsetAsync(bad, 0, 4, s));
         hipLaunchKernelGGL(k_bucket_keys, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const uint64_t *)d_kmers, n, modulo,
-                           keys[0], vals[0]);
+                           bucket_begin, n_buckets, keys[0], vals[0], bad);
         HIP_G(hipGetLastError());
+        if (n_buckets != modulo) {
+            int h_bad = 0;
+            HIP_G(hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, s));
+            HIP_G(hipStreamSynchronize(s));
+            if (h_bad) CLEANUP_RETURN(gki_set_error(GKI_ERR_BAD_ARG, "a record's bucket lies outside [%llu, +%llu)",
+                                                    (unsigned long long)bucket_begin, (unsigned long long)n_buckets));
+        }
         int cur = 0;
         {
-            int r = radix_sort_pairs(keys, vals, n, key_bits(modulo - 1), hist, offs, tmp, tmp_bytes, s, &cur);
+            int r = radix_sort_pairs(keys, vals, n, key_bits(n_buckets - 1), hist, offs, tmp, tmp_bytes, s, &cur);
             if (r != GKI_OK) CLEANUP_RETURN(r);
         }
         HIP_G(hipMalloc((void **)&rows, (size_t)n * 32));
@@ -513,6 +565,66 @@ done:
     return rc;
 }
 
+int gki_index_build(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
+                    uint64_t modulo, int skip_frequencies, void *d_hashes_to_index, void *d_n_kmers, void *d_out_kmers,
+                    void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32, void *d_out_frequencies,
+                    void *d_out_permutation) {
+    return gki_index_build_range(d_kmers, d_nodes, d_ref_offsets, d_af32, n, modulo, 0, modulo, skip_frequencies,
+                                 d_hashes_to_index, d_n_kmers, d_out_kmers, d_out_nodes, d_out_ref_offsets, d_out_af32,
+                                 d_out_frequencies, d_out_permutation);
+}
+
+int gki_partition_by_bucket_range(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32,
+                                  int64_t n, uint64_t modulo, int n_parts, void *d_out_kmers, void *d_out_nodes,
+                                  void *d_out_ref_offsets, void *d_out_af32, int64_t *h_part_start) {
+    if (modulo == 0 || modulo > 0xFFFFFFFFull) return gki_set_error(GKI_ERR_BAD_ARG, "modulo must be in 1..2^32-1");
+    if (n_parts < 1 || n_parts > 256) return gki_set_error(GKI_ERR_BAD_ARG, "n_parts must be in 1..256");
+    if (n >= (1ll << 31)) return gki_set_error(GKI_ERR_OVERFLOW, "%lld records: partition at most 2^31-1 at a time", (long long)n);
+    for (int p = 0; p <= n_parts; p++) h_part_start[p] = 0;
+    if (n <= 0) return GKI_OK;
+    hipStream_t s = 0;
+    const int64_t hist_n = (int64_t)RBINS * ceil_div(n, RTILE);
+    const int64_t tmp_bytes = gki_scan_tmp_bytes(hist_n);
+    uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *hist = nullptr, *offs = nullptr;
+    int64_t *pstart = nullptr;
+    uint4 *rows = nullptr;
+    void *tmp = nullptr;
+    int rc = GKI_OK;
+#define HIP_G(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = gki_set_error(GKI_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); goto done; } } while (0)
+    {
+        for (int i = 0; i < 2; i++) {
+            HIP_G(hipMalloc((void **)&keys[i], (size_t)n * 4));
+            HIP_G(hipMalloc((void **)&vals[i], (size_t)n * 4));
+        }
+        HIP_G(hipMalloc((void **)&hist, (size_t)hist_n * 4));
+        HIP_G(hipMalloc((void **)&offs, (size_t)(hist_n + 1) * 4));
+        HIP_G(hipMalloc(&tmp, (size_t)tmp_bytes));
+        HIP_G(hipMalloc((void **)&rows, (size_t)n * 32));
+        HIP_G(hipMalloc((void **)&pstart, 257 * 8));
+        hipLaunchKernelGGL(k_part_keys, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const uint64_t *)d_kmers, n, modulo, n_parts,
+                           keys[0], vals[0]);
+        HIP_G(hipGetLastError());
+        int cur = 0;
+        rc = radix_sort_pairs(keys, vals, n, key_bits((uint64_t)n_parts - 1), hist, offs, tmp, tmp_bytes, s, &cur);
+        if (rc != GKI_OK) goto done;
+        hipLaunchKernelGGL(k_pack_rows, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const uint64_t *)d_kmers,
+                           (const uint32_t *)d_nodes, (const uint64_t *)d_ref_offsets, (const float *)d_af32, n, rows);
+        HIP_G(hipGetLastError());
+        hipLaunchKernelGGL(k_gather_rows, dim3(stream_grid(n, 256)), dim3(256), 0, s, vals[cur], n, (const uint4 *)rows,
+                           (uint64_t *)d_out_kmers, (uint32_t *)d_out_nodes, (uint64_t *)d_out_ref_offsets, (float *)d_out_af32);
+        HIP_G(hipGetLastError());
+        hipLaunchKernelGGL(k_part_starts, dim3(2), dim3(256), 0, s, keys[cur], n, n_parts, pstart);
+        HIP_G(hipGetLastError());
+        HIP_G(hipMemcpyAsync(h_part_start, pstart, (size_t)(n_parts + 1) * 8, hipMemcpyDeviceToHost, s));
+        HIP_G(hipStreamSynchronize(s));
+    }
+done:
+    for (int i = 0; i < 2; i++) { (void)hipFree(keys[i]); (void)hipFree(vals[i]); }
+    (void)hipFree(hist); (void)hipFree(offs); (void)hipFree(tmp); (void)hipFree(rows); (void)hipFree(pstart);
+#undef HIP_G
+    return rc;
+}
+
 int gki_reverse_index_build(const void *d_nodes, const void *d_kmers, const void *d_ref_offsets, int64_t n, int64_t n_nodes,
                             void *d_index_positions, void *d_n_hashes, void *d_out_kmers, void *d_out_ref_offsets) {
     if (n_nodes <= 0 || n_nodes > (1ll << 32)) return gki_set_error(GKI_ERR_BAD_ARG, "n_nodes must be in 1..2^32");
@@ -566,6 +678,7 @@ static IndexDev view_of(const gki_index_view *ix) {
     d.kmers = (const uint64_t *)ix->d_kmers; d.nodes = (const uint32_t *)ix->d_nodes;
     d.refs = (const uint64_t *)ix->d_ref_offsets; d.freq = (const uint16_t *)ix->d_frequencies;
     d.af = (const float *)ix->d_af32; d.modulo = ix->modulo;
+    d.bucket_begin = ix->n_buckets ? ix->bucket_begin : 0; d.n_buckets = ix->n_buckets ? ix->n_buckets : ix->modulo;
     return d;
 }
 

@@ -18,7 +18,7 @@ struct gki_probe {
     uint4 *rows = nullptr;           // [n]
     const uint32_t *n_kmers = nullptr;   // the index's own array (borrowed): exact length of saturated buckets
     unsigned long long *counters = nullptr;   // [2] device: hits, k-mers probed
-    uint64_t modulo = 0;
+    uint64_t modulo = 0, bucket_begin = 0, n_buckets = 0;
     int64_t n = 0;
 };
 
@@ -33,10 +33,10 @@ __device__ __forceinline__ uint32_t fp_bit(uint64_t kmer) {
 }
 
 __global__ __launch_bounds__(256) void k_probe_dir(const int32_t *__restrict__ h2i, const uint32_t *__restrict__ nk,
-                                                   const uint64_t *__restrict__ kmers, uint64_t modulo,
+                                                   const uint64_t *__restrict__ kmers, uint64_t n_buckets,
                                                    uint2 *__restrict__ dir) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < (int64_t)modulo; b += stride) {
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < (int64_t)n_buckets; b += stride) {
         const uint32_t m = nk[b];
         const uint32_t s = (uint32_t)h2i[b];
         uint32_t fp = 0;
@@ -57,13 +57,15 @@ __global__ __launch_bounds__(256) void k_probe_rows(const uint64_t *__restrict__
 
 struct ProbeDev {
     const uint2 *dir; const uint4 *rows; const uint32_t *nk; uint64_t modulo, inv;   // inv = floor((2^64 - 1) / modulo)
+    uint64_t bucket_begin, n_buckets;      // the directory holds this slice of the buckets only
 };
 
 // kmer % modulo without the 64-bit division routine: q = mulhi(kmer, inv) is the quotient or one or two short.
+// Returns the bucket relative to the slice; >= n_buckets means the k-mer belongs to another slice (a miss here).
 __device__ __forceinline__ uint64_t bucket_of(const ProbeDev &t, uint64_t km) {
     uint64_t r = km - __umul64hi(km, t.inv) * t.modulo;
     while (r >= t.modulo) r -= t.modulo;
-    return r;                                                           // collision_free_kmer_index.py:304
+    return r - t.bucket_begin;                                          // collision_free_kmer_index.py:304
 }
 
 // CollisionFreeKmerIndex.get for one k-mer, counting instead of returning (:303-315 + map_kmers :210-212), in two
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void k_probe_kmers(ProbeDev t, const uint64_t 
 #pragma unroll
         for (int u = 0; u < PROBE_UNROLL; u++) {
             b[u] = bucket_of(t, km[u]);
-            d[u] = (i0 + u * stride) < q ? t.dir[b[u]] : make_uint2(0u, 0u);
+            d[u] = ((i0 + u * stride) < q && b[u] < t.n_buckets) ? t.dir[b[u]] : make_uint2(0u, 0u);
         }
 #pragma unroll
         for (int u = 0; u < PROBE_UNROLL; u++) hits += probe_finish(t, km[u], b[u], d[u], max_hits, counts, n_counts);
@@ -179,8 +181,8 @@ __global__ __launch_bounds__(256) void k_probe_reads(ProbeDev t, const uint8_t *
                     const uint64_t rc = spread31(__brevll(a & ~l) >> (64 - k)) | (spread31(__brevll(a & ~h) >> (64 - k)) << 1);
                     const uint64_t bf = bucket_of(t, fw), br = bucket_of(t, rc);
                     const uint2 none = make_uint2(0u, 0u);
-                    const uint2 df = (strands & 1) ? t.dir[bf] : none;          // both directory words in flight
-                    const uint2 dr = (strands & 2) ? t.dir[br] : none;
+                    const uint2 df = ((strands & 1) && bf < t.n_buckets) ? t.dir[bf] : none;    // both directory words in flight
+                    const uint2 dr = ((strands & 2) && br < t.n_buckets) ? t.dir[br] : none;
                     hits += probe_finish(t, fw, bf, df, max_hits, counts, n_counts);
                     hits += probe_finish(t, rc, br, dr, max_hits, counts, n_counts);
                     probed += (strands & 1) + ((strands >> 1) & 1);
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) void k_probe_reads(ProbeDev t, const uint8_t *
 
 static ProbeDev dev_of(const gki_probe *p) {
     ProbeDev d; d.dir = p->dir; d.rows = p->rows; d.nk = p->n_kmers; d.modulo = p->modulo;
-    d.inv = ~0ull / p->modulo;
+    d.inv = ~0ull / p->modulo; d.bucket_begin = p->bucket_begin; d.n_buckets = p->n_buckets;
     return d;
 }
 
@@ -218,16 +220,17 @@ int gki_probe_create(const gki_index_view *ix, gki_probe **out) {
     if (ix->n < 0 || ix->n >= (1ll << 32)) return gki_set_error(GKI_ERR_BAD_ARG, "record count must be below 2^32");
     gki_probe *p = new gki_probe();
     p->modulo = ix->modulo; p->n = ix->n; p->n_kmers = (const uint32_t *)ix->d_n_kmers;
-    hipError_t e = hipMalloc((void **)&p->dir, (size_t)ix->modulo * sizeof(uint2));
+    p->bucket_begin = ix->n_buckets ? ix->bucket_begin : 0; p->n_buckets = ix->n_buckets ? ix->n_buckets : ix->modulo;
+    hipError_t e = hipMalloc((void **)&p->dir, (size_t)p->n_buckets * sizeof(uint2));
     if (e == hipSuccess) e = hipMalloc((void **)&p->rows, (size_t)(ix->n > 0 ? ix->n : 1) * sizeof(uint4));
     if (e == hipSuccess) e = hipMalloc((void **)&p->counters, 2 * sizeof(unsigned long long));
     if (e == hipSuccess) {
         if (ix->n > 0)
             hipLaunchKernelGGL(k_probe_rows, dim3(stream_grid(ix->n, 256)), dim3(256), 0, 0, (const uint64_t *)ix->d_kmers,
                                (const uint32_t *)ix->d_nodes, (const uint16_t *)ix->d_frequencies, ix->n, p->rows);
-        hipLaunchKernelGGL(k_probe_dir, dim3(stream_grid((int64_t)ix->modulo, 256)), dim3(256), 0, 0,
+        hipLaunchKernelGGL(k_probe_dir, dim3(stream_grid((int64_t)p->n_buckets, 256)), dim3(256), 0, 0,
                            (const int32_t *)ix->d_hashes_to_index, (const uint32_t *)ix->d_n_kmers,
-                           (const uint64_t *)ix->d_kmers, ix->modulo, p->dir);
+                           (const uint64_t *)ix->d_kmers, p->n_buckets, p->dir);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(0);
     }

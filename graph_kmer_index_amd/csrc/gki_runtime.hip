@@ -58,6 +58,10 @@ int gki_memcpy_d2h(void *h_dst, const void *d_src, int64_t bytes) {
     if (bytes > 0) HIP_TRY(hipMemcpy(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost));
     return GKI_OK;
 }
+int gki_memcpy_d2d(void *d_dst, const void *d_src, int64_t bytes) {
+    if (bytes > 0) HIP_TRY(hipMemcpy(d_dst, d_src, (size_t)bytes, hipMemcpyDeviceToDevice));
+    return GKI_OK;
+}
 
 int gki_memset(void *d_dst, int value, int64_t bytes) {
     if (bytes > 0) HIP_TRY(hipMemset(d_dst, value, (size_t)bytes));

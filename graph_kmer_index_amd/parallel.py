@@ -37,6 +37,14 @@ class TorchControlPlane:
         self._dist.all_gather(out, torch.tensor([int(x)], dtype=torch.int64), group=self._group)
         return [int(o[0]) for o in out]
 
+    def allgather_ints(self, xs):
+        """Every rank's list of `world` integers -> the world x world matrix (row r = rank r's list)."""
+        import torch
+        mine = torch.tensor([int(x) for x in xs], dtype=torch.int64)
+        out = [torch.zeros(len(xs), dtype=torch.int64) for _ in range(self.world)]
+        self._dist.all_gather(out, mine, group=self._group)
+        return [[int(v) for v in o] for o in out]
+
 
 class Comm:
     """RCCL communicator of libgki_hip.so (gki_comm_*)."""
@@ -66,6 +74,26 @@ class Comm:
         out.n = total
         return out, counts
 
+    def alltoall_flat(self, dflat, send_start):
+        """dflat partitioned by destination rank (slice r = [send_start[r], send_start[r+1])) -> the records every
+        rank sent to this one, in rank order.  Returns (DeviceFlatKmers, recv_start)."""
+        world = self.control.world
+        matrix = self.control.allgather_ints([send_start[r + 1] - send_start[r] for r in range(world)])
+        recv_counts = [matrix[r][self.control.rank] for r in range(world)]
+        recv_start = np.concatenate([[0], np.cumsum(recv_counts)]).astype(np.int64)
+        out = DeviceFlatKmers.allocate(int(recv_start[-1]))
+        ss = (C.c_int64 * (world + 1))(*[int(x) for x in send_start])
+        rs = (C.c_int64 * (world + 1))(*[int(x) for x in recv_start])
+        _lib.check(_lib.load().gki_comm_alltoall_flat(
+            self.handle, ss, dflat.hashes.ptr, dflat.nodes.ptr, dflat.ref_offsets.ptr, dflat.allele_frequencies.ptr,
+            rs, out.hashes.ptr, out.nodes.ptr, out.ref_offsets.ptr, out.allele_frequencies.ptr))
+        return out, [int(x) for x in recv_start]
+
+    def allreduce_counts(self, counts):
+        """In-place sum over ranks of a uint32 DeviceArray."""
+        _lib.check(_lib.load().gki_comm_allreduce_u32(self.handle, counts.ptr, counts.n))
+        return counts
+
     def close(self):
         if self.handle is not None:
             _lib.load().gki_comm_destroy(self.handle)
@@ -94,3 +122,29 @@ def build_index_sharded(graph_arrays, k, critical_graph_paths, comm, modulo=4529
     index = DeviceIndex.build(everything, modulo, skip_frequencies)
     everything.free()
     return index, counts
+
+
+def build_index_partitioned(graph_arrays, k, critical_graph_paths, comm, modulo=452930477, skip_frequencies=False,
+                            **finder_kwargs):
+    """Bucket-range partitioned build: find (sharded by critical paths) -> partition the rank's
+    records by owning rank (bucket range) -> one all-to-all(v) over RCCL -> every rank sorts and keeps only its
+    1/world of the directory.  Returns this rank's slice as a DeviceIndex (bucket_begin / n_buckets set)."""
+    from .collision_free_kmer_index import DeviceIndex, bucket_range, partition_by_bucket_range
+    rank, world = comm.control.rank, comm.control.world
+    mine = find_sharded(graph_arrays, k, critical_graph_paths, rank, world, **finder_kwargs)
+    by_dest, send_start = partition_by_bucket_range(mine, modulo, world)
+    mine.free()
+    received, _ = comm.alltoall_flat(by_dest, send_start)
+    by_dest.free()
+    lo, hi = bucket_range(modulo, world, rank)
+    index = DeviceIndex.build(received, modulo, skip_frequencies, bucket_begin=lo, n_buckets=hi - lo)
+    received.free()
+    return index
+
+
+def map_reads_partitioned(index_slice, comm, letters, read_start, k, n_nodes, strands=3, max_hits=10):
+    """Node counts of all k-mers of the reads against a bucket-partitioned index: every rank probes its slice with all
+    reads (a k-mer of another slice misses after the modulo, without a memory access), then one all-reduce of the
+    uint32 histogram.  Returns the summed counts (DeviceArray) on every rank."""
+    counts, _, _ = index_slice.count_nodes_from_reads(letters, read_start, k, n_nodes, strands, max_hits)
+    return comm.allreduce_counts(counts)

@@ -42,6 +42,7 @@ int gki_malloc(void **d_ptr, int64_t bytes);
 int gki_free(void *d_ptr);
 int gki_memcpy_h2d(void *d_dst, const void *h_src, int64_t bytes);
 int gki_memcpy_d2h(void *h_dst, const void *d_src, int64_t bytes);
+int gki_memcpy_d2d(void *d_dst, const void *d_src, int64_t bytes);
 int gki_memset(void *d_dst, int value, int64_t bytes);
 int gki_device_synchronize(void);
 /* bytes free / total on the current device */
@@ -185,6 +186,22 @@ int gki_index_build(const void *d_kmers, const void *d_nodes, const void *d_ref_
                     void *d_out_kmers, void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32,
                     void *d_out_frequencies, void *d_out_permutation);
 
+/* Bucket-range partitioned build.  Part p of n_parts owns the buckets
+ * [modulo*p/n_parts, modulo*(p+1)/n_parts) (integer division): every GPU sorts and owns 1/n_parts of the directory,
+ * which removes the redundant full sort of the all-gather build and the 2^31-records-per-index limit.
+ * gki_partition_by_bucket_range: stable partition of n (< 2^31) records by part; h_part_start[n_parts+1] (host) receives
+ *   the slice boundaries in the output columns.  n_parts <= 256.
+ * gki_index_build_range: gki_index_build for the records of one slice: directory arrays int32 / uint32 [n_buckets],
+ *   indexed by bucket - bucket_begin; a record whose bucket lies outside the range is GKI_ERR_BAD_ARG. */
+int gki_partition_by_bucket_range(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32,
+                                  int64_t n, uint64_t modulo, int n_parts, void *d_out_kmers, void *d_out_nodes,
+                                  void *d_out_ref_offsets, void *d_out_af32, int64_t *h_part_start);
+int gki_index_build_range(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32,
+                          int64_t n, uint64_t modulo, uint64_t bucket_begin, uint64_t n_buckets, int skip_frequencies,
+                          void *d_hashes_to_index, void *d_n_kmers,
+                          void *d_out_kmers, void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32,
+                          void *d_out_frequencies, void *d_out_permutation);
+
 /* ---------------------------------------------------------------- ReverseKmerIndex
  * Replaces ReverseKmerIndex.from_flat_kmers (reverse_kmer_index.py:47-60): records stably sorted by
  * node.  Inputs: device columns nodes uint32[n], kmers uint64[n], ref_offsets uint64[n]; n_nodes =
@@ -206,6 +223,9 @@ typedef struct {
     const void *d_hashes_to_index, *d_n_kmers, *d_kmers, *d_nodes, *d_ref_offsets, *d_frequencies, *d_af32;
     uint64_t modulo;
     int64_t n;
+    /* bucket-range slice (gki_index_build_range): the directory arrays hold buckets [bucket_begin, bucket_begin +
+     * n_buckets) only and a k-mer whose bucket lies outside is a miss; n_buckets == 0 means the whole [0, modulo). */
+    uint64_t bucket_begin, n_buckets;
 } gki_index_view;
 int gki_index_lookup_count(const gki_index_view *ix, const void *d_queries, int64_t q, int64_t max_hits,
                            void *d_hit_start, int64_t *n_hits);
@@ -247,6 +267,15 @@ typedef struct gki_comm gki_comm;
 int gki_comm_get_unique_id(void *h_id);
 int gki_comm_create(gki_comm **out, int world_size, int rank, const void *h_id);
 int gki_comm_destroy(gki_comm *c);
+/* All-to-all(v) of FlatKmers columns for the bucket-range partitioned build: the send columns hold this rank's records
+ * partitioned by destination, slice r = [h_send_start[r], h_send_start[r+1]); what rank r sends to this rank lands at
+ * [h_recv_start[r], h_recv_start[r+1]) of the receive columns (both tables host int64[world+1]; the counts travel
+ * over the caller's control plane first). */
+int gki_comm_alltoall_flat(gki_comm *c, const int64_t *h_send_start, const void *d_hashes, const void *d_nodes,
+                           const void *d_ref_offsets, const void *d_af32, const int64_t *h_recv_start, void *d_out_hashes,
+                           void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32);
+/* In-place sum over ranks of a uint32 device array (node counts of a bucket-partitioned lookup). */
+int gki_comm_allreduce_u32(gki_comm *c, void *d_buf, int64_t n);
 int gki_comm_allgather_flat(gki_comm *c, const int64_t *h_counts, const void *d_hashes, const void *d_nodes,
                             const void *d_ref_offsets, const void *d_af32, void *d_out_hashes, void *d_out_nodes,
                             void *d_out_ref_offsets, void *d_out_af32);

@@ -5,9 +5,11 @@ import numpy as np
 import pytest
 
 from graph_kmer_index_amd import CriticalGraphPaths, DenseKmerFinder, DeviceFlatKmers, FlatKmers, _lib
-from graph_kmer_index_amd.collision_free_kmer_index import DeviceIndex
+from graph_kmer_index_amd.collision_free_kmer_index import (DeviceIndex, PartitionedDeviceIndex, bucket_range,
+                                                            partition_by_bucket_range)
 from graph_kmer_index_amd.graph import synthetic_snp_graph
-from graph_kmer_index_amd.parallel import Comm, build_index_sharded, find_sharded
+from graph_kmer_index_amd.parallel import (Comm, build_index_partitioned, build_index_sharded, find_sharded,
+                                           map_reads_partitioned)
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -21,6 +23,9 @@ class OneRank:
 
     def allgather_int(self, x):
         return [int(x)]
+
+    def allgather_ints(self, xs):
+        return [[int(x) for x in xs]]
 
 
 def test_rccl_world1_allgather_and_sharded_build():
@@ -94,3 +99,85 @@ def test_command_line_drivers_write_the_reference_formats(tmp_path):
     assert len(rc._hashes) == 2 * n and np.array_equal(rc._hashes[:n], flat._hashes)
     assert np.array_equal(rc._hashes[n:], oracle.reverse_complement(flat._hashes, 31))
     assert np.array_equal(rc._nodes[n:], flat._nodes)
+
+
+# ------------------------------------------------------------------ bucket-range partitioned build
+def _random_flat(n, n_distinct, seed):
+    rng = np.random.default_rng(seed)
+    pool = rng.integers(0, 4 ** 31, size=n_distinct, dtype=np.uint64)
+    return FlatKmers(pool[rng.integers(0, n_distinct, size=n)], rng.integers(0, 5000, size=n).astype(np.uint32),
+                     rng.integers(0, 300, size=n).astype(np.uint64), rng.random(n).astype(np.float32)), pool
+
+
+@pytest.mark.parametrize("modulo,n_parts", [(100003, 8), (257, 3), (452930477, 5), (1000, 256)])
+def test_partitioned_index_is_the_monolithic_index_cut_by_bucket_range(modulo, n_parts):
+    flat, pool = _random_flat(120000, 30000, modulo % 97)
+    dflat = DeviceFlatKmers.from_flat_kmers(flat)
+    whole = DeviceIndex.build(dflat, modulo)
+    parts = PartitionedDeviceIndex.build(dflat, modulo, n_parts)
+    n = dflat.n
+    assert parts.n == n
+    h2i, nk = whole.hashes_to_index.to_host(), whole.n_kmers.to_host()
+    cols = ("kmers", "nodes", "ref_offsets", "allele_frequencies", "frequencies")
+    base = 0
+    for p, part in enumerate(parts.parts):
+        lo, hi = bucket_range(modulo, n_parts, p)
+        assert (part.bucket_begin, part.n_buckets) == (lo, hi - lo)
+        # the stable global sort by bucket puts slice p at [base, base + part.n): payload and directory must agree
+        for c in cols:
+            assert np.array_equal(getattr(part, c).to_host(part.n), getattr(whole, c).to_host(n)[base:base + part.n]), c
+        pn = part.n_kmers.to_host()
+        assert np.array_equal(pn, nk[lo:hi])
+        ph = part.hashes_to_index.to_host()
+        assert np.array_equal(ph[pn > 0] + base, h2i[lo:hi][pn > 0])
+        base += part.n
+    assert base == n
+    # counting over the slices == counting on the whole index (reference layout and probe table)
+    rng = np.random.default_rng(5)
+    queries = np.concatenate([pool[:4000], rng.integers(0, 4 ** 31, size=3000, dtype=np.uint64)])
+    for max_hits in (2 ** 62, 3):
+        want = whole.count_nodes(queries, 5000, max_hits, use_probe_table=False).to_host()
+        assert np.array_equal(parts.count_nodes(queries, 5000, max_hits).to_host(), want)
+    # a slice refuses records of another slice
+    if n_parts > 1:
+        lo, hi = bucket_range(modulo, n_parts, 0)
+        with pytest.raises(_lib.GkiError):
+            DeviceIndex.build(dflat, modulo, bucket_begin=lo, n_buckets=hi - lo)
+
+
+def test_partition_is_stable_and_complete():
+    flat, _ = _random_flat(50000, 50000, 3)
+    dflat = DeviceFlatKmers.from_flat_kmers(flat)
+    modulo, n_parts = 7919, 7
+    out, start = partition_by_bucket_range(dflat, modulo, n_parts)
+    assert start[0] == 0 and start[-1] == dflat.n
+    got = out.to_flat_kmers()
+    bucket = flat._hashes % np.uint64(modulo)
+    begins = np.array([bucket_range(modulo, n_parts, p)[0] for p in range(n_parts)], dtype=np.uint64)
+    part = np.searchsorted(begins, bucket, side="right") - 1
+    order = np.argsort(part, kind="stable")
+    for name in ("_hashes", "_nodes", "_ref_offsets", "_allele_frequencies"):
+        assert np.array_equal(getattr(got, name), getattr(flat, name)[order]), name
+    assert start == np.concatenate([[0], np.cumsum(np.bincount(part, minlength=n_parts))]).tolist()
+
+
+def test_rccl_world1_partitioned_build_and_read_mapping():
+    g = synthetic_snp_graph(120000, 1300, k=31, seed=19)
+    cp = CriticalGraphPaths.from_graph(g, 31)
+    comm = Comm(OneRank())
+    index = build_index_partitioned(g, 31, cp, comm, modulo=200003, only_save_one_node_per_kmer=True, max_variant_nodes=5)
+    f = DenseKmerFinder(g, 31, critical_graph_paths=cp, only_save_one_node_per_kmer=True, max_variant_nodes=5)
+    flat = f.find_flat_on_device()
+    f.synchronize()
+    whole = DeviceIndex.build(flat, 200003)
+    assert index.n == whole.n and (index.bucket_begin, index.n_buckets) == (0, 200003)
+    assert np.array_equal(index.kmers.to_host(index.n), whole.kmers.to_host(whole.n))
+    assert np.array_equal(index.hashes_to_index.to_host(), whole.hashes_to_index.to_host())
+    rng = np.random.default_rng(1)
+    starts = rng.integers(0, len(g.seq) - 100, size=300)
+    letters = np.frombuffer(b"ACGT", np.uint8)[g.seq[(starts[:, None] + np.arange(100)[None, :]).ravel()]]
+    read_start = np.arange(301, dtype=np.int64) * 100
+    got = map_reads_partitioned(index, comm, letters, read_start, 31, g.n_nodes).to_host()
+    want, _, _ = whole.count_nodes_from_reads(letters, read_start, 31, g.n_nodes)
+    assert got.sum() > 0 and np.array_equal(got, want.to_host())
+    comm.close()

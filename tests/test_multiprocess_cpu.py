@@ -26,8 +26,14 @@ def _worker(rank, world, port, tmpdir):
                        stop_at_critical_path_number=b)
     counts = cp_plane.allgather_int(len(mine["kmers"]))
     ident = cp_plane.broadcast_bytes(bytes(range(128)) if rank == 0 else None, 0)
+    # all-to-all bookkeeping of the bucket-range partitioned build: row r = what rank r sends to each rank
+    modulo = 100003
+    bucket = mine["kmers"].astype(np.uint64) % np.uint64(modulo)
+    begins = np.array([modulo * p // world for p in range(world)], dtype=np.uint64)
+    send = np.bincount(np.searchsorted(begins, bucket, side="right") - 1, minlength=world)
+    matrix = cp_plane.allgather_ints(send.tolist())
     np.savez(os.path.join(tmpdir, "r%d.npz" % rank), counts=np.array(counts), ident=np.frombuffer(ident, np.uint8),
-             **mine)
+             send=send, matrix=np.array(matrix), **mine)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -43,6 +49,10 @@ def test_two_rank_sharding_and_control_plane(tmp_path):
     for p in parts:
         assert p["counts"].tolist() == [len(q["kmers"]) for q in parts]
         assert p["ident"].tolist() == list(range(128))
+    # the counts matrix every rank holds: row r = rank r's send counts; its column r = what rank r receives
+    for p in parts:
+        assert np.array_equal(p["matrix"], np.stack([q["send"] for q in parts]))
+    assert parts[0]["matrix"].sum() == len(full["kmers"])
     # shards are balanced by bases
     assert abs(len(parts[0]["kmers"]) - len(parts[1]["kmers"])) < 0.1 * len(full["kmers"])
 
