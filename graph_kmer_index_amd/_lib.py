@@ -45,6 +45,7 @@ SYMBOLS = {
     "gki_memset": (_I32, [_P, _I32, _I64]),
     "gki_device_synchronize": (_I32, []),
     "gki_mem_info": (_I32, [C.POINTER(_I64), C.POINTER(_I64)]),
+    "gki_compact_flat": (_I32, [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I64, C.POINTER(_I64)]),
     "gki_column_checksum": (_I32, [_P, _I64, _I32, C.POINTER(_U64), C.POINTER(_U64)]),
     "gki_hash_sequence": (_I32, [_P, _I64, _I32, _P]),
     "gki_hash_reads": (_I32, [_P, _P, _I64, _I32, _I32, _P, _P, _I64, C.POINTER(_I64)]),
@@ -75,6 +76,7 @@ SYMBOLS = {
     "gki_index_lookup_emit": (_I32, [C.POINTER(IndexView), _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "gki_probe_create": (_I32, [C.POINTER(IndexView), C.POINTER(_P)]),
     "gki_probe_destroy": (_I32, [_P]),
+    "gki_probe_contains": (_I32, [_P, _P, _I64, _P]),
     "gki_probe_count_nodes": (_I32, [_P, _P, _I64, _I64, _P, _I64, C.POINTER(_I64)]),
     "gki_probe_reads_count_nodes": (_I32, [_P, _P, _P, _I64, _I32, _I32, _I64, _P, _I64, C.POINTER(_I64), C.POINTER(_I64)]),
     "gki_comm_get_unique_id": (_I32, [_P]),

@@ -84,6 +84,18 @@ class DeviceIndex:
             self._probe = p
         return self._probe
 
+    def contains(self, queries):
+        """`kmer in index` for every query (gki_probe_contains).  queries: NumPy array or DeviceArray of uint64.
+        Returns a DeviceArray uint8[q] of 0 / 1."""
+        own = not isinstance(queries, _lib.DeviceArray)
+        dq = _lib.DeviceArray.from_host(np.ascontiguousarray(np.asarray(queries)).astype(np.uint64)) if own else queries
+        flags = _lib.DeviceArray(max(dq.n, 1), np.uint8)
+        _lib.check(_lib.load().gki_probe_contains(self.probe_table(), dq.ptr, dq.n, flags.ptr))
+        flags.n = dq.n
+        if own:
+            dq.free()
+        return flags
+
     def count_nodes(self, queries, n_nodes, max_hits=10, counts=None, use_probe_table=True, return_hits=False):
         """Fused probe + node histogram.  queries: NumPy array or DeviceArray of uint64.  Returns a DeviceArray
         uint32[n_nodes] (accumulates into `counts` when given).  use_probe_table=False probes the reference-layout
@@ -336,8 +348,10 @@ class CollisionFreeKmerIndex:
 
     def has_kmers(self, kmers):
         """kmer_mapper.in_graph_index equivalent (:214-216): membership of every query."""
-        hs = self._device_index().lookup_positions(kmers, max_hits=2 ** 62)[0]
-        return np.diff(hs) > 0
+        flags = self._device_index().contains(kmers)
+        out = flags.to_host(len(kmers)).astype(bool)
+        flags.free()
+        return out
 
     def map_kmers(self, kmers, n_nodes):
         """kmer_mapper.map_kmers_to_graph_index equivalent (:210-212): node hit counts, probe and histogram fused

@@ -50,17 +50,13 @@ def index(args):
     cp = load_critical_paths(args.critical_graph_paths) or CriticalGraphPaths.from_graph(graph, k)
     whitelist = None
     if args.whitelist is not None:
-        whitelist = set(int(x) for x in np.unique(CollisionFreeKmerIndex.from_file(args.whitelist)._kmers))
+        whitelist = CollisionFreeKmerIndex.from_file(args.whitelist)                      # :634 (`kmer in whitelist`)
     finder = DenseKmerFinder(graph, k, critical_graph_paths=cp, max_variant_nodes=args.max_variant_nodes,
                              only_save_one_node_per_kmer=True, whitelist=whitelist)      # :559-565
-    if whitelist is None:
-        dflat = finder.find_flat_on_device(split_layout=False)
-        finder.synchronize()
-        flat = dflat.to_flat_kmers()
-        dflat.free()
-    else:
-        finder.find()
-        flat = FlatKmers.from_multiple_flat_kmers([finder.get_flat_kmers(v="1")])
+    dflat = finder.find_flat_on_device(split_layout=False)      # with a whitelist: membership probe + compaction in HBM
+    finder.synchronize()
+    flat = dflat.to_flat_kmers()
+    dflat.free()
     logging.info("N kmers in flat kmers: %d" % len(flat._hashes))
     if args.include_reverse_complement:                                                    # :616-620
         flat = FlatKmers.from_multiple_flat_kmers([flat, flat.get_reverse_complement_flat_kmers(k)])

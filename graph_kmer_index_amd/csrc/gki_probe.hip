@@ -119,6 +119,30 @@ __global__ __launch_bounds__(256) void k_probe_kmers(ProbeDev t, const uint64_t 
     wave_add(&counters[0], hits);
 }
 
+// `kmer in index` (collision_free_kmer_index.py:295-296: get(kmer, max_hits = 10^11) is not None), one flag per query:
+// the whitelist test of DenseKmerFinder._add_kmer / _process_whole_node (kmer_finder.py:130-132, 362-365).
+__global__ __launch_bounds__(256) void k_probe_contains(ProbeDev t, const uint64_t *__restrict__ queries, int64_t q,
+                                                        uint8_t *__restrict__ flags) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += stride) {
+        const uint64_t km = queries[i];
+        const uint64_t b = bucket_of(t, km);
+        uint8_t found = 0;
+        if (b < t.n_buckets) {
+            const uint2 d = t.dir[b];
+            const uint32_t c16 = d.y & 0xFFFFu;
+            if (c16 != 0u && ((d.y >> 16) & fp_bit(km)) != 0u) {
+                const int64_t m = c16 == CNT_SAT ? (int64_t)t.nk[b] : (int64_t)c16;
+                for (int64_t j = d.x; j < (int64_t)d.x + m && !found; j++) {
+                    const uint4 r = t.rows[j];
+                    found = ((((uint64_t)r.y << 32) | r.x) == km) ? 1 : 0;
+                }
+            }
+        }
+        flags[i] = found;
+    }
+}
+
 // 31 low bits -> even bit positions (Morton spread)
 __device__ __forceinline__ uint64_t spread31(uint64_t x) {
     x &= 0x7FFFFFFFull;
@@ -277,6 +301,15 @@ int gki_probe_reads_count_nodes(gki_probe *p, const void *d_reads, const void *d
                        p->counters);
     HIP_TRY(hipGetLastError());
     return read_counters(p, n_hits, n_kmers);
+}
+
+int gki_probe_contains(gki_probe *p, const void *d_queries, int64_t q, void *d_flags) {
+    if (q <= 0) return GKI_OK;
+    hipLaunchKernelGGL(k_probe_contains, dim3(stream_grid(q, 256)), dim3(256), 0, 0, dev_of(p), (const uint64_t *)d_queries, q,
+                       (uint8_t *)d_flags);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(0));
+    return GKI_OK;
 }
 
 }  // extern "C"

@@ -25,6 +25,26 @@ __global__ __launch_bounds__(256) void k_checksum(const T *__restrict__ v, int64
 }
 }  // namespace
 
+namespace {
+// ---- stable compaction of FlatKmers columns by a byte flag per record
+__global__ __launch_bounds__(256) void k_widen_flags(const uint8_t *__restrict__ f, int64_t n, uint32_t *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = f[i] ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_compact_flat(const uint8_t *__restrict__ f, const int64_t *__restrict__ pos, int64_t n,
+                                                      int64_t base, const uint64_t *__restrict__ h, const uint32_t *__restrict__ nd,
+                                                      const uint64_t *__restrict__ r, const float *__restrict__ af,
+                                                      uint64_t *__restrict__ oh, uint32_t *__restrict__ ond,
+                                                      uint64_t *__restrict__ orf, float *__restrict__ oaf) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (!f[i]) continue;
+        const int64_t o = base + pos[i];
+        oh[o] = h[i]; ond[o] = nd[i]; orf[o] = r[i]; oaf[o] = af[i];
+    }
+}
+}  // namespace
+
 extern "C" {
 
 const char *gki_last_error(void) { return gki_err_buf; }
@@ -77,9 +97,48 @@ int gki_mem_info(int64_t *free_bytes, int64_t *total_bytes) {
     return GKI_OK;
 }
 
+int gki_compact_flat(const void *d_flags, int64_t n, const void *d_hashes, const void *d_nodes, const void *d_ref_offsets,
+                     const void *d_af32, void *d_out_hashes, void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32,
+                     int64_t out_capacity, int64_t *n_out) {
+    *n_out = 0;
+    if (n <= 0) return GKI_OK;
+    const int64_t CH = 1ll << 27;                     // records per scan: bounds the temporaries at 1.6 GB
+    const int64_t m = n < CH ? n : CH;
+    uint32_t *wide = nullptr; int64_t *pos = nullptr; void *tmp = nullptr;
+    const int64_t tmp_bytes = gki_scan_tmp_bytes(m);
+    hipError_t e = hipMalloc((void **)&wide, (size_t)m * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&pos, (size_t)(m + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc(&tmp, (size_t)tmp_bytes);
+    int rc = e == hipSuccess ? GKI_OK : gki_set_error(GKI_ERR_HIP, "gki_compact_flat: %s", hipGetErrorString(e));
+    int64_t base = 0;
+    for (int64_t a = 0; a < n && rc == GKI_OK; a += CH) {
+        const int64_t c = n - a < CH ? n - a : CH;
+        const uint8_t *f = (const uint8_t *)d_flags + a;
+        hipLaunchKernelGGL(k_widen_flags, dim3(stream_grid(c, 256)), dim3(256), 0, 0, f, c, wide);
+        rc = gki_scan_u32_to_i64(wide, c, pos, tmp, tmp_bytes, 0);
+        int64_t kept = 0;
+        if (rc == GKI_OK && hipMemcpy(&kept, pos + c, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = gki_set_error(GKI_ERR_HIP, "copy of the chunk total failed");
+        if (rc == GKI_OK && base + kept > out_capacity)
+            rc = gki_set_error(GKI_ERR_BAD_ARG, "gki_compact_flat: output needs more than %lld records", (long long)out_capacity);
+        if (rc == GKI_OK && kept > 0) {
+            hipLaunchKernelGGL(k_compact_flat, dim3(stream_grid(c, 256)), dim3(256), 0, 0, f, pos, c, base,
+                               (const uint64_t *)d_hashes + a, (const uint32_t *)d_nodes + a, (const uint64_t *)d_ref_offsets + a,
+                               (const float *)d_af32 + a, (uint64_t *)d_out_hashes, (uint32_t *)d_out_nodes,
+                               (uint64_t *)d_out_ref_offsets, (float *)d_out_af32);
+            if (hipGetLastError() != hipSuccess) rc = gki_set_error(GKI_ERR_HIP, "k_compact_flat launch failed");
+        }
+        base += kept;
+    }
+    if (hipDeviceSynchronize() != hipSuccess && rc == GKI_OK) rc = gki_set_error(GKI_ERR_HIP, "gki_compact_flat failed");
+    (void)hipFree(wide); (void)hipFree(pos); (void)hipFree(tmp);
+    if (rc == GKI_OK) *n_out = base;
+    return rc;
+}
+
 int gki_column_checksum(const void *d_column, int64_t n, int elem_bytes, uint64_t *sum, uint64_t *xor_fold) {
     *sum = 0; *xor_fold = 0;
-    if (elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8) return gki_set_error(GKI_ERR_BAD_ARG, "elem_bytes must be 2, 4 or 8");
+    if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8)
+        return gki_set_error(GKI_ERR_BAD_ARG, "elem_bytes must be 1, 2, 4 or 8");
     if (n <= 0) return GKI_OK;
     unsigned long long *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, 16));
@@ -88,7 +147,8 @@ int gki_column_checksum(const void *d_column, int64_t n, int elem_bytes, uint64_
         const dim3 grid(stream_grid(n, 256)), block(256);
         if (elem_bytes == 8) hipLaunchKernelGGL(k_checksum<uint64_t>, grid, block, 0, 0, (const uint64_t *)d_column, n, d);
         else if (elem_bytes == 4) hipLaunchKernelGGL(k_checksum<uint32_t>, grid, block, 0, 0, (const uint32_t *)d_column, n, d);
-        else hipLaunchKernelGGL(k_checksum<uint16_t>, grid, block, 0, 0, (const uint16_t *)d_column, n, d);
+        else if (elem_bytes == 2) hipLaunchKernelGGL(k_checksum<uint16_t>, grid, block, 0, 0, (const uint16_t *)d_column, n, d);
+        else hipLaunchKernelGGL(k_checksum<uint8_t>, grid, block, 0, 0, (const uint8_t *)d_column, n, d);
         e = hipGetLastError();
     }
     unsigned long long h[2] = {0, 0};

@@ -114,6 +114,19 @@ class DeviceFlatKmers:
                    _lib.DeviceArray.from_host(np.asarray(flat._ref_offsets).astype(np.uint64)),
                    _lib.DeviceArray.from_host(np.asarray(flat._allele_frequencies).astype(np.float32)))
 
+    def compacted(self, flags):
+        """Records whose flag (DeviceArray uint8, one per record) is set, order kept (gki_compact_flat)."""
+        import ctypes as C
+        keep, _ = flags.checksum(self.n)
+        out = DeviceFlatKmers.allocate(keep)
+        n_out = C.c_int64(0)
+        _lib.check(_lib.load().gki_compact_flat(flags.ptr, self.n, self.hashes.ptr, self.nodes.ptr, self.ref_offsets.ptr,
+                                                self.allele_frequencies.ptr, out.hashes.ptr, out.nodes.ptr,
+                                                out.ref_offsets.ptr, out.allele_frequencies.ptr, max(keep, 1),
+                                                C.byref(n_out)))
+        assert n_out.value == keep
+        return out
+
     def to_flat_kmers(self):
         return FlatKmers(self.hashes.to_host(self.n), self.nodes.to_host(self.n), self.ref_offsets.to_host(self.n),
                          self.allele_frequencies.to_host(self.n))

@@ -96,6 +96,7 @@ class DenseKmerFinder:
         self._only_follow_nodes = only_follow_nodes   # honoured by find_only_kmers_starting_at_position (its only caller,
         # unique_variant_kmers.py:91-96); find() with forced traversal raises
         self._params_cache = None
+        self._whitelist_device = None
         self._cols = None          # host columns after find()
         self._device = None
         self._finder = None
@@ -202,8 +203,7 @@ class DenseKmerFinder:
         kmers, start_nodes, start_offsets, nodes, af = cols
         keep = None
         if self._whitelist is not None:                                # kmer_finder.py:130-132, 362-365
-            wl = np.fromiter((int(x) for x in self._whitelist), dtype=np.int64)
-            keep = np.isin(kmers, wl)
+            keep = self._in_whitelist(kmers)
         if self._only_store_nodes is not None:                         # :153 (the bulk path :370-374 ignores it)
             g, k = self._arrays, self._k
             osn = np.fromiter((int(x) for x in self._only_store_nodes), dtype=np.int64)
@@ -220,8 +220,8 @@ class DenseKmerFinder:
         HBM (the CLI `index` path, command_line_interface.py:559-614).  Returns DeviceFlatKmers.
         split_layout: records whose window lies inside one node first, then the others (GKI_LAYOUT_SPLIT) -- the
         same multiset, written as two dense streams; False gives find()'s by-node order."""
-        if self._whitelist is not None or self._only_store_nodes is not None:
-            raise NotImplementedError("whitelist / only_store_nodes filters are applied by find() on the host")
+        if self._only_store_nodes is not None:
+            raise NotImplementedError("the only_store_nodes filter is applied by find() on the host")
         n = self._count(layout=1 if split_layout else 0)
         if out is None or out.hashes.n < n:
             out = DeviceFlatKmers.allocate(n)
@@ -229,7 +229,46 @@ class DenseKmerFinder:
         if n:
             _lib.check(_lib.load().gki_finder_emit_flat(self._finder_handle(), out.hashes.ptr, out.nodes.ptr,
                                                         out.ref_offsets.ptr, out.allele_frequencies.ptr))
+        if self._whitelist is not None and n:
+            # kmer_finder.py:130-132, 362-365: keep a record iff `kmer in whitelist`; on the device: membership probe of
+            # every hash against the whitelist index, then a stable compaction of the four columns
+            self.synchronize()
+            flags = self._whitelist_index().contains(out.hashes.view(0, n))
+            kept = out.compacted(flags)
+            flags.free()
+            out.free()
+            out = kept
         return out
+
+    def _in_whitelist(self, kmers):
+        """bool per k-mer: `kmer in whitelist`, probed on the device."""
+        kmers = np.ascontiguousarray(kmers)
+        if len(kmers) == 0:
+            return np.zeros(0, dtype=bool)
+        flags = self._whitelist_index().contains(kmers.astype(np.int64).view(np.uint64))
+        keep = flags.to_host(len(kmers)).astype(bool)
+        flags.free()
+        return keep
+
+    def _whitelist_index(self):
+        """The whitelist as a DeviceIndex: a CollisionFreeKmerIndex (what the reference's CLI passes,
+        command_line_interface.py:634), a DeviceIndex, or any iterable of k-mer hashes."""
+        if self._whitelist_device is None:
+            from .collision_free_kmer_index import CollisionFreeKmerIndex, DeviceIndex
+            from .flat_kmers import FlatKmers
+            wl = self._whitelist
+            if isinstance(wl, DeviceIndex):
+                self._whitelist_device = wl
+            elif isinstance(wl, CollisionFreeKmerIndex):
+                self._whitelist_device = wl._device_index()
+            else:
+                kmers = np.unique(np.fromiter((int(x) for x in wl), dtype=np.int64)).astype(np.uint64)
+                z = np.zeros(len(kmers), np.uint32)
+                modulo = max(2 * len(kmers) + 1, 1009)
+                self._whitelist_device = DeviceIndex.build(
+                    DeviceFlatKmers.from_flat_kmers(FlatKmers(kmers, z, z.astype(np.uint64), z.astype(np.float32))),
+                    modulo, skip_frequencies=True)
+        return self._whitelist_device
 
     def synchronize(self):
         _lib.check(_lib.load().gki_finder_synchronize(self._finder_handle()))
@@ -281,7 +320,7 @@ class DenseKmerFinder:
         kmers, start_nodes, start_offsets, out_nodes, af = cols
         keep = None
         if self._whitelist is not None:
-            keep = np.isin(kmers, np.fromiter((int(x) for x in self._whitelist), dtype=np.int64))
+            keep = self._in_whitelist(kmers)
         if self._only_store_nodes is not None:
             sel = np.isin(out_nodes, np.fromiter((int(x) for x in self._only_store_nodes), dtype=np.int64))
             keep = sel if keep is None else keep & sel

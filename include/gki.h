@@ -47,9 +47,14 @@ int gki_memset(void *d_dst, int value, int64_t bytes);
 int gki_device_synchronize(void);
 /* bytes free / total on the current device */
 int gki_mem_info(int64_t *free_bytes, int64_t *total_bytes);
-/* Order-independent checksums of a device column of n elements of 2, 4 or 8 bytes (zero-extended): sum mod 2^64 and
+/* Order-independent checksums of a device column of n elements of 1, 2, 4 or 8 bytes (zero-extended): sum mod 2^64 and
  * xor.  Lets a caller check that two layouts / a set of shards hold the same multiset without copying it back. */
 int gki_column_checksum(const void *d_column, int64_t n, int elem_bytes, uint64_t *sum, uint64_t *xor_fold);
+/* Stable compaction of FlatKmers columns: keeps record i iff d_flags[i] (uint8) != 0.  Output columns sized by the
+ * caller (out_capacity records; the number of set flags is gki_column_checksum's sum for flags of 0/1). */
+int gki_compact_flat(const void *d_flags, int64_t n, const void *d_hashes, const void *d_nodes, const void *d_ref_offsets,
+                     const void *d_af32, void *d_out_hashes, void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32,
+                     int64_t out_capacity, int64_t *n_out);
 
 /* ---------------------------------------------------------------- hashing (A1, A8, A10)
  * hash = sum_i base[i] * 4^i, first base least significant, a/n/m=0 c=1 g=2 t=3
@@ -252,6 +257,9 @@ int gki_probe_create(const gki_index_view *ix, gki_probe **out);
 int gki_probe_destroy(gki_probe *p);
 int gki_probe_count_nodes(gki_probe *p, const void *d_queries, int64_t q, int64_t max_hits, void *d_counts,
                           int64_t n_counts, int64_t *n_hits);
+/* `kmer in index` (collision_free_kmer_index.py:295-296) for q k-mers: d_flags uint8[q] = 1 / 0.  The whitelist test of
+ * DenseKmerFinder (kmer_finder.py:130-132, 362-365); follow with gki_compact_flat. */
+int gki_probe_contains(gki_probe *p, const void *d_queries, int64_t q, void *d_flags);
 int gki_probe_reads_count_nodes(gki_probe *p, const void *d_reads, const void *d_read_start, int64_t n_reads, int k,
                                 int strands, int64_t max_hits, void *d_counts, int64_t n_counts, int64_t *n_kmers,
                                 int64_t *n_hits);

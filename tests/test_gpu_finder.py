@@ -226,6 +226,46 @@ def test_whitelist_and_only_store_nodes_filters():
     assert_same_records(finder_cols(f), oracle.find(g, 31, None, False, 4, only_store_nodes=variant_nodes))
 
 
+def test_whitelist_on_device_as_set_index_and_flat_columns():
+    # kmer_finder.py:130-132, 362-365 with the whitelist a CollisionFreeKmerIndex, as the reference's CLI passes it
+    # (command_line_interface.py:634): membership probe + stable compaction in HBM
+    from graph_kmer_index_amd import CollisionFreeKmerIndex, FlatKmers
+    g = synthetic_snp_graph(90000, 1100, k=31, seed=31)
+    base = oracle.find(g, 31, None, True, 5)
+    rng = np.random.default_rng(3)
+    chosen = np.unique(base["kmers"][rng.random(len(base["kmers"])) < 0.3])
+    foreign = rng.integers(0, 4 ** 31, size=5000, dtype=np.int64)
+    wl_kmers = np.concatenate([chosen, foreign])
+    wl_index = CollisionFreeKmerIndex.from_flat_kmers(
+        FlatKmers(wl_kmers, np.zeros(len(wl_kmers), np.uint32), np.zeros(len(wl_kmers), np.uint64),
+                  np.ones(len(wl_kmers), np.float32)), modulo=20011)
+    want = oracle.find(g, 31, None, True, 5, whitelist=set(int(x) for x in wl_kmers))
+    assert 0 < len(want["kmers"]) < len(base["kmers"])
+    for wl in (wl_index, set(int(x) for x in wl_kmers)):
+        f = DenseKmerFinder(g, 31, only_save_one_node_per_kmer=True, max_variant_nodes=5, whitelist=wl)
+        f.find()
+        assert_same_records(finder_cols(f), want)
+        pos = g.position_id_base()[want["start_nodes"]] + want["start_offsets"]
+        for split in (False, True):
+            d = f.find_flat_on_device(split_layout=split)
+            flat = d.to_flat_kmers()
+            assert d.n == len(want["kmers"])
+            og = np.lexsort((flat._allele_frequencies, flat._nodes, flat._hashes, flat._ref_offsets))
+            ow = np.lexsort((want["allele_frequencies"].astype(np.float32), want["nodes"], want["kmers"], pos))
+            assert np.array_equal(flat._hashes[og], want["kmers"].astype(np.uint64)[ow])
+            assert np.array_equal(flat._nodes[og], want["nodes"].astype(np.uint32)[ow])
+            assert np.array_equal(flat._ref_offsets[og], pos.astype(np.uint64)[ow])
+            assert np.array_equal(flat._allele_frequencies[og], want["allele_frequencies"].astype(np.float32)[ow])
+            if not split:          # compaction is stable: by-node order of find() survives
+                got_v2 = finder_cols(f)
+                assert np.array_equal(flat._hashes, got_v2["kmers"].astype(np.uint64))
+    # nothing whitelisted -> empty columns
+    f = DenseKmerFinder(g, 31, only_save_one_node_per_kmer=True, whitelist={1})
+    assert f.find_flat_on_device().n == 0
+    f.find()
+    assert len(finder_cols(f)["kmers"]) == 0
+
+
 @pytest.mark.parametrize("case", [c for c in TOY if "from_position" in c["kw"]], ids=lambda c: c["name"])
 def test_kmers_from_position_reference_cases(case):
     # tests/test_kmer_finder.py:118-129, 300-382 of the reference (early-stop searches), exact order

@@ -381,3 +381,23 @@ def test_map_reads_fused_vs_oracle(k):
         c, n_kmers, n_hits = idx._device_index().count_nodes_from_reads(np.frombuffer(enc, np.uint8), start, k, n_nodes,
                                                                        strands=2, max_hits=max_hits)
         assert np.array_equal(c.to_host(n_nodes), e_r) and n_kmers == len(rev) and n_hits == h_r
+
+
+def test_contains_and_compaction_primitives():
+    from graph_kmer_index_amd import DeviceFlatKmers
+    rng = np.random.default_rng(8)
+    n = 300000
+    kmers = rng.integers(0, 4 ** 31, size=n, dtype=np.uint64)
+    flat = FlatKmers(kmers, rng.integers(0, 99, size=n).astype(np.uint32), np.arange(n, dtype=np.uint64),
+                     rng.random(n).astype(np.float32))
+    idx = CollisionFreeKmerIndex.from_flat_kmers(FlatKmers(kmers[::3], np.zeros(n // 3, np.uint32), np.zeros(n // 3, np.uint64),
+                                                           np.ones(n // 3, np.float32)), modulo=50021)
+    member = np.isin(kmers, kmers[::3])
+    assert np.array_equal(idx.has_kmers(kmers), member)
+    assert not idx.has_kmers(rng.integers(0, 4 ** 31, size=1000, dtype=np.uint64)).any()
+    d = DeviceFlatKmers.from_flat_kmers(flat)
+    flags = idx._device_index().contains(d.hashes)
+    assert flags.checksum(n)[0] == int(member.sum())
+    kept = d.compacted(flags).to_flat_kmers()
+    for name in ("_hashes", "_nodes", "_ref_offsets", "_allele_frequencies"):
+        assert np.array_equal(getattr(kept, name), getattr(flat, name)[member]), name
