@@ -39,6 +39,7 @@ SYMBOLS = {
     "gki_set_device": (_I32, [_I32]),
     "gki_malloc": (_I32, [C.POINTER(_P), _I64]),
     "gki_free": (_I32, [_P]),
+    "gki_trim": (_I32, []),
     "gki_memcpy_h2d": (_I32, [_P, _P, _I64]),
     "gki_memcpy_d2h": (_I32, [_P, _P, _I64]),
     "gki_memcpy_d2d": (_I32, [_P, _P, _I64]),

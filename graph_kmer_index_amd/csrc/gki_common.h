@@ -25,6 +25,11 @@ int gki_set_error(int code, const char *fmt, ...);
         if (r_ != GKI_OK) return r_;   \
     } while (0)
 
+// pooled device memory (gki_runtime.hip): every buffer of the library is allocated and freed through these
+hipError_t gki_dev_malloc(void **ptr, size_t bytes);
+hipError_t gki_dev_free(void *ptr);
+template <typename T> static inline hipError_t gki_dev_malloc(T **ptr, size_t bytes) { return gki_dev_malloc((void **)ptr, bytes); }
+
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Grid for a grid-stride streaming kernel: enough blocks to fill 256 CUs x 8 blocks, no more.

@@ -851,19 +851,19 @@ int gki_finder_create(gki_graph *g, gki_finder **out) {
     for (int i = 0; i < 8; i++) HIP_TRY(hipEventCreate(&f->ev[i]));
     HIP_TRY(hipEventCreateWithFlags(&f->ev_ready, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&f->ev_join, hipEventDisableTiming));
-    HIP_TRY(hipMalloc((void **)&f->bcount, (size_t)n * 4));
-    HIP_TRY(hipMalloc((void **)&f->total, (size_t)n * 4));
-    HIP_TRY(hipMalloc((void **)&f->rec_base, (size_t)(n + 1) * 8));
-    HIP_TRY(hipMalloc((void **)&f->bnd_base, (size_t)(n + 1) * 8));
-    HIP_TRY(hipMalloc((void **)&f->ne, (size_t)(g->d.n_nonempty + 1) * sizeof(NodeEmit)));
+    HIP_TRY(gki_dev_malloc((void **)&f->bcount, (size_t)n * 4));
+    HIP_TRY(gki_dev_malloc((void **)&f->total, (size_t)n * 4));
+    HIP_TRY(gki_dev_malloc((void **)&f->rec_base, (size_t)(n + 1) * 8));
+    HIP_TRY(gki_dev_malloc((void **)&f->bnd_base, (size_t)(n + 1) * 8));
+    HIP_TRY(gki_dev_malloc((void **)&f->ne, (size_t)(g->d.n_nonempty + 1) * sizeof(NodeEmit)));
     HIP_TRY(hipMemset(f->ne, 0, (size_t)(g->d.n_nonempty + 1) * sizeof(NodeEmit)));   // cnt = 0: a record never refreshed emits nothing
-    HIP_TRY(hipMalloc((void **)&f->lossy, (size_t)n * 2));
-    HIP_TRY(hipMalloc((void **)&f->d_err, 4));
-    HIP_TRY(hipMalloc((void **)&f->d_totals, 4 * 8));
+    HIP_TRY(gki_dev_malloc((void **)&f->lossy, (size_t)n * 2));
+    HIP_TRY(gki_dev_malloc((void **)&f->d_err, 4));
+    HIP_TRY(gki_dev_malloc((void **)&f->d_totals, 4 * 8));
     HIP_TRY(hipMemset(f->d_totals, 0, 4 * 8));
-    HIP_TRY(hipMalloc((void **)&f->d_bsum, 8));
+    HIP_TRY(gki_dev_malloc((void **)&f->d_bsum, 8));
     f->scan_tmp_bytes = gki_scan_tmp_bytes(n);
-    HIP_TRY(hipMalloc(&f->scan_tmp, (size_t)f->scan_tmp_bytes));
+    HIP_TRY(gki_dev_malloc(&f->scan_tmp, (size_t)f->scan_tmp_bytes));
     *out = f;
     return GKI_OK;
 }
@@ -873,7 +873,7 @@ int gki_finder_destroy(gki_finder *f) {
     (void)hipStreamSynchronize(f->stream);
     (void)hipStreamSynchronize(f->stream2);
     void *ptrs[] = {f->bcount, f->total, f->rec_base, f->bnd_base, f->ne, f->lossy, f->scan_tmp, f->d_err, f->d_totals, f->d_bsum};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *p : ptrs) if (p) (void)gki_dev_free(p);
     for (int i = 0; i < 8; i++) (void)hipEventDestroy(f->ev[i]);
     (void)hipEventDestroy(f->ev_ready);
     (void)hipEventDestroy(f->ev_join);

@@ -124,9 +124,9 @@ int gki_forward_count(gki_graph *gr, int k, int max_variant_nodes, int one_node,
     if (n_pos <= 0) { HIP_TRY(hipMemset(d_rec_start, 0, 8)); return GKI_OK; }
     uint32_t *cnt = nullptr; void *tmp = nullptr; int *d_err = nullptr;
     int64_t tmp_bytes = gki_scan_tmp_bytes(n_pos);
-    HIP_TRY(hipMalloc((void **)&cnt, (size_t)n_pos * 4));
-    HIP_TRY(hipMalloc(&tmp, (size_t)tmp_bytes));
-    HIP_TRY(hipMalloc((void **)&d_err, 4));
+    HIP_TRY(gki_dev_malloc((void **)&cnt, (size_t)n_pos * 4));
+    HIP_TRY(gki_dev_malloc(&tmp, (size_t)tmp_bytes));
+    HIP_TRY(gki_dev_malloc((void **)&d_err, 4));
     HIP_TRY(hipMemset(d_err, 0, 4));
     FwdOut none{nullptr, nullptr, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(k_forward<false>, dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, k, max_variant_nodes > 250 ? 250 : max_variant_nodes,
@@ -137,7 +137,7 @@ int gki_forward_count(gki_graph *gr, int k, int max_variant_nodes, int one_node,
     int64_t total = 0; int herr = 0;
     hipError_t e1 = hipMemcpy(&total, (const int64_t *)d_rec_start + n_pos, 8, hipMemcpyDeviceToHost);
     hipError_t e2 = hipMemcpy(&herr, d_err, 4, hipMemcpyDeviceToHost);
-    (void)hipFree(cnt); (void)hipFree(tmp); (void)hipFree(d_err);
+    (void)gki_dev_free(cnt); (void)gki_dev_free(tmp); (void)gki_dev_free(d_err);
     if (rc != GKI_OK) return rc;
     HIP_TRY(e1); HIP_TRY(e2);
     if (herr) return gki_set_error(herr, "a forward k-window crosses more than %d nodes", FMAX - 2);
@@ -150,7 +150,7 @@ int gki_forward_emit(gki_graph *gr, int k, int max_variant_nodes, int one_node, 
                      void *d_nodes_out, void *d_af64) {
     if (n_pos <= 0) return GKI_OK;
     int *d_err = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_err, 4));
+    HIP_TRY(gki_dev_malloc((void **)&d_err, 4));
     HIP_TRY(hipMemset(d_err, 0, 4));
     FwdOut out{(int64_t *)d_hashes, (int32_t *)d_start_nodes, (int16_t *)d_start_offsets, (int32_t *)d_nodes_out, (double *)d_af64};
     hipLaunchKernelGGL(k_forward<true>, dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, k, max_variant_nodes > 250 ? 250 : max_variant_nodes,
@@ -158,7 +158,7 @@ int gki_forward_emit(gki_graph *gr, int k, int max_variant_nodes, int one_node, 
                        (uint32_t *)nullptr, (const int64_t *)d_rec_start, out, d_err);
     hipError_t e = hipGetLastError();
     hipError_t e2 = hipDeviceSynchronize();
-    (void)hipFree(d_err);
+    (void)gki_dev_free(d_err);
     HIP_TRY(e); HIP_TRY(e2);
     return GKI_OK;
 }

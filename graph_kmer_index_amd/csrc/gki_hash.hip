@@ -104,7 +104,7 @@ int gki_hash_sequence(const void *d_codes, int64_t n, int k, void *d_out) {
     if (n < k) return GKI_OK;
     void *seq2 = nullptr;
     int64_t n_u64 = ceil_div(n, 32) + 2;
-    HIP_TRY(hipMalloc(&seq2, (size_t)n_u64 * 8));
+    HIP_TRY(gki_dev_malloc(&seq2, (size_t)n_u64 * 8));
     HIP_TRY(hipMemsetAsync(seq2, 0, (size_t)n_u64 * 8, 0));
     int rc = gki_launch_pack((const uint8_t *)d_codes, n, (uint32_t *)seq2, 0);
     if (rc == GKI_OK) {
@@ -114,7 +114,7 @@ int gki_hash_sequence(const void *d_codes, int64_t n, int k, void *d_out) {
         if (hipGetLastError() != hipSuccess) rc = gki_set_error(GKI_ERR_HIP, "k_hash_windows launch failed");
     }
     hipError_t e = hipStreamSynchronize(0);
-    (void)hipFree(seq2);
+    (void)gki_dev_free(seq2);
     if (rc != GKI_OK) return rc;
     HIP_TRY(e);
     return GKI_OK;
@@ -128,15 +128,15 @@ int gki_hash_reads(const void *d_reads, const void *d_read_start, int64_t n_read
     if (n_reads <= 0) { HIP_TRY(hipMemset(d_out_start, 0, 8)); return GKI_OK; }
     void *cnt = nullptr, *tmp = nullptr;
     int64_t tmp_bytes = gki_scan_tmp_bytes(n_reads);
-    HIP_TRY(hipMalloc(&cnt, (size_t)n_reads * 4));
-    HIP_TRY(hipMalloc(&tmp, (size_t)tmp_bytes));
+    HIP_TRY(gki_dev_malloc(&cnt, (size_t)n_reads * 4));
+    HIP_TRY(gki_dev_malloc(&tmp, (size_t)tmp_bytes));
     hipLaunchKernelGGL(k_read_counts, dim3(stream_grid(n_reads, 256)), dim3(256), 0, 0, (const int64_t *)d_read_start,
                        n_reads, k, (uint32_t *)cnt);
     int rc = gki_scan_u32_to_i64((const uint32_t *)cnt, n_reads, (int64_t *)d_out_start, tmp, tmp_bytes, 0);
     int64_t total = 0;
     hipError_t e = hipMemcpy(&total, (const int64_t *)d_out_start + n_reads, 8, hipMemcpyDeviceToHost);
-    (void)hipFree(cnt);
-    (void)hipFree(tmp);
+    (void)gki_dev_free(cnt);
+    (void)gki_dev_free(tmp);
     if (rc != GKI_OK) return rc;
     HIP_TRY(e);
     *n_out = total;

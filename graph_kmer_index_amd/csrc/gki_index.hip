@@ -482,12 +482,12 @@ int gki_index_build_range(const void *d_kmers, const void *d_nodes, const void *
 #define HIP_G(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = gki_set_error(GKI_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); goto done; } } while (0)
     {
         for (int i = 0; i < 2; i++) {
-            HIP_G(hipMalloc((void **)&keys[i], (size_t)n * 4));
-            HIP_G(hipMalloc((void **)&vals[i], (size_t)n * 4));
+            HIP_G(gki_dev_malloc((void **)&keys[i], (size_t)n * 4));
+            HIP_G(gki_dev_malloc((void **)&vals[i], (size_t)n * 4));
         }
-        HIP_G(hipMalloc((void **)&hist, (size_t)hist_n * 4));
-        HIP_G(hipMalloc((void **)&offs, (size_t)(hist_n + 1) * 4));
-        HIP_G(hipMalloc(&tmp, (size_t)tmp_bytes));
+        HIP_G(gki_dev_malloc((void **)&hist, (size_t)hist_n * 4));
+        HIP_G(gki_dev_malloc((void **)&offs, (size_t)(hist_n + 1) * 4));
+        HIP_G(gki_dev_malloc(&tmp, (size_t)tmp_bytes));
         int *bad = (int *)hist;                       // hist is not in use yet
         HIP_G(hipMemsetAsync(bad, 0, 4, s));
         hipLaunchKernelGGL(k_bucket_keys, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const uint64_t *)d_kmers, n, modulo,
@@ -505,7 +505,7 @@ int gki_index_build_range(const void *d_kmers, const void *d_nodes, const void *
             int r = radix_sort_pairs(keys, vals, n, key_bits(n_buckets - 1), hist, offs, tmp, tmp_bytes, s, &cur);
             if (r != GKI_OK) CLEANUP_RETURN(r);
         }
-        HIP_G(hipMalloc((void **)&rows, (size_t)n * 32));
+        HIP_G(gki_dev_malloc((void **)&rows, (size_t)n * 32));
         hipLaunchKernelGGL(k_pack_rows, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const uint64_t *)d_kmers,
                            (const uint32_t *)d_nodes, (const uint64_t *)d_ref_offsets, (const float *)d_af32, n, rows);
         HIP_G(hipGetLastError());
@@ -535,14 +535,14 @@ int gki_index_build_range(const void *d_kmers, const void *d_nodes, const void *
                 hipLaunchKernelGGL(k_large_sizes, dim3(stream_grid(n_large, 256)), dim3(256), 0, s, large_list, n_large,
                                    (const uint32_t *)d_n_kmers, sizes);
                 HIP_G(hipGetLastError());
-                HIP_G(hipMalloc((void **)&starts, ((size_t)n_large + 1) * 8));
+                HIP_G(gki_dev_malloc((void **)&starts, ((size_t)n_large + 1) * 8));
                 void *tmp2 = nullptr;
                 int64_t tmp2_bytes = gki_scan_tmp_bytes(n_large);
-                hipError_t e2 = hipMalloc(&tmp2, (size_t)tmp2_bytes);
+                hipError_t e2 = gki_dev_malloc(&tmp2, (size_t)tmp2_bytes);
                 int r = e2 == hipSuccess ? gki_scan_u32_to_i64(sizes, n_large, starts, tmp2, tmp2_bytes, s) : GKI_ERR_HIP;
                 int64_t total = 0;
                 if (r == GKI_OK && hipMemcpy(&total, starts + n_large, 8, hipMemcpyDeviceToHost) != hipSuccess) r = GKI_ERR_HIP;
-                if (r == GKI_OK && hipMalloc((void **)&scratch, (size_t)total * sizeof(Pair)) != hipSuccess) r = GKI_ERR_HIP;
+                if (r == GKI_OK && gki_dev_malloc((void **)&scratch, (size_t)total * sizeof(Pair)) != hipSuccess) r = GKI_ERR_HIP;
                 if (r == GKI_OK) {
                     unsigned grid = n_large < 2048 ? n_large : 2048;
                     hipLaunchKernelGGL(k_frequencies_large, dim3(grid), dim3(256), 0, s, large_list, n_large,
@@ -551,15 +551,15 @@ int gki_index_build_range(const void *d_kmers, const void *d_nodes, const void *
                                        (uint16_t *)d_out_frequencies);
                     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) r = GKI_ERR_HIP;
                 }
-                (void)hipFree(starts); (void)hipFree(tmp2); (void)hipFree(scratch);
+                (void)gki_dev_free(starts); (void)gki_dev_free(tmp2); (void)gki_dev_free(scratch);
                 if (r != GKI_OK) CLEANUP_RETURN(gki_set_error(r, "large-bucket frequency pass failed"));
             }
         }
         HIP_G(hipStreamSynchronize(s));
     }
 done:
-    for (int i = 0; i < 2; i++) { (void)hipFree(keys[i]); (void)hipFree(vals[i]); }
-    (void)hipFree(hist); (void)hipFree(offs); (void)hipFree(tmp); (void)hipFree(rows);
+    for (int i = 0; i < 2; i++) { (void)gki_dev_free(keys[i]); (void)gki_dev_free(vals[i]); }
+    (void)gki_dev_free(hist); (void)gki_dev_free(offs); (void)gki_dev_free(tmp); (void)gki_dev_free(rows);
 #undef HIP_G
 #undef CLEANUP_RETURN
     return rc;
@@ -593,14 +593,14 @@ int gki_partition_by_bucket_range(const void *d_kmers, const void *d_nodes, cons
 #define HIP_G(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = gki_set_error(GKI_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); goto done; } } while (0)
     {
         for (int i = 0; i < 2; i++) {
-            HIP_G(hipMalloc((void **)&keys[i], (size_t)n * 4));
-            HIP_G(hipMalloc((void **)&vals[i], (size_t)n * 4));
+            HIP_G(gki_dev_malloc((void **)&keys[i], (size_t)n * 4));
+            HIP_G(gki_dev_malloc((void **)&vals[i], (size_t)n * 4));
         }
-        HIP_G(hipMalloc((void **)&hist, (size_t)hist_n * 4));
-        HIP_G(hipMalloc((void **)&offs, (size_t)(hist_n + 1) * 4));
-        HIP_G(hipMalloc(&tmp, (size_t)tmp_bytes));
-        HIP_G(hipMalloc((void **)&rows, (size_t)n * 32));
-        HIP_G(hipMalloc((void **)&pstart, 257 * 8));
+        HIP_G(gki_dev_malloc((void **)&hist, (size_t)hist_n * 4));
+        HIP_G(gki_dev_malloc((void **)&offs, (size_t)(hist_n + 1) * 4));
+        HIP_G(gki_dev_malloc(&tmp, (size_t)tmp_bytes));
+        HIP_G(gki_dev_malloc((void **)&rows, (size_t)n * 32));
+        HIP_G(gki_dev_malloc((void **)&pstart, 257 * 8));
         hipLaunchKernelGGL(k_part_keys, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const uint64_t *)d_kmers, n, modulo, n_parts,
                            keys[0], vals[0]);
         HIP_G(hipGetLastError());
@@ -619,8 +619,8 @@ int gki_partition_by_bucket_range(const void *d_kmers, const void *d_nodes, cons
         HIP_G(hipStreamSynchronize(s));
     }
 done:
-    for (int i = 0; i < 2; i++) { (void)hipFree(keys[i]); (void)hipFree(vals[i]); }
-    (void)hipFree(hist); (void)hipFree(offs); (void)hipFree(tmp); (void)hipFree(rows); (void)hipFree(pstart);
+    for (int i = 0; i < 2; i++) { (void)gki_dev_free(keys[i]); (void)gki_dev_free(vals[i]); }
+    (void)gki_dev_free(hist); (void)gki_dev_free(offs); (void)gki_dev_free(tmp); (void)gki_dev_free(rows); (void)gki_dev_free(pstart);
 #undef HIP_G
     return rc;
 }
@@ -642,13 +642,13 @@ int gki_reverse_index_build(const void *d_nodes, const void *d_kmers, const void
 #define HIP_G(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = gki_set_error(GKI_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); goto done; } } while (0)
     {
         for (int i = 0; i < 2; i++) {
-            HIP_G(hipMalloc((void **)&keys[i], (size_t)n * 4));
-            HIP_G(hipMalloc((void **)&vals[i], (size_t)n * 4));
+            HIP_G(gki_dev_malloc((void **)&keys[i], (size_t)n * 4));
+            HIP_G(gki_dev_malloc((void **)&vals[i], (size_t)n * 4));
         }
-        HIP_G(hipMalloc((void **)&hist, (size_t)hist_n * 4));
-        HIP_G(hipMalloc((void **)&offs, (size_t)(hist_n + 1) * 4));
-        HIP_G(hipMalloc(&tmp, (size_t)tmp_bytes));
-        HIP_G(hipMalloc((void **)&rows, (size_t)n * 16));
+        HIP_G(gki_dev_malloc((void **)&hist, (size_t)hist_n * 4));
+        HIP_G(gki_dev_malloc((void **)&offs, (size_t)(hist_n + 1) * 4));
+        HIP_G(gki_dev_malloc(&tmp, (size_t)tmp_bytes));
+        HIP_G(gki_dev_malloc((void **)&rows, (size_t)n * 16));
         hipLaunchKernelGGL(k_node_keys, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const uint32_t *)d_nodes, n, keys[0], vals[0]);
         HIP_G(hipGetLastError());
         int cur = 0;
@@ -666,8 +666,8 @@ int gki_reverse_index_build(const void *d_nodes, const void *d_kmers, const void
         HIP_G(hipStreamSynchronize(s));
     }
 done:
-    for (int i = 0; i < 2; i++) { (void)hipFree(keys[i]); (void)hipFree(vals[i]); }
-    (void)hipFree(hist); (void)hipFree(offs); (void)hipFree(tmp); (void)hipFree(rows);
+    for (int i = 0; i < 2; i++) { (void)gki_dev_free(keys[i]); (void)gki_dev_free(vals[i]); }
+    (void)gki_dev_free(hist); (void)gki_dev_free(offs); (void)gki_dev_free(tmp); (void)gki_dev_free(rows);
 #undef HIP_G
     return rc;
 }
@@ -701,8 +701,8 @@ int gki_index_lookup_count(const gki_index_view *ix, const void *d_queries, int6
     uint32_t *cnt = nullptr;
     void *tmp = nullptr;
     int64_t tmp_bytes = gki_scan_tmp_bytes(q);
-    HIP_TRY(hipMalloc((void **)&cnt, (size_t)q * 4));
-    HIP_TRY(hipMalloc(&tmp, (size_t)tmp_bytes));
+    HIP_TRY(gki_dev_malloc((void **)&cnt, (size_t)q * 4));
+    HIP_TRY(gki_dev_malloc(&tmp, (size_t)tmp_bytes));
     hipLaunchKernelGGL(k_lookup<false>, dim3(stream_grid(q, 256)), dim3(256), 0, 0, view_of(ix), (const uint64_t *)d_queries, q,
                        max_hits, cnt, (const int64_t *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr, (int64_t *)nullptr,
                        (uint16_t *)nullptr, (float *)nullptr, (int64_t *)nullptr);
@@ -710,7 +710,7 @@ int gki_index_lookup_count(const gki_index_view *ix, const void *d_queries, int6
     if (rc == GKI_OK) rc = gki_scan_u32_to_i64(cnt, q, (int64_t *)d_hit_start, tmp, tmp_bytes, 0);
     int64_t total = 0;
     hipError_t e = hipMemcpy(&total, (const int64_t *)d_hit_start + q, 8, hipMemcpyDeviceToHost);
-    (void)hipFree(cnt); (void)hipFree(tmp);
+    (void)gki_dev_free(cnt); (void)gki_dev_free(tmp);
     if (rc != GKI_OK) return rc;
     HIP_TRY(e);
     *n_hits = total;

@@ -245,9 +245,9 @@ int gki_probe_create(const gki_index_view *ix, gki_probe **out) {
     gki_probe *p = new gki_probe();
     p->modulo = ix->modulo; p->n = ix->n; p->n_kmers = (const uint32_t *)ix->d_n_kmers;
     p->bucket_begin = ix->n_buckets ? ix->bucket_begin : 0; p->n_buckets = ix->n_buckets ? ix->n_buckets : ix->modulo;
-    hipError_t e = hipMalloc((void **)&p->dir, (size_t)p->n_buckets * sizeof(uint2));
-    if (e == hipSuccess) e = hipMalloc((void **)&p->rows, (size_t)(ix->n > 0 ? ix->n : 1) * sizeof(uint4));
-    if (e == hipSuccess) e = hipMalloc((void **)&p->counters, 2 * sizeof(unsigned long long));
+    hipError_t e = gki_dev_malloc((void **)&p->dir, (size_t)p->n_buckets * sizeof(uint2));
+    if (e == hipSuccess) e = gki_dev_malloc((void **)&p->rows, (size_t)(ix->n > 0 ? ix->n : 1) * sizeof(uint4));
+    if (e == hipSuccess) e = gki_dev_malloc((void **)&p->counters, 2 * sizeof(unsigned long long));
     if (e == hipSuccess) {
         if (ix->n > 0)
             hipLaunchKernelGGL(k_probe_rows, dim3(stream_grid(ix->n, 256)), dim3(256), 0, 0, (const uint64_t *)ix->d_kmers,
@@ -259,7 +259,7 @@ int gki_probe_create(const gki_index_view *ix, gki_probe **out) {
         if (e == hipSuccess) e = hipStreamSynchronize(0);
     }
     if (e != hipSuccess) {
-        (void)hipFree(p->dir); (void)hipFree(p->rows); (void)hipFree(p->counters);
+        (void)gki_dev_free(p->dir); (void)gki_dev_free(p->rows); (void)gki_dev_free(p->counters);
         delete p;
         return gki_set_error(GKI_ERR_HIP, "gki_probe_create: %s", hipGetErrorString(e));
     }
@@ -269,7 +269,7 @@ int gki_probe_create(const gki_index_view *ix, gki_probe **out) {
 
 int gki_probe_destroy(gki_probe *p) {
     if (!p) return GKI_OK;
-    (void)hipFree(p->dir); (void)hipFree(p->rows); (void)hipFree(p->counters);
+    (void)gki_dev_free(p->dir); (void)gki_dev_free(p->rows); (void)gki_dev_free(p->counters);
     delete p;
     return GKI_OK;
 }

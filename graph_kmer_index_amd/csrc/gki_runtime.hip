@@ -12,6 +12,80 @@ int gki_set_error(int code, const char *fmt, ...) {
     return code;
 }
 
+// ------------------------------------------------------------------------------------------ device memory pool
+// hipMalloc / hipFree of tens of GB are not cheap on this stack: a fresh 76 GB allocation costs 0.4 s, and after two
+// alloc/free rounds of that size the third hipMalloc was measured at 4.3 s (the frees are deferred and paid then).  The
+// build and probe paths allocate their temporaries per call, so every buffer of the library goes through a cache of
+// freed blocks instead: gki_dev_free parks the block, gki_dev_malloc reuses a parked block of at least the requested
+// size and at most 1/8 more.  When the device runs out, the cache is released and the allocation retried.
+// gki_trim() releases it on demand; GKI_POOL=0 disables the cache.
+#include <map>
+#include <mutex>
+#include <unordered_map>
+namespace {
+std::mutex g_pool_mu;
+std::multimap<size_t, void *> g_pool_free;          // parked blocks by size
+std::unordered_map<void *, size_t> g_pool_live;     // size of every block handed out
+bool pool_enabled() { static const bool on = !(getenv("GKI_POOL") && atoi(getenv("GKI_POOL")) == 0); return on; }
+void pool_trim() {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    for (auto &kv : g_pool_free) (void)hipFree(kv.second);
+    g_pool_free.clear();
+}
+}  // namespace
+
+hipError_t gki_dev_malloc(void **ptr, size_t bytes) {
+    *ptr = nullptr;
+    if (bytes == 0) bytes = 16;
+    // size classes: 256 B steps below 1 MB, above it 1/16 of the size's power of two (at least 2 MB), so that buffers
+    // sized by record counts that differ by a fraction of a percent (shards, slices) land in the same class
+    size_t gran = 256;
+    if (bytes >= (1u << 20)) {
+        size_t p2 = (size_t)1 << 20;
+        while ((p2 << 1) <= bytes) p2 <<= 1;
+        gran = p2 / 16 > ((size_t)2 << 20) ? p2 / 16 : (size_t)2 << 20;
+    }
+    bytes = (bytes + gran - 1) / gran * gran;
+    if (pool_enabled()) {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        auto it = g_pool_free.lower_bound(bytes);
+        if (it != g_pool_free.end() && it->first <= bytes + bytes / 8) {
+            *ptr = it->second;
+            g_pool_live[*ptr] = it->first;
+            g_pool_free.erase(it);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(ptr, bytes);
+    if (e != hipSuccess) {                               // out of memory: give the cache back and retry once
+        (void)hipGetLastError();
+        pool_trim();
+        e = hipMalloc(ptr, bytes);
+    }
+    if (e == hipSuccess && pool_enabled()) {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        g_pool_live[*ptr] = bytes;
+    }
+    return e;
+}
+
+hipError_t gki_dev_free(void *ptr) {
+    if (!ptr) return hipSuccess;
+    if (pool_enabled()) {
+        // like hipFree, do not return before work that may still use the block has finished
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) return e;
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        auto it = g_pool_live.find(ptr);
+        if (it != g_pool_live.end()) {
+            g_pool_free.emplace(it->second, ptr);
+            g_pool_live.erase(it);
+            return hipSuccess;
+        }
+    }
+    return hipFree(ptr);
+}
+
 namespace {
 // order-independent checksums of a column: sum mod 2^64 and xor of the zero-extended elements
 template <typename T>
@@ -62,12 +136,13 @@ int gki_set_device(int device) { HIP_TRY(hipSetDevice(device)); return GKI_OK; }
 int gki_malloc(void **d_ptr, int64_t bytes) {
     *d_ptr = nullptr;
     if (bytes < 0) return gki_set_error(GKI_ERR_BAD_ARG, "gki_malloc: negative size");
-    if (bytes == 0) bytes = 16;
-    HIP_TRY(hipMalloc(d_ptr, (size_t)bytes));
+    HIP_TRY(gki_dev_malloc(d_ptr, (size_t)bytes));
     return GKI_OK;
 }
 
-int gki_free(void *d_ptr) { if (d_ptr) HIP_TRY(hipFree(d_ptr)); return GKI_OK; }
+int gki_free(void *d_ptr) { if (d_ptr) HIP_TRY(gki_dev_free(d_ptr)); return GKI_OK; }
+
+int gki_trim(void) { pool_trim(); return GKI_OK; }
 
 int gki_memcpy_h2d(void *d_dst, const void *h_src, int64_t bytes) {
     if (bytes > 0) HIP_TRY(hipMemcpy(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice));
@@ -106,9 +181,9 @@ int gki_compact_flat(const void *d_flags, int64_t n, const void *d_hashes, const
     const int64_t m = n < CH ? n : CH;
     uint32_t *wide = nullptr; int64_t *pos = nullptr; void *tmp = nullptr;
     const int64_t tmp_bytes = gki_scan_tmp_bytes(m);
-    hipError_t e = hipMalloc((void **)&wide, (size_t)m * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&pos, (size_t)(m + 1) * 8);
-    if (e == hipSuccess) e = hipMalloc(&tmp, (size_t)tmp_bytes);
+    hipError_t e = gki_dev_malloc((void **)&wide, (size_t)m * 4);
+    if (e == hipSuccess) e = gki_dev_malloc((void **)&pos, (size_t)(m + 1) * 8);
+    if (e == hipSuccess) e = gki_dev_malloc(&tmp, (size_t)tmp_bytes);
     int rc = e == hipSuccess ? GKI_OK : gki_set_error(GKI_ERR_HIP, "gki_compact_flat: %s", hipGetErrorString(e));
     int64_t base = 0;
     for (int64_t a = 0; a < n && rc == GKI_OK; a += CH) {
@@ -130,7 +205,7 @@ int gki_compact_flat(const void *d_flags, int64_t n, const void *d_hashes, const
         base += kept;
     }
     if (hipDeviceSynchronize() != hipSuccess && rc == GKI_OK) rc = gki_set_error(GKI_ERR_HIP, "gki_compact_flat failed");
-    (void)hipFree(wide); (void)hipFree(pos); (void)hipFree(tmp);
+    (void)gki_dev_free(wide); (void)gki_dev_free(pos); (void)gki_dev_free(tmp);
     if (rc == GKI_OK) *n_out = base;
     return rc;
 }
@@ -141,7 +216,7 @@ int gki_column_checksum(const void *d_column, int64_t n, int elem_bytes, uint64_
         return gki_set_error(GKI_ERR_BAD_ARG, "elem_bytes must be 1, 2, 4 or 8");
     if (n <= 0) return GKI_OK;
     unsigned long long *d = nullptr;
-    HIP_TRY(hipMalloc((void **)&d, 16));
+    HIP_TRY(gki_dev_malloc((void **)&d, 16));
     hipError_t e = hipMemsetAsync(d, 0, 16, 0);
     if (e == hipSuccess) {
         const dim3 grid(stream_grid(n, 256)), block(256);
@@ -153,7 +228,7 @@ int gki_column_checksum(const void *d_column, int64_t n, int elem_bytes, uint64_
     }
     unsigned long long h[2] = {0, 0};
     if (e == hipSuccess) e = hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
-    (void)hipFree(d);
+    (void)gki_dev_free(d);
     HIP_TRY(e);
     *sum = h[0]; *xor_fold = h[1];
     return GKI_OK;

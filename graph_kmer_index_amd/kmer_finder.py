@@ -34,6 +34,16 @@ def update_hash(current_base, current_hash, first_base, k, only_add=False):
 
 
 def check_supported_graph(g, k):
+    """Raises for graphs outside the established equivalence.  O(nodes + edges): the verdict is kept on
+    the graph object, finders over the same graph (shards, chunks) do not repeat it."""
+    done = g.__dict__.setdefault("_supported_for_k", set())
+    if k in done:
+        return
+    _check_supported_graph(g, k)
+    done.add(k)
+
+
+def _check_supported_graph(g, k):
     indeg = np.diff(g.rev_start)
     has_pred = indeg > 0
     if len(g.rev_edges):
@@ -166,8 +176,10 @@ class DenseKmerFinder:
                 chunked = True
                 node_end, off_end = int(crit_nodes[stop_at]), int(crit_offsets[stop_at])
         if chunked and len(g.edges):
-            src = np.repeat(np.arange(g.n_nodes), np.diff(g.edge_start))
-            if np.any(g.edges <= src):
+            if "_ids_increase_along_edges" not in g.__dict__:
+                src = np.repeat(np.arange(g.n_nodes), np.diff(g.edge_start))
+                g.__dict__["_ids_increase_along_edges"] = not np.any(g.edges <= src)
+            if not g.__dict__["_ids_increase_along_edges"]:
                 raise NotImplementedError("chunked find() needs node ids that increase along every edge")
         p = _lib.FindParams(k, self._max_variant_nodes, int(self._only_save_one_node_per_kmer), 0,
                             node_begin, off_begin, node_end, off_end, _lib.hptr(lossy))

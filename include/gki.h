@@ -40,6 +40,9 @@ int gki_device_count(int *count);
 int gki_set_device(int device);
 int gki_malloc(void **d_ptr, int64_t bytes);
 int gki_free(void *d_ptr);
+/* gki_malloc / gki_free and the library's own temporaries go through a cache of freed blocks (a fresh hipMalloc of
+ * tens of GB costs up to seconds on this stack); gki_trim returns the cache to the device.  GKI_POOL=0 disables it. */
+int gki_trim(void);
 int gki_memcpy_h2d(void *d_dst, const void *h_src, int64_t bytes);
 int gki_memcpy_d2h(void *h_dst, const void *d_src, int64_t bytes);
 int gki_memcpy_d2d(void *d_dst, const void *d_src, int64_t bytes);

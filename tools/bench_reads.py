@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--max-hits", type=int, default=10)
     ap.add_argument("--skip-two-pass", action="store_true")
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--whitelist-find", action="store_true",
+                    help="also time DenseKmerFinder.find_flat_on_device with the variant index as whitelist")
     args = ap.parse_args()
     lib = _lib.load(); _lib.require_device()
     k = 31
@@ -66,6 +68,18 @@ def main():
     idx = DeviceIndex.build(bnd, args.modulo)
     res["index_build_s"] = time.perf_counter() - t
     flat.free(); f = None
+    if args.whitelist_find:
+        # the CLI `index --whitelist` flow (command_line_interface.py:559-565, 634) in HBM: emit, membership probe of
+        # every record against the whitelist index, stable compaction
+        fw = DenseKmerFinder(g, k, critical_graph_paths=cp, only_save_one_node_per_kmer=True, max_variant_nodes=5, whitelist=idx)
+        for rep in range(2):
+            t = time.perf_counter()
+            kept = fw.find_flat_on_device()
+            _lib.check(lib.gki_device_synchronize())
+            res["whitelisted_find_s"] = time.perf_counter() - t
+            res["whitelisted_records"] = kept.n
+            kept.free()
+        fw.close(); fw = None
     t = time.perf_counter()
     idx.probe_table()
     res["probe_table_build_s"] = time.perf_counter() - t
