@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--cpu-sample-bases", type=float, default=3e7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--linear", action="store_true", help="diagnostic: linear chain graph without variants (BASELINE configs[1] shape)")
+    ap.add_argument("--indels", type=float, default=0.0, help="diagnostic: this fraction of the sites each become 1-bp "
+                    "deletions and insertions (north star's SNP/indel mix; empty nodes in the graph)")
     ap.add_argument("--all-nodes", action="store_true", help="diagnostic: only_save_one_node_per_kmer=False")
     ap.add_argument("--pretend-shard", default=None, help="diagnostic: R/W -> run only rank R's shard of W on this one GPU")
     ap.add_argument("--verify", action="store_true", help="size-independent checks on the full output (slow)")
@@ -102,7 +104,7 @@ def main():
             os.close(saved)
 
     from graph_kmer_index_amd import _lib, DenseKmerFinder, CriticalGraphPaths, DeviceGraph
-    from graph_kmer_index_amd.graph import synthetic_snp_graph, synthetic_linear_graph
+    from graph_kmer_index_amd.graph import synthetic_snp_graph, synthetic_linear_graph, synthetic_indel_graph
     from graph_kmer_index_amd.sharding import shard_range
     lib = _lib.load()
     _lib.require_device()
@@ -111,7 +113,12 @@ def main():
 
     G, S, k = int(args.bases), int(args.sites), args.k
     t0 = time.perf_counter()
-    g = synthetic_linear_graph(G, 25000, seed=1234) if args.linear else synthetic_snp_graph(G, S, k=k, seed=1234)
+    if args.linear:
+        g = synthetic_linear_graph(G, 25000, seed=1234)
+    elif args.indels > 0:
+        g = synthetic_indel_graph(G, S, k=k, seed=1234, p_del=args.indels, p_ins=args.indels)
+    else:
+        g = synthetic_snp_graph(G, S, k=k, seed=1234)
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
     cp = CriticalGraphPaths.from_graph(g, k)
@@ -174,7 +181,7 @@ def main():
         value = n_total * args.steps / elapsed
         avg_int_ms = float(np.mean(interior_ms))
         achieved = BYTES_PER_RECORD * n_interior / (avg_int_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(G, S, k) if world == 1 and not args.linear else (None, None)
+        traffic, traffic_src = pmc_traffic(G, S, k) if world == 1 and not args.linear and not args.indels else (None, None)
         res = {
             "metric": "k-mers hashed+indexed per second (k=31, 3 Gbp graph)", "value": value, "unit": "k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,

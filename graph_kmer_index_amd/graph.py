@@ -382,6 +382,85 @@ def synthetic_snp_graph(n_ref_bases, n_sites, k=31, seed=1234, max_node_len=3276
                        first_node=0, chromosome_start_nodes=[0], node_to_ref_offset=ntro)
 
 
+def synthetic_indel_graph(n_ref_bases, n_sites, k=31, seed=1234, p_del=0.1, p_ins=0.1, max_node_len=32767):
+    """The SNP/indel variant of BASELINE config 3 (north star: "~5 M SNP/indel bubbles"): like
+    `synthetic_snp_graph`, but a site is a 1-bp deletion with probability `p_del` (ref allele = the reference base, alt
+    allele = an EMPTY node) or a 1-bp insertion with probability `p_ins` (ref allele = an empty linear-ref dummy node,
+    alt allele = the inserted base; the reference base at the site opens the next segment).  Node ids are topological:
+    segment chunks, ref allele, alt allele, next segment ...; successor order [ref_allele, alt_allele]."""
+    sites = synthetic_snp_sites(n_ref_bases, n_sites, k, seed)
+    S = len(sites)
+    rng = np.random.default_rng([seed, 13])
+    kind = rng.random(S)
+    is_del = kind < p_del
+    is_ins = (kind >= p_del) & (kind < p_del + p_ins)
+    ref_len = np.where(is_ins, 0, 1).astype(np.int64)          # reference bases the ref allele holds
+    alt_len = np.where(is_del, 0, 1).astype(np.int64)
+    reference = random_codes(n_ref_bases, seed)
+    # ref segments between the sites: [0, s0), [s0 + ref_len0, s1), ..., [s_last + ref_len_last, G)
+    seg_lo = np.concatenate([[0], sites + ref_len])
+    seg_hi = np.concatenate([sites, [n_ref_bases]])
+    seg_len = seg_hi - seg_lo
+    assert np.all(seg_len >= 1)
+    n_chunks = np.maximum(1, -(-seg_len // max_node_len))
+    if np.any(n_chunks > 1):
+        assert np.all(seg_len[n_chunks > 1] // n_chunks[n_chunks > 1] > k + 1)
+    total_seg_nodes = int(n_chunks.sum())
+    n_nodes = total_seg_nodes + 2 * S
+    node_size = np.zeros(n_nodes, dtype=np.int32)
+    is_ref = np.ones(n_nodes, dtype=np.uint8)
+    af = np.ones(n_nodes, dtype=np.float64)
+    seg_first = np.zeros(S + 1, dtype=np.int64)
+    seg_first[1:] = np.cumsum(n_chunks[:-1] + 2)
+    chunk_seg = np.repeat(np.arange(S + 1), n_chunks)
+    chunk_idx = np.arange(total_seg_nodes) - np.repeat(np.cumsum(n_chunks) - n_chunks, n_chunks)
+    base = seg_len[chunk_seg] // n_chunks[chunk_seg]
+    rem = seg_len[chunk_seg] - base * n_chunks[chunk_seg]
+    chunk_node = seg_first[chunk_seg] + chunk_idx
+    node_size[chunk_node] = base + (chunk_idx < rem)
+    ref_allele = seg_first[:-1] + n_chunks[:-1]
+    alt_allele = ref_allele + 1
+    node_size[ref_allele] = ref_len
+    node_size[alt_allele] = alt_len
+    is_ref[alt_allele] = 0                                       # the empty ref allele of an insertion stays a ref dummy
+    f = rng.uniform(0.01, 0.99, size=S)
+    af[ref_allele] = f
+    af[alt_allele] = 1.0 - f
+    # sequence in node order: every base is a reference base except the alt alleles' (SNP: a different base, insertion:
+    # any base)
+    seq_start = np.zeros(n_nodes + 1, dtype=np.int64)
+    np.cumsum(node_size, out=seq_start[1:])
+    seq = np.empty(int(seq_start[-1]), dtype=np.uint8)
+    alt_slot = seq_start[alt_allele[alt_len == 1]]
+    is_alt_base = np.zeros(len(seq), dtype=bool)
+    is_alt_base[alt_slot] = True
+    seq[~is_alt_base] = reference
+    ref_at_site = reference[sites[alt_len == 1]]
+    shifted = (ref_at_site + 1 + rng.integers(0, 3, size=len(ref_at_site), dtype=np.uint8)) % 4
+    anyb = rng.integers(0, 4, size=len(ref_at_site), dtype=np.uint8)
+    seq[alt_slot] = np.where(is_ins[alt_len == 1], anyb, shifted)
+    # edges as in synthetic_snp_graph
+    out_deg = np.ones(n_nodes, dtype=np.int64)
+    last_chunk = seg_first + n_chunks - 1
+    out_deg[last_chunk[:-1]] = 2
+    out_deg[last_chunk[-1]] = 0
+    edge_start = np.zeros(n_nodes + 1, dtype=np.int64)
+    np.cumsum(out_deg, out=edge_start[1:])
+    edges = np.zeros(int(edge_start[-1]), dtype=np.int32)
+    inner = np.ones(total_seg_nodes, dtype=bool)
+    inner[np.cumsum(n_chunks) - 1] = False
+    edges[edge_start[chunk_node[inner]]] = chunk_node[inner] + 1
+    edges[edge_start[last_chunk[:-1]]] = ref_allele
+    edges[edge_start[last_chunk[:-1]] + 1] = alt_allele
+    edges[edge_start[ref_allele]] = seg_first[1:]
+    edges[edge_start[alt_allele]] = seg_first[1:]
+    ntro = np.zeros(n_nodes + 1, dtype=np.int64)
+    lin = np.nonzero(is_ref)[0]
+    ntro[lin] = np.concatenate([[0], np.cumsum(node_size[lin])[:-1]])
+    return GraphArrays(node_size, seq, edge_start, edges, is_ref, af,
+                       first_node=0, chromosome_start_nodes=[0], node_to_ref_offset=ntro)
+
+
 def synthetic_haplotype_sequence(graph, seed=99):
     """Base codes along one random path of a `synthetic_snp_graph`: at every SNP bubble the ref or the alt allele
     with probability 1/2 (read simulation for the lookup benchmarks)."""

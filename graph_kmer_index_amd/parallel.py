@@ -148,3 +148,15 @@ def map_reads_partitioned(index_slice, comm, letters, read_start, k, n_nodes, st
     uint32 histogram.  Returns the summed counts (DeviceArray) on every rank."""
     counts, _, _ = index_slice.count_nodes_from_reads(letters, read_start, k, n_nodes, strands, max_hits)
     return comm.allreduce_counts(counts)
+
+
+def map_reads_replicated(index, comm, letters, read_start, k, n_nodes, strands=3, max_hits=10):
+    """BASELINE configs[4] on N GPUs, replicas: every rank holds the whole index (DeviceIndex) and maps ITS share of the
+    reads; the uint32 node histograms are summed with one all-reduce.  Returns the summed counts on every rank."""
+    counts, _, _ = index.count_nodes_from_reads(letters, read_start, k, n_nodes, strands, max_hits)
+    return comm.allreduce_counts(counts)
+
+
+def read_shard(n_reads, rank, world):
+    """[begin, end) of the reads rank `rank` maps."""
+    return n_reads * rank // world, n_reads * (rank + 1) // world

@@ -8,7 +8,7 @@ import pytest
 from golden_cases import canonical_digest
 from gpu_util import finder_cols, assert_same_records
 from graph_kmer_index_amd import DenseKmerFinder, GraphArrays, CriticalGraphPaths
-from graph_kmer_index_amd.graph import synthetic_linear_graph, synthetic_snp_graph
+from graph_kmer_index_amd.graph import synthetic_indel_graph, synthetic_linear_graph, synthetic_snp_graph
 from graphgen import random_bubble_graph, overlapping_bubble_graph
 from oracle import oracle
 
@@ -132,6 +132,16 @@ def test_snp_graph_k31_against_oracle(G, S, M, one):
     f = DenseKmerFinder(g, 31, only_save_one_node_per_kmer=one, max_variant_nodes=M)
     f.find()
     assert_same_records(finder_cols(f), exp)
+
+
+@pytest.mark.parametrize("G,S,M,one,p", [(300000, 3500, 5, True, 0.2), (150000, 4000, 2, False, 0.35), (120000, 5000, 0, True, 0.5)])
+def test_indel_graph_k31_against_oracle(G, S, M, one, p):
+    # SNP / 1-bp deletion / 1-bp insertion sites: empty alt nodes and empty linear-ref dummy nodes at k=31
+    g = synthetic_indel_graph(G, S, k=31, seed=G % 97, p_del=p / 2, p_ins=p / 2)
+    assert (g.node_size == 0).sum() > S * p * 0.8
+    f = DenseKmerFinder(g, 31, only_save_one_node_per_kmer=one, max_variant_nodes=M)
+    f.find()
+    assert_same_records(finder_cols(f), oracle.find(g, 31, None, one, M))
 
 
 def test_flat_layout_on_device_matches_v2_columns():

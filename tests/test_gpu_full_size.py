@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from graph_kmer_index_amd import CriticalGraphPaths, DenseKmerFinder
-from graph_kmer_index_amd.graph import synthetic_linear_graph, synthetic_snp_graph
+from graph_kmer_index_amd.graph import synthetic_indel_graph, synthetic_linear_graph, synthetic_snp_graph
 from graph_kmer_index_amd.sharding import critical_path_cuts
 from gpu_util import assert_same_records, finder_cols
 from oracle import oracle
@@ -37,8 +37,13 @@ def test_config1_linear_10mbp_equals_oracle_record_by_record():
     assert_same_records(got, exp, exact_order=True)
 
 
-def test_config2_full_size_properties():
-    g = synthetic_snp_graph(3_000_000_000, 5_000_000, k=K, seed=1234)
+@pytest.mark.parametrize("kind", ["snp", "snp_indel"])
+def test_config2_full_size_properties(kind):
+    # "snp_indel": 10 % of the sites 1-bp deletions (empty alt node), 10 % insertions (empty ref-dummy node)
+    if kind == "snp":
+        g = synthetic_snp_graph(3_000_000_000, 5_000_000, k=K, seed=1234)
+    else:
+        g = synthetic_indel_graph(3_000_000_000, 5_000_000, k=K, seed=1234, p_del=0.1, p_ins=0.1)
     cp = CriticalGraphPaths.from_graph(g, K)
     kw = dict(critical_graph_paths=cp, only_save_one_node_per_kmer=True, max_variant_nodes=5)
 

@@ -9,7 +9,7 @@ from graph_kmer_index_amd.collision_free_kmer_index import (DeviceIndex, Partiti
                                                             partition_by_bucket_range)
 from graph_kmer_index_amd.graph import synthetic_snp_graph
 from graph_kmer_index_amd.parallel import (Comm, build_index_partitioned, build_index_sharded, find_sharded,
-                                           map_reads_partitioned)
+                                           map_reads_partitioned, map_reads_replicated, read_shard)
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -180,4 +180,11 @@ def test_rccl_world1_partitioned_build_and_read_mapping():
     got = map_reads_partitioned(index, comm, letters, read_start, 31, g.n_nodes).to_host()
     want, _, _ = whole.count_nodes_from_reads(letters, read_start, 31, g.n_nodes)
     assert got.sum() > 0 and np.array_equal(got, want.to_host())
+    # replicas: the shards of the reads (here mapped in turn) add up to the whole
+    total = np.zeros(g.n_nodes, np.uint64)
+    for r in range(3):
+        a, b = read_shard(300, r, 3)
+        part = map_reads_replicated(whole, comm, letters[a * 100:b * 100], read_start[a:b + 1] - read_start[a], 31, g.n_nodes)
+        total += part.to_host()
+    assert np.array_equal(total, want.to_host())
     comm.close()

@@ -87,3 +87,29 @@ def test_chunked_find_equals_unchunked():
                              stop_at_critical_path_number=b) for a, b in zip(cuts[:-1], cuts[1:])]
         for key in ("kmers", "nodes", "start_nodes", "start_offsets"):
             assert np.array_equal(np.concatenate([p[key] for p in parts]), full[key])
+
+
+def test_indel_generator_graphs_match_reference():
+    # the SNP/indel graph of the full-size parity test (graph_kmer_index_amd.graph.synthetic_indel_graph): the
+    # reference on the same graph (through the obgraph stand-in) against the oracle, emission order, all columns
+    from graph_kmer_index_amd.graph import synthetic_indel_graph
+    letters = "ACGT"
+    for seed, k, M, one in [(1, 5, 4, True), (2, 7, 5, True), (3, 6, 2, False), (4, 7, 5, False), (5, 4, 1, True)]:
+        g = synthetic_indel_graph(1500, 70, k=k, seed=seed, p_del=0.3, p_ins=0.3)
+        seqs = {n: "".join(letters[c] for c in g.seq[g.seq_start[n]:g.seq_start[n + 1]]) for n in range(g.n_nodes)}
+        edges = {n: g.edges[g.edge_start[n]:g.edge_start[n + 1]].tolist() for n in range(g.n_nodes)
+                 if g.edge_start[n + 1] > g.edge_start[n]}
+        lin = [n for n in range(g.n_nodes) if g.is_ref[n] and g.node_size[n] > 0]
+        af = {n: float(g.allele_freq[n]) for n in range(g.n_nodes)}
+        rg = Graph.from_dicts(seqs, edges, lin, af)
+        g2 = GraphArrays.from_dicts(seqs, edges, lin, af)
+        assert np.array_equal(g2.is_ref, g.is_ref)                # the adapter infers the same ref-dummy flags
+        cp = CriticalGraphPaths.from_graph(rg, k)
+        f = DenseKmerFinder(rg, k, critical_graph_paths=cp, max_variant_nodes=M, only_save_one_node_per_kmer=one)
+        f.find()
+        fl = f.get_flat_kmers()
+        o, flags = oracle.find(g, k, (cp.nodes, cp.offsets), one, M, return_flags=True)
+        assert flags == 0
+        assert np.array_equal(o["kmers"], fl._hashes) and np.array_equal(o["nodes"], fl._nodes)
+        assert np.array_equal(o["start_nodes"], fl._start_nodes) and np.array_equal(o["start_offsets"], fl._start_offsets)
+        assert np.array_equal(o["allele_frequencies"], fl._allele_frequencies)
