@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--sites", type=float, default=5e6, help="SNP bubbles")
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--max-variant-nodes", type=int, default=5)      # CLI `index` default, command_line_interface.py:637
-    ap.add_argument("--cpu-sample-bases", type=float, default=3e7)
+    ap.add_argument("--cpu-sample-bases", type=float, default=2e8)     # ~13 s of one host core
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--linear", action="store_true", help="diagnostic: linear chain graph without variants (BASELINE configs[1] shape)")
     ap.add_argument("--indels", type=float, default=0.0, help="diagnostic: this fraction of the sites each become 1-bp "
