@@ -88,12 +88,15 @@ def test_medium_snp_graph_digests():
         assert canonical_digest(got) == m["digest"], name
 
 
-@pytest.mark.parametrize("mode,n,seed", [("bubble", 60, 21), ("overlap", 40, 22), ("chain", 80, 23)])
+@pytest.mark.parametrize("mode,n,seed", [("bubble", 60, 21), ("overlap", 40, 22), ("chain", 80, 23),
+                                         ("bubble_bigk", 60, 24), ("overlap_bigk", 30, 25), ("chain_bigk", 70, 26)])
 def test_random_graphs_against_oracle(mode, n, seed):
     rng = np.random.default_rng(seed)
     checked = 0
+    bigk = mode.endswith("_bigk")
+    mode = mode.split("_")[0]
     for _ in range(n):
-        k = int(rng.integers(3, 12))
+        k = int(rng.integers(12, 32)) if bigk else int(rng.integers(3, 12))
         M = int(rng.choice([0, 1, 2, 3, 4, 100]))
         one = bool(rng.integers(0, 2))
         if mode == "bubble":
