@@ -14,10 +14,11 @@ from .critical_graph_paths import CriticalGraphPaths  # noqa: F401
 from .kmer_finder import DenseKmerFinder  # noqa: F401
 from .collision_free_kmer_index import CollisionFreeKmerIndex  # noqa: F401
 from .collision_free_kmer_index import CollisionFreeKmerIndex as KmerIndex  # noqa: F401
+from .collision_free_kmer_index import CounterKmerIndex  # noqa: F401
 from .reverse_kmer_index import ReverseKmerIndex  # noqa: F401
 from .read_kmers import ReadKmers  # noqa: F401
 from .nplist import NpList  # noqa: F401
 
 __all__ = ["letter_sequence_to_numeric", "numeric_to_letter_sequence", "kmer_to_hash_fast",
            "sequence_to_kmer_hash", "kmer_hash_to_sequence", "FlatKmers", "FlatKmers2", "DeviceFlatKmers",
-           "GraphArrays", "DeviceGraph", "CriticalGraphPaths", "DenseKmerFinder", "CollisionFreeKmerIndex", "KmerIndex", "ReverseKmerIndex", "ReadKmers", "NpList"]
+           "GraphArrays", "DeviceGraph", "CriticalGraphPaths", "DenseKmerFinder", "CollisionFreeKmerIndex", "KmerIndex", "CounterKmerIndex", "ReverseKmerIndex", "ReadKmers", "NpList"]

@@ -230,6 +230,54 @@ class PartitionedDeviceIndex:
             p.free()
 
 
+class CounterKmerIndex:
+    """collision_free_kmer_index.py:14-40 (what kmer_mapper feeds KAGE): count how often every index k-mer occurs among
+    the k-mers handed to `count_kmers`, then `get_node_counts` = for every node the summed counts of its records'
+    k-mers.  The reference keeps a per-k-mer npstructures.Counter (uint16 values) and reduces it with np.bincount; here
+    the probe adds straight into a per-node histogram on the device (gki_probe_count_nodes), which is the same sum as
+    long as no k-mer is seen more than 65 535 times (npstructures' behaviour beyond that is not pinned offline)."""
+
+    def __init__(self, kmers, nodes, counter=None, modulo=452930477):
+        self.kmers = kmers
+        self.nodes = nodes
+        self.counter = counter
+        self._modulo = int(modulo)
+        self._index = None
+        self._counts = None
+
+    @classmethod
+    def from_kmer_index(cls, kmer_index):
+        out = cls(np.asarray(kmer_index._kmers).astype(np.int64), kmer_index._nodes, None, kmer_index._modulo)
+        out._index = kmer_index._device_index()
+        return out
+
+    def _n_nodes(self):
+        return int(np.max(self.nodes)) + 1 if len(self.nodes) else 1
+
+    def reset(self):
+        if self._counts is not None:
+            self._counts.zero()
+
+    def count_kmers(self, kmers, update_counter=True):
+        if not update_counter:
+            self.reset()
+        if self._index is None:                       # constructed from bare arrays: build the table once
+            z = np.zeros(len(self.kmers), np.uint64)
+            self._index = DeviceIndex.build(DeviceFlatKmers.from_flat_kmers(
+                FlatKmers(np.asarray(self.kmers).astype(np.uint64), np.asarray(self.nodes).astype(np.uint32), z,
+                          z.astype(np.float32))), self._modulo, skip_frequencies=True)
+        self._counts = self._index.count_nodes(np.asarray(kmers).astype(np.int64).view(np.uint64), self._n_nodes(),
+                                               max_hits=2 ** 62, counts=self._counts)
+
+    def get_node_counts(self, min_nodes=0):
+        """float64 like np.bincount with weights (:39-40)."""
+        n = self._n_nodes()
+        got = self._counts.to_host(n).astype(np.float64) if self._counts is not None else np.zeros(n)
+        if min_nodes > n:
+            got = np.concatenate([got, np.zeros(min_nodes - n)])
+        return got
+
+
 class CollisionFreeKmerIndex:
     properties = {"_hashes_to_index", "_n_kmers", "_nodes", "_ref_offsets", "_kmers", "_modulo", "_frequencies",
                   "_allele_frequencies"}

@@ -401,3 +401,36 @@ def test_contains_and_compaction_primitives():
     kept = d.compacted(flags).to_flat_kmers()
     for name in ("_hashes", "_nodes", "_ref_offsets", "_allele_frequencies"):
         assert np.array_equal(getattr(kept, name), getattr(flat, name)[member]), name
+
+
+def test_counter_kmer_index_node_counts():
+    # collision_free_kmer_index.py:14-40 restated with NumPy: counter[kmer] = occurrences among the counted k-mers,
+    # node counts = bincount(nodes, weights=counter[kmers])
+    from graph_kmer_index_amd import CounterKmerIndex
+    rng = np.random.default_rng(17)
+    n = 40000
+    pool = rng.integers(0, 4 ** 31, size=6000, dtype=np.int64)
+    kmers = pool[rng.integers(0, len(pool), size=n)]
+    nodes = rng.integers(0, 700, size=n).astype(np.uint32)
+    idx = CollisionFreeKmerIndex.from_flat_kmers(FlatKmers(kmers, nodes, np.zeros(n, np.uint64), np.ones(n, np.float32)),
+                                                 modulo=30011)
+    counter = CounterKmerIndex.from_kmer_index(idx)
+    batches = [np.concatenate([pool[rng.integers(0, len(pool), size=5000)], rng.integers(0, 4 ** 31, size=800, dtype=np.int64)])
+               for _ in range(3)]
+
+    def expect(seen):
+        uniq, cnt = np.unique(seen, return_counts=True)
+        per_kmer = dict(zip(uniq.tolist(), cnt.tolist()))
+        w = np.array([per_kmer.get(int(km), 0) for km in idx._kmers.astype(np.int64)], dtype=np.float64)
+        return np.bincount(idx._nodes.astype(np.int64), w, minlength=900)
+
+    counter.count_kmers(batches[0])
+    counter.count_kmers(batches[1])
+    got = counter.get_node_counts(min_nodes=900)
+    assert got.dtype == np.float64 and len(got) == 900
+    assert np.array_equal(got, expect(np.concatenate(batches[:2])))
+    counter.count_kmers(batches[2], update_counter=False)           # resets first
+    assert np.array_equal(counter.get_node_counts(900), expect(batches[2]))
+    bare = CounterKmerIndex(idx._kmers, idx._nodes, None, modulo=30011)
+    bare.count_kmers(batches[0])
+    assert np.array_equal(bare.get_node_counts(900), expect(batches[0]))
