@@ -68,22 +68,54 @@ __device__ __forceinline__ uint64_t bucket_of(const ProbeDev &t, uint64_t km) {
     return r - t.bucket_begin;                                          // collision_free_kmer_index.py:304
 }
 
-// CollisionFreeKmerIndex.get for one k-mer, counting instead of returning (:303-315 + map_kmers :210-212), in two
-// steps so that a lane can have the directory words of several k-mers in flight.  Returns the hits counted.
-__device__ __forceinline__ uint32_t probe_finish(const ProbeDev &t, uint64_t km, uint64_t b, uint2 d, int64_t max_hits,
-                                                 unsigned int *__restrict__ counts, int64_t n_counts) {
+// CollisionFreeKmerIndex.get for one k-mer, counting instead of returning (:303-315 + map_kmers :210-212), in two steps.
+// Step 1 (every k-mer): the directory word.  ~95 % of the k-mers of a read end there (empty bucket, fingerprint miss).
+// Step 2 (the rest): scan the bucket's rows, count the hits.  Done in place, step 2 runs with a few lanes of the wave
+// while the others idle behind its dependent loads; instead the survivors are parked in a per-wave LDS queue (ballot +
+// prefix sum) and the queue is worked off 64 at a time, one candidate per lane.
+constexpr int CQ = 64 + 4 * 64;      // a round adds at most 4 candidates per lane to a residue of < 64
+
+__device__ __forceinline__ void cand_push(uint4 *__restrict__ qe, int &n, bool cand, uint64_t km, uint32_t start, uint32_t count,
+                                          int lane) {
+    const uint64_t m = __ballot(cand);
+    if (cand) qe[n + __popcll(m & ((1ull << lane) - 1ull))] = make_uint4((uint32_t)km, (uint32_t)(km >> 32), start, count);
+    n += __popcll(m);
+}
+
+// is (km, relative bucket b, directory word d) a candidate, and how many rows does its bucket hold
+__device__ __forceinline__ bool cand_of(const ProbeDev &t, uint64_t km, uint64_t b, uint2 d, uint32_t &count) {
     const uint32_t c16 = d.y & 0xFFFFu;
-    if (c16 == 0u || ((d.y >> 16) & fp_bit(km)) == 0u) return 0u;
-    const int64_t m = c16 == CNT_SAT ? (int64_t)t.nk[b] : (int64_t)c16;
-    const int64_t s = d.x;
+    if (c16 == 0u || ((d.y >> 16) & fp_bit(km)) == 0u) return false;
+    count = c16 == CNT_SAT ? t.nk[b] : c16;
+    return true;
+}
+
+__device__ __forceinline__ uint32_t cand_scan(const ProbeDev &t, uint4 e, int64_t max_hits, unsigned int *__restrict__ counts,
+                                              int64_t n_counts) {
+    const uint64_t km = ((uint64_t)e.y << 32) | e.x;
     uint32_t hits = 0;
-    for (int64_t j = s; j < s + m; j++) {
+    for (int64_t j = e.z; j < (int64_t)e.z + (int64_t)e.w; j++) {
         const uint4 r = t.rows[j];
         if ((((uint64_t)r.y << 32) | r.x) != km) continue;              // :309
         if (hits == 0u && (int64_t)r.w > max_hits) break;               // :312 (frequency of the first match)
         if ((int64_t)r.z < n_counts) atomicAdd(&counts[r.z], 1u);
         hits++;
     }
+    return hits;
+}
+
+// works off the queue in groups of 64 (all of it when `all`); returns this lane's hits
+__device__ __forceinline__ uint32_t cand_drain(const ProbeDev &t, const uint4 *__restrict__ qe, int &n, bool all, int64_t max_hits,
+                                               unsigned int *__restrict__ counts, int64_t n_counts, int lane) {
+    uint32_t hits = 0;
+    __builtin_amdgcn_wave_barrier();
+    while (n >= 64 || (all && n > 0)) {
+        const int first = n >= 64 ? n - 64 : 0;
+        const int mine = first + lane;
+        if (mine < n) hits += cand_scan(t, qe[mine], max_hits, counts, n_counts);
+        n = first;
+    }
+    __builtin_amdgcn_wave_barrier();
     return hits;
 }
 
@@ -98,9 +130,15 @@ constexpr int PROBE_UNROLL = 4;
 __global__ __launch_bounds__(256) void k_probe_kmers(ProbeDev t, const uint64_t *__restrict__ queries, int64_t q,
                                                      int64_t max_hits, unsigned int *__restrict__ counts, int64_t n_counts,
                                                      unsigned long long *__restrict__ counters) {
+    __shared__ uint4 s_cand[4][CQ];
+    const int lane = threadIdx.x & 63;
+    uint4 *qe = s_cand[threadIdx.x >> 6];
+    int n_c = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     uint64_t hits = 0;
-    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < q; i0 += stride * PROBE_UNROLL) {
+    // wave-uniform trip count (the queue bookkeeping uses ballots): the wave's first lane decides
+    for (int64_t w0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); w0 < q; w0 += stride * PROBE_UNROLL) {
+        const int64_t i0 = w0 + lane;
         uint64_t km[PROBE_UNROLL], b[PROBE_UNROLL];
         uint2 d[PROBE_UNROLL];
 #pragma unroll
@@ -114,8 +152,14 @@ __global__ __launch_bounds__(256) void k_probe_kmers(ProbeDev t, const uint64_t 
             d[u] = ((i0 + u * stride) < q && b[u] < t.n_buckets) ? t.dir[b[u]] : make_uint2(0u, 0u);
         }
 #pragma unroll
-        for (int u = 0; u < PROBE_UNROLL; u++) hits += probe_finish(t, km[u], b[u], d[u], max_hits, counts, n_counts);
+        for (int u = 0; u < PROBE_UNROLL; u++) {
+            uint32_t cnt = 0;
+            const bool cand = cand_of(t, km[u], b[u], d[u], cnt);
+            cand_push(qe, n_c, cand, km[u], d[u].x, cnt, lane);
+        }
+        hits += cand_drain(t, qe, n_c, false, max_hits, counts, n_counts, lane);
     }
+    hits += cand_drain(t, qe, n_c, true, max_hits, counts, n_counts, lane);
     wave_add(&counters[0], hits);
 }
 
@@ -143,9 +187,10 @@ __global__ __launch_bounds__(256) void k_probe_contains(ProbeDev t, const uint64
     }
 }
 
-// 31 low bits -> even bit positions (Morton spread)
-__device__ __forceinline__ uint64_t spread31(uint64_t x) {
-    x &= 0x7FFFFFFFull;
+
+// 32 low bits -> even bit positions
+__device__ __forceinline__ uint64_t spread32(uint64_t x) {
+    x &= 0xFFFFFFFFull;
     x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
     x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
     x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
@@ -154,9 +199,6 @@ __device__ __forceinline__ uint64_t spread31(uint64_t x) {
     return x;
 }
 
-__device__ __forceinline__ uint64_t funnel(uint64_t cur, uint64_t next, int lane) {
-    return (cur >> lane) | ((next << 1) << (63 - lane));
-}
 
 // One wave per read.  Forward k-mer of window j: bases j..j+k-1, first base least significant (read_kmers.py:70).
 // Reverse strand (read_kmers.py:23-26): the k-mers of str(Seq(read).reverse_complement()) are, window by window,
@@ -169,7 +211,10 @@ __global__ __launch_bounds__(256) void k_probe_reads(ProbeDev t, const uint8_t *
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const uint64_t kmask = (1ull << k) - 1ull;
+    __shared__ uint4 s_cand[4][CQ];
+    uint4 *qe = s_cand[threadIdx.x >> 6];
+    int n_c = 0;
+    const uint64_t kmask2 = (1ull << (2 * k)) - 1ull;
     uint64_t hits = 0, probed = 0;
     // Letters are fetched one step ahead (the next 64 letters of this read, or the first 64 of the wave's next read)
     // so that their latency hides behind the directory loads of the current step.
@@ -184,7 +229,11 @@ __global__ __launch_bounds__(256) void k_probe_reads(ProbeDev t, const uint8_t *
             ch_next = lane < lenn ? reads[sn + lane] : 0u;
         } else {
             const int64_t n_out = len - k + 1;
-            uint64_t lo_cur = 0, hi_cur = 0, ok_cur = 0;
+            // The 64 letters of a step become wave-uniform bit planes (__ballot) and are interleaved ONCE per step into
+            // the 2-bit stream (scalar work): C0,C1 = this step's 64 bases, N0,N1 = the next step's.  A lane's window is
+            // then one funnel shift of that stream, and its reverse complement a complement + bit reversal of the same
+            // word (first version: two Morton spreads per window and strand on the vector units).
+            uint64_t C0 = 0, C1 = 0, Cm0 = 0, Cm1 = 0;
             for (int64_t c = 0; c == 0 || (c - 1) * 64 < n_out; c++) {
                 const unsigned ch = ch_next | 0x20u;                     // 0 (past the end) -> ' ': code 0, not ACGT
                 const bool last = c * 64 >= n_out;                       // no further step for this read
@@ -193,29 +242,40 @@ __global__ __launch_bounds__(256) void k_probe_reads(ProbeDev t, const uint8_t *
                 else ch_next = i_next < len ? reads[s + i_next] : 0u;
                 const unsigned code = ch == 'c' ? 1u : ch == 'g' ? 2u : ch == 't' ? 3u : 0u;
                 const bool acgt = ch == 'a' || code != 0u;
-                const uint64_t lo_next = __ballot(code & 1u);
-                const uint64_t hi_next = __ballot(code & 2u);
-                const uint64_t ok_next = __ballot(acgt);
+                const uint64_t lo = __ballot(code & 1u), hi = __ballot(code & 2u), ok = __ballot(acgt);
+                const uint64_t N0 = spread32(lo) | (spread32(hi) << 1), N1 = spread32(lo >> 32) | (spread32(hi >> 32) << 1);
+                const uint64_t Nm0 = spread32(ok) * 3ull, Nm1 = spread32(ok >> 32) * 3ull;
                 const int64_t j = (c - 1) * 64 + lane;
+                bool cand_f = false, cand_r = false;
+                uint64_t fw = 0, rc = 0;
+                uint32_t sf = 0, sr = 0, cf = 0, cr = 0;
                 if (c > 0 && j < n_out) {
-                    const uint64_t l = funnel(lo_cur, lo_next, lane) & kmask;
-                    const uint64_t h = funnel(hi_cur, hi_next, lane) & kmask;
-                    const uint64_t a = funnel(ok_cur, ok_next, lane) & kmask;
-                    const uint64_t fw = spread31(l) | (spread31(h) << 1);
-                    const uint64_t rc = spread31(__brevll(a & ~l) >> (64 - k)) | (spread31(__brevll(a & ~h) >> (64 - k)) << 1);
+                    const int sh = (lane & 31) * 2;
+                    const bool up = lane >= 32;
+                    const uint64_t a = up ? C1 : C0, b = up ? N0 : C1, am = up ? Cm1 : Cm0, bm = up ? Nm0 : Cm1;
+                    fw = ((a >> sh) | ((b << 1) << (63 - sh))) & kmask2;
+                    const uint64_t m = ((am >> sh) | ((bm << 1) << (63 - sh))) & kmask2;
+                    rc = __brevll(~fw & m) >> (64 - 2 * k);              // bases reversed, the two bits of a base swapped
+                    rc = ((rc & 0x5555555555555555ull) << 1) | ((rc >> 1) & 0x5555555555555555ull);
                     const uint64_t bf = bucket_of(t, fw), br = bucket_of(t, rc);
                     const uint2 none = make_uint2(0u, 0u);
                     const uint2 df = ((strands & 1) && bf < t.n_buckets) ? t.dir[bf] : none;    // both directory words in flight
                     const uint2 dr = ((strands & 2) && br < t.n_buckets) ? t.dir[br] : none;
-                    hits += probe_finish(t, fw, bf, df, max_hits, counts, n_counts);
-                    hits += probe_finish(t, rc, br, dr, max_hits, counts, n_counts);
+                    cand_f = cand_of(t, fw, bf, df, cf); sf = df.x;
+                    cand_r = cand_of(t, rc, br, dr, cr); sr = dr.x;
                     probed += (strands & 1) + ((strands >> 1) & 1);
                 }
-                lo_cur = lo_next; hi_cur = hi_next; ok_cur = ok_next;
+                if (c > 0) {                                             // wave-uniform: the queue uses ballots
+                    cand_push(qe, n_c, cand_f, fw, sf, cf, lane);
+                    cand_push(qe, n_c, cand_r, rc, sr, cr, lane);
+                    hits += cand_drain(t, qe, n_c, false, max_hits, counts, n_counts, lane);
+                }
+                C0 = N0; C1 = N1; Cm0 = Nm0; Cm1 = Nm1;
             }
         }
         r = rn; s = sn; len = lenn;
     }
+    hits += cand_drain(t, qe, n_c, true, max_hits, counts, n_counts, lane);
     wave_add(&counters[0], hits);
     wave_add(&counters[1], probed);
 }
