@@ -1,0 +1,28 @@
+#!/bin/bash
+# usage: tools/exp/pmc_sq.sh <tag> [ENV=VAL ...]  -> SQ counters of the boundary kernel for one bench run
+tag="$1"; shift
+R="$(pwd)"; export TMPDIR=/tmp
+for e in "$@"; do export "$e"; done
+cd /tmp
+A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA"
+B="SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_LDS_BANK_CONFLICT"
+i=0
+for grp in "$A" "$B"; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d "$R/gpurun_out/sq_${tag}_$i" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$R/gpurun_out/sq_${tag}_$i.json" 2> "$R/gpurun_out/sq_${tag}_$i.err" || echo "pass $i failed"
+done
+cd "$R"
+python3 - "$tag" <<'PY'
+import csv, glob, sys, collections
+tag = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("gpurun_out/sq_%s_*/*/*counter_collection.csv" % tag):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "k_emit_boundary_one" in k or "k_count_boundary" in k or "k_emit_interior_runs" in k:
+            acc[k.split("(")[0][-40:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in acc.items():
+    print("==", tag, k)
+    for c, v in sorted(d.items()):
+        print("   %-32s %.4g" % (c, sum(v) / len(v)))
+PY
