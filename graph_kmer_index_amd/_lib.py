@@ -77,6 +77,8 @@ SYMBOLS = {
     "gki_index_lookup_emit": (_I32, [C.POINTER(IndexView), _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "gki_probe_create": (_I32, [C.POINTER(IndexView), C.POINTER(_P)]),
     "gki_probe_destroy": (_I32, [_P]),
+    "gki_probe_lookup_count": (_I32, [_P, _P, _I64, _I64, _P, C.POINTER(_I64)]),
+    "gki_probe_lookup_emit": (_I32, [_P, _P, _I64, _I64, _P, _P, _P]),
     "gki_probe_contains": (_I32, [_P, _P, _I64, _P]),
     "gki_probe_count_nodes": (_I32, [_P, _P, _I64, _I64, _P, _I64, C.POINTER(_I64)]),
     "gki_probe_reads_count_nodes": (_I32, [_P, _P, _P, _I64, _I32, _I32, _I64, _P, _I64, C.POINTER(_I64), C.POINTER(_I64)]),

@@ -53,23 +53,31 @@ class DeviceIndex:
             None if perm is None else perm.ptr))
         return out
 
-    def lookup_positions(self, queries, max_hits=10):
+    def lookup_positions(self, queries, max_hits=10, use_probe_table=True):
         """Batched CollisionFreeKmerIndex.get: (hit_start int64[q+1], position int64[hits] into the payload
-        arrays, query index int64[hits]) as NumPy arrays."""
+        arrays, query index int64[hits]) as NumPy arrays.  use_probe_table=False probes the reference-layout arrays
+        (gki_index_lookup_*) instead of the probe table (gki_probe_lookup_*)."""
         lib = _lib.load()
         q = np.ascontiguousarray(np.asarray(queries)).astype(np.uint64)
         nq = len(q)
         dq = _lib.DeviceArray.from_host(q if nq else np.zeros(1, np.uint64))
         hs = _lib.DeviceArray(nq + 1, np.int64)
-        view = self.view()
         n_hits = C.c_int64(0)
         mh = int(min(max_hits, 2 ** 62))
-        _lib.check(lib.gki_index_lookup_count(C.byref(view), dq.ptr, nq, mh, hs.ptr, C.byref(n_hits)))
+        if use_probe_table:
+            table = self.probe_table()
+            _lib.check(lib.gki_probe_lookup_count(table, dq.ptr, nq, mh, hs.ptr, C.byref(n_hits)))
+        else:
+            view = self.view()
+            _lib.check(lib.gki_index_lookup_count(C.byref(view), dq.ptr, nq, mh, hs.ptr, C.byref(n_hits)))
         m = n_hits.value
         pos, qi = _lib.DeviceArray(max(m, 1), np.int64), _lib.DeviceArray(max(m, 1), np.int64)
         if m:
-            _lib.check(lib.gki_index_lookup_emit(C.byref(view), dq.ptr, nq, mh, hs.ptr, None, None, qi.ptr, None, None,
-                                                 pos.ptr))
+            if use_probe_table:
+                _lib.check(lib.gki_probe_lookup_emit(table, dq.ptr, nq, mh, hs.ptr, qi.ptr, pos.ptr))
+            else:
+                _lib.check(lib.gki_index_lookup_emit(C.byref(view), dq.ptr, nq, mh, hs.ptr, None, None, qi.ptr, None, None,
+                                                     pos.ptr))
         out = (hs.to_host(), pos.to_host(m), qi.to_host(m))
         for b in (dq, hs, pos, qi):
             b.free()

@@ -163,6 +163,38 @@ __global__ __launch_bounds__(256) void k_probe_kmers(ProbeDev t, const uint64_t 
     wave_add(&counters[0], hits);
 }
 
+// Batched CollisionFreeKmerIndex.get on the table (collision_free_kmer_index.py:303-315, 354-391): count pass, then
+// (after a scan of the counts) an emit pass writing, per hit, the query index and the hit's position in the payload
+// arrays -- rows[j] is record j, so a caller gathers nodes / ref_offsets / frequencies / allele frequencies from its own
+// columns.  One or two sectors per query instead of the four to five of the reference layout.
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_probe_lookup(ProbeDev t, const uint64_t *__restrict__ queries, int64_t q, int64_t max_hits,
+                                                      uint32_t *__restrict__ cnt, const int64_t *__restrict__ hit_start,
+                                                      int64_t *__restrict__ o_query, int64_t *__restrict__ o_pos) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += stride) {
+        int64_t o = 0;
+        if (EMIT) { o = hit_start[i]; if (hit_start[i + 1] == o) continue; }
+        const uint64_t km = queries[i];
+        const uint64_t b = bucket_of(t, km);
+        uint32_t c = 0;
+        if (b < t.n_buckets) {
+            const uint2 d = t.dir[b];
+            uint32_t m = 0;
+            if (cand_of(t, km, b, d, m)) {
+                for (int64_t j = d.x; j < (int64_t)d.x + (int64_t)m; j++) {
+                    const uint4 r = t.rows[j];
+                    if ((((uint64_t)r.y << 32) | r.x) != km) continue;              // :309
+                    if (!EMIT && c == 0u && (int64_t)r.w > max_hits) break;         // :312 (frequency of the first match)
+                    if (EMIT) { o_query[o] = i; o_pos[o] = j; o++; }
+                    c++;
+                }
+            }
+        }
+        if (!EMIT) cnt[i] = c;
+    }
+}
+
 // `kmer in index` (collision_free_kmer_index.py:295-296: get(kmer, max_hits = 10^11) is not None), one flag per query:
 // the whitelist test of DenseKmerFinder._add_kmer / _process_whole_node (kmer_finder.py:130-132, 362-365).
 __global__ __launch_bounds__(256) void k_probe_contains(ProbeDev t, const uint64_t *__restrict__ queries, int64_t q,
@@ -367,6 +399,38 @@ int gki_probe_contains(gki_probe *p, const void *d_queries, int64_t q, void *d_f
     if (q <= 0) return GKI_OK;
     hipLaunchKernelGGL(k_probe_contains, dim3(stream_grid(q, 256)), dim3(256), 0, 0, dev_of(p), (const uint64_t *)d_queries, q,
                        (uint8_t *)d_flags);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(0));
+    return GKI_OK;
+}
+
+int gki_probe_lookup_count(gki_probe *p, const void *d_queries, int64_t q, int64_t max_hits, void *d_hit_start, int64_t *n_hits) {
+    *n_hits = 0;
+    if (q <= 0) { HIP_TRY(hipMemset(d_hit_start, 0, 8)); return GKI_OK; }
+    uint32_t *cnt = nullptr;
+    void *tmp = nullptr;
+    const int64_t tmp_bytes = gki_scan_tmp_bytes(q);
+    HIP_TRY(gki_dev_malloc((void **)&cnt, (size_t)q * 4));
+    hipError_t e = gki_dev_malloc(&tmp, (size_t)tmp_bytes);
+    if (e != hipSuccess) { (void)gki_dev_free(cnt); HIP_TRY(e); }
+    hipLaunchKernelGGL(k_probe_lookup<false>, dim3(stream_grid(q, 256)), dim3(256), 0, 0, dev_of(p), (const uint64_t *)d_queries, q,
+                       max_hits, cnt, (const int64_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr);
+    int rc = hipGetLastError() == hipSuccess ? GKI_OK : gki_set_error(GKI_ERR_HIP, "k_probe_lookup launch failed");
+    if (rc == GKI_OK) rc = gki_scan_u32_to_i64(cnt, q, (int64_t *)d_hit_start, tmp, tmp_bytes, 0);
+    int64_t total = 0;
+    e = hipMemcpy(&total, (const int64_t *)d_hit_start + q, 8, hipMemcpyDeviceToHost);
+    (void)gki_dev_free(cnt); (void)gki_dev_free(tmp);
+    if (rc != GKI_OK) return rc;
+    HIP_TRY(e);
+    *n_hits = total;
+    return GKI_OK;
+}
+
+int gki_probe_lookup_emit(gki_probe *p, const void *d_queries, int64_t q, int64_t max_hits, const void *d_hit_start,
+                          void *d_hit_query, void *d_hit_position) {
+    if (q <= 0) return GKI_OK;
+    hipLaunchKernelGGL(k_probe_lookup<true>, dim3(stream_grid(q, 256)), dim3(256), 0, 0, dev_of(p), (const uint64_t *)d_queries, q,
+                       max_hits, (uint32_t *)nullptr, (const int64_t *)d_hit_start, (int64_t *)d_hit_query, (int64_t *)d_hit_position);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(0));
     return GKI_OK;

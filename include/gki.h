@@ -260,6 +260,12 @@ int gki_probe_create(const gki_index_view *ix, gki_probe **out);
 int gki_probe_destroy(gki_probe *p);
 int gki_probe_count_nodes(gki_probe *p, const void *d_queries, int64_t q, int64_t max_hits, void *d_counts,
                           int64_t n_counts, int64_t *n_hits);
+/* gki_index_lookup_count / _emit on the table: d_hit_start int64[q+1] as above; the emit pass writes the query index and
+ * the hit's position in the payload arrays (int64 each), from which a caller gathers any column. */
+int gki_probe_lookup_count(gki_probe *p, const void *d_queries, int64_t q, int64_t max_hits, void *d_hit_start,
+                           int64_t *n_hits);
+int gki_probe_lookup_emit(gki_probe *p, const void *d_queries, int64_t q, int64_t max_hits, const void *d_hit_start,
+                          void *d_hit_query, void *d_hit_position);
 /* `kmer in index` (collision_free_kmer_index.py:295-296) for q k-mers: d_flags uint8[q] = 1 / 0.  The whitelist test of
  * DenseKmerFinder (kmer_finder.py:130-132, 362-365); follow with gki_compact_flat. */
 int gki_probe_contains(gki_probe *p, const void *d_queries, int64_t q, void *d_flags);

@@ -434,3 +434,21 @@ def test_counter_kmer_index_node_counts():
     bare = CounterKmerIndex(idx._kmers, idx._nodes, None, modulo=30011)
     bare.count_kmers(batches[0])
     assert np.array_equal(bare.get_node_counts(900), expect(batches[0]))
+
+
+def test_lookup_positions_probe_table_equals_reference_layout():
+    rng = np.random.default_rng(23)
+    n = 80000
+    pool = rng.integers(0, 4 ** 31, size=9000, dtype=np.uint64)
+    kmers = pool[rng.integers(0, len(pool), size=n)]
+    idx = CollisionFreeKmerIndex.from_flat_kmers(FlatKmers(kmers, rng.integers(0, 500, size=n).astype(np.uint32),
+                                                           rng.integers(0, 40, size=n).astype(np.uint64), np.ones(n, np.float32)),
+                                                 modulo=12007)
+    queries = np.concatenate([pool[:3000], rng.integers(0, 4 ** 31, size=2000, dtype=np.uint64), pool[:50]])
+    dev = idx._device_index()
+    for max_hits in (2 ** 62, 10, 3, 1):
+        a = dev.lookup_positions(queries, max_hits, use_probe_table=True)
+        b = dev.lookup_positions(queries, max_hits, use_probe_table=False)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+        assert len(a[1]) > 0

@@ -72,6 +72,23 @@ def main():
         tot_hash += dt_h; tot_probe += dt_p; hits += m
     res.update({"reads": n_reads, "kmers_per_strand": nq, "hash_reads_kmers_per_s": 2 * nq / tot_hash,
                 "lookup_queries_per_s": 2 * nq / tot_probe, "hits": hits})
+    # the same batched get on the probe table: per hit the query index and the payload position
+    table = idx.probe_table()
+    tot = 0.0
+    hits_t = 0
+    for strand in (0, 1):
+        _lib.check(lib.gki_hash_reads(d_letters.ptr, d_start.ptr, n_reads, k, strand, d_out_start.ptr, d_q.ptr, nq, C.byref(n_out)))
+        for rep in range(2):
+            nh = C.c_int64(0)
+            t = time.perf_counter()
+            _lib.check(lib.gki_probe_lookup_count(table, d_q.ptr, nq, 10, d_hs.ptr, C.byref(nh)))
+            m = nh.value
+            qi, pos = _lib.DeviceArray(max(m, 1), np.int64), _lib.DeviceArray(max(m, 1), np.int64)
+            _lib.check(lib.gki_probe_lookup_emit(table, d_q.ptr, nq, 10, d_hs.ptr, qi.ptr, pos.ptr))
+            dt = time.perf_counter() - t
+            qi.free(); pos.free()
+        tot += dt; hits_t += m
+    res.update({"probe_table_lookup_queries_per_s": 2 * nq / tot, "probe_table_hits": hits_t})
     print(json.dumps(res))
 
 
