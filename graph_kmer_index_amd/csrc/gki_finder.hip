@@ -10,7 +10,7 @@
 //   * the first bnd_len bases of a node ("boundary") share one predecessor tree: ONE lane walks it
 //     once per node and, each time it steps onto a predecessor q with c context bases already
 //     collected, completes the windows of every offset o with c < k-1-o <= c+size(q) from a single
-//     62-bit context register (k_count_boundary / k_emit_boundary).
+//     62-bit context register (k_count_boundary / k_emit_boundary_one).
 // Output slots come from a count pass + one exclusive scan over nodes, never from atomics, so the
 // record order is deterministic: by end node; inside a node first the boundary windows in walk
 // order (offset ascending inside one step, nodes of a window ascending), then the interior offsets.
@@ -98,12 +98,8 @@ __device__ __forceinline__ int32_t bnd_len_of(const DevGraph &g, const FindArgs 
 // ------------------------------------------------------------------------------------ boundary walk
 // One lane per node: depth-first over predecessor lists with an explicit stack.  Stepping onto predecessor q
 // (size s) with c context bases collected before it completes the windows of offsets o with c < k-1-o <= c+s.
-struct WalkStack {               // whole stack in (scratch) arrays: used by the all-nodes emit kernel, which needs
-    int32_t nd[MAXN], cur[MAXN], end[MAXN];   // the node list of every window
-    uint8_t cum[MAXN], vc[MAXN];
-};
 
-// The walk used by the count pass and by the one-node emit pass keeps the TOP of the stack in registers and only
+// The walk used by the count pass and by the emit pass keeps the TOP of the stack in registers and only
 // the levels below it in (scratch) arrays: PMC showed the first version, with the whole stack in scratch, writing
 // 1.4 GB of spills in the count pass and ~5 GB in the emit pass of the 3 Gbp graph, and every step began with a
 // dependent scratch load.  Node facts come from one aligned 32-byte NodeWalk record per visited node.
@@ -185,158 +181,8 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
     }
 }
 
-// Emit pass.  Each lane walks the predecessor tree of one node (as in the count pass); whenever a lane
-// has a finished step -- a run of offsets [from, to) that share one context register and one node
-// list -- the WAVE writes that run together: ballot over the lanes holding a step, broadcast the
-// step's constants from its lane, lane t writes record t.  A step of a SNP join node is ~30 records,
-// i.e. 240 contiguous bytes of hashes per store instruction instead of 64 scattered 8-byte stores.
-// Steps are issued in post-order (a node's own step after the steps below it), so the offsets of a
-// single predecessor chain come out ascending: on a linear graph the order is the reference's.
-template <bool HAS_LOSSY, int FMT>
-__global__ __launch_bounds__(256) void k_emit_boundary(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
-                                                       const uint32_t *__restrict__ bcount,
-                                                       const int64_t *__restrict__ rec_base,
-                                                       const int64_t *__restrict__ bnd_shift,
-                                                       typename OutSel<FMT>::T out, int *__restrict__ err) {
-    __shared__ int32_t s_nodes[4][MAXN];
-    WalkStack st;
-    uint8_t evf[MAXN], evt[MAXN];
-    uint64_t ctx[MAXN];                 // context bases collected through level j; the d-th base before the end node
-                                        // sits in 2-bit slot k-1-d, so the window of offset o is (ctx >> 2o) | own << 2(k-1-o)
-    const int lane = threadIdx.x & 63;
-    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int k = a.k;
-    const uint64_t kmask = (1ull << (2 * k)) - 1ull;
-    const int64_t n_threads = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t base = a.n0 + (int64_t)blockIdx.x * blockDim.x + wib * 64; base < a.n1; base += n_threads) {
-        const int64_t n = base + lane;
-        int L = 0, o_lo = 0, hi = 0;
-        int64_t idx = 0, pos0 = 0;
-        uint64_t own = 0;
-        if (n < a.n1 && bcount[n] > 0) {
-            const int32_t size = g.node_size[n];
-            const int32_t bl = bnd_len_of(g, a, lossy, n, size);
-            idx = rec_base[n] + *bnd_shift;
-            pos0 = g.pos_base[n];
-            o_lo = (n == a.node_begin) ? (int)(a.off_begin < bl ? a.off_begin : bl) : 0;
-            const int o_hi = (n == a.node_end) ? (int)(a.off_end < bl ? a.off_end : bl) : bl;
-            const int v0 = g.is_ref[n] ? 0 : 1;
-            const int cn = HAS_LOSSY ? lossy_of(lossy, (int32_t)n) : -1;
-            if (o_lo < o_hi && v0 <= a.M) {
-                // windows inside the node itself (lossy-restart nodes only; rare, written by the lane alone)
-                for (int o = o_lo > k - 1 ? o_lo : k - 1; o < o_hi; o++) {
-                    if (HAS_LOSSY && cn >= 0 && o + 1 - k <= cn - 1 && cn <= o) continue;
-                    put(out, idx++, gki_extract(g.seq2, g.seq_start[n] + o + 1 - k, k), (int32_t)n, (int32_t)n, o, pos0 + o,
-                        g.allele_freq[n]);
-                }
-                hi = o_hi < k - 1 ? o_hi : k - 1;
-                if (HAS_LOSSY && cn >= 1 && cn < hi) hi = cn;
-                if (o_lo < hi) {
-                    st.nd[0] = (int32_t)n; st.cur[0] = (int32_t)g.rev_start[n]; st.end[0] = (int32_t)g.rev_start[n + 1];
-                    st.cum[0] = 0; st.vc[0] = (uint8_t)v0;
-                    evf[0] = evt[0] = 0; ctx[0] = 0;
-                    own = gki_extract(g.seq2, g.seq_start[n], hi);
-                    L = 1;
-                }
-            }
-        }
-        while (__any(L > 0)) {
-            bool ev = false;
-            int e_from = 0, e_to = 0, e_L = 0;
-            uint64_t e_ctx = 0;
-            if (L > 0) {
-                const int j = L - 1;
-                const int32_t e = st.cur[j];
-                if (e >= st.end[j]) {                       // leave level j: its own step comes after its subtree
-                    if (evf[j] < evt[j]) { ev = true; e_from = evf[j]; e_to = evt[j]; e_L = j + 1; e_ctx = ctx[j]; }
-                    L--;
-                } else {
-                    st.cur[j] = e + 1;
-                    const int32_t q = g.rev_edges[e];
-                    const int vq = st.vc[j] + (g.is_ref[q] ? 0 : 1);
-                    if (vq <= a.M) {
-                        if (L >= MAXN - 1) {
-                            *err = GKI_ERR_WINDOW_TOO_DEEP;
-                        } else {
-                            const int s = g.node_size[q];
-                            const int c = st.cum[j];
-                            st.nd[L] = q; st.vc[L] = (uint8_t)vq;
-                            if (s == 0) {
-                                st.cum[L] = (uint8_t)c; st.cur[L] = (int32_t)g.rev_start[q]; st.end[L] = (int32_t)g.rev_start[q + 1];
-                                evf[L] = evt[L] = 0; ctx[L] = ctx[j];
-                                L++;
-                            } else {
-                                int from = k - 1 - c - s; if (from < o_lo) from = o_lo;
-                                int to = k - 1 - c; if (to > hi) to = hi;
-                                const int cq = HAS_LOSSY ? lossy_of(lossy, q) : -1;
-                                if (HAS_LOSSY && cq >= 0) { const int min_ok = k - 1 - c - s + cq; if (from < min_ok) from = min_ok; }
-                                const int tq = s < k - 1 - c ? s : k - 1 - c;
-                                const uint64_t cx = ctx[j] | (gki_extract(g.seq2, g.seq_start[q] + s - tq, tq) << (2 * (k - 1 - c - tq)));
-                                const bool deeper = (k - 1 - c - s > o_lo) && !(HAS_LOSSY && cq >= 1);
-                                if (deeper) {
-                                    st.cum[L] = (uint8_t)(c + s); st.cur[L] = (int32_t)g.rev_start[q]; st.end[L] = (int32_t)g.rev_start[q + 1];
-                                    evf[L] = (uint8_t)(from < to ? from : 0); evt[L] = (uint8_t)(from < to ? to : 0); ctx[L] = cx;
-                                    L++;
-                                } else if (from < to) {
-                                    ev = true; e_from = from; e_to = to; e_L = L + 1; e_ctx = cx;
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-            int32_t mn = INT_MAX;
-            double maf = INFINITY;
-            if (ev) {
-                for (int j = 0; j < e_L; j++) {
-                    const int32_t q = st.nd[j];
-                    mn = q < mn ? q : mn;
-                    maf = fmin(maf, g.allele_freq[q]);                // np.min, kmer_finder.py:143
-                }
-            }
-            uint64_t pending = __ballot(ev);
-            while (pending) {
-                const int src = __builtin_ctzll(pending);
-                pending &= pending - 1;
-                const uint64_t b_ctx = __shfl(e_ctx, src, 64), b_own = __shfl(own, src, 64);
-                const int b_from = __shfl(e_from, src, 64), b_cnt = __shfl(e_to, src, 64) - b_from, b_L = __shfl(e_L, src, 64);
-                const int64_t b_idx = __shfl(idx, src, 64), b_pos0 = __shfl(pos0, src, 64);
-                const int32_t b_mn = __shfl(mn, src, 64);
-                const double b_maf = __shfl(maf, src, 64);
-                const int32_t b_n = (int32_t)(base + src);
-                if (a.one_node) {                                     // :145-146 nodes[0] of np.unique
-                    if (lane < b_cnt) {
-                        const int o = b_from + lane;
-                        const uint64_t h = ((b_ctx >> (2 * o)) | (b_own << (2 * (k - 1 - o)))) & kmask;
-                        put(out, b_idx + lane, h, b_mn, b_n, o, b_pos0 + o, b_maf);
-                    }
-                    if (lane == src) idx += b_cnt;
-                } else {
-                    if (lane == src) {                                // ascending distinct nodes (np.unique :134)
-                        int32_t last = INT_MIN;
-                        for (int r = 0; r < e_L; r++) {
-                            int32_t best = INT_MAX;
-                            for (int j = 0; j < e_L; j++) { const int32_t q = st.nd[j]; if (q > last && q < best) best = q; }
-                            s_nodes[wib][r] = best;
-                            last = best;
-                        }
-                        idx += (int64_t)b_cnt * b_L;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    const int total = b_cnt * b_L;
-                    for (int t = lane; t < total; t += 64) {
-                        const int o = b_from + t / b_L;
-                        const uint64_t h = ((b_ctx >> (2 * o)) | (b_own << (2 * (k - 1 - o)))) & kmask;
-                        put(out, b_idx + t, h, s_nodes[wib][t % b_L], b_n, o, b_pos0 + o, b_maf);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-        }
-    }
-}
-
-// Emit pass for only_save_one_node_per_kmer (the CLI `index` configuration): walk and write are separated
+// Emit pass (ALL = false: only_save_one_node_per_kmer, the CLI `index` configuration; ALL = true: one record per
+// distinct window node, the constructor's default): walk and write are separated
 // inside the wave.  Phase A -- the lanes walk their nodes (loads only) and park every finished step as a
 // 50-byte descriptor in the wave's LDS queue: {context register, own bases, first record slot, ...}.
 // Phase B -- when the queue fills up or the walk is over, the wave expands the queue with one lane per
@@ -345,7 +191,9 @@ __global__ __launch_bounds__(256) void k_emit_boundary(DevGraph g, FindArgs a, c
 // retire in order through one counter, so a store inside the walk stalls the next dependent load.
 constexpr int EVQ = 128;            // step descriptors per wave queue (a walk round adds at most 64)
 
-template <int FMT>
+constexpr int NLQ = 6;              // all-nodes mode: node lists of up to NLQ nodes travel through the queue
+
+template <int FMT, bool ALL>
 struct EvQueue {
     uint64_t ctx[EVQ], own[EVQ];
     int64_t idx[EVQ], pos0[EVQ];
@@ -353,6 +201,8 @@ struct EvQueue {
     int32_t mn[EVQ], n[EVQ];
     uint32_t key[EVQ];           // (idx - min idx) << 8 | slot, sorted: the steps in output order
     uint8_t from[EVQ], cnt[EVQ];
+    uint8_t nl[ALL ? EVQ : 1];                 // all-nodes mode: number of distinct window nodes of the step ...
+    int32_t nodes[ALL ? EVQ : 1][NLQ];         // ... and the nodes, ascending (np.unique, kmer_finder.py:134)
 };
 
 __device__ int g_dbg_skip_expand = 0;     // diagnostics only (GKI_DBG_SKIP_EXPAND): phase A alone
@@ -362,8 +212,8 @@ __device__ int g_dbg_skip_expand = 0;     // diagnostics only (GKI_DBG_SKIP_EXPA
 // apart, and at ~5 TB/s of writes a 4-MB L2 turns over in ~6 us, so lines left half-written were flushed twice
 // (PMC: 11.4 GB written for 7.4 GB of records).  Sorting the <= 128 steps by their first record slot (bitonic sort
 // of packed keys in LDS) makes consecutive lanes write consecutive records.
-template <int FMT>
-__device__ __forceinline__ void expand_queue(EvQueue<FMT> &q, int n_ev, typename OutSel<FMT>::T out, int k, uint64_t kmask,
+template <int FMT, bool ALL>
+__device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, typename OutSel<FMT>::T out, int k, uint64_t kmask,
                                              int lane) {
     if (g_dbg_skip_expand == 1) return;
     static_assert(EVQ == 128, "two steps per lane");
@@ -398,10 +248,19 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT> &q, int n_ev, typename
         const int pos = i + half;
         if (pos < n_ev) {
             const int e = (int)(q.key[pos] & 0xFFu);
-            if (l < (int)q.cnt[e]) {
-                const int o = q.from[e] + l;
-                const uint64_t h = ((q.ctx[e] >> (2 * o)) | (q.own[e] << (2 * (k - 1 - o)))) & kmask;
-                put(out, q.idx[e] + l, h, q.mn[e], q.n[e], o, q.pos0[e] + o, q.maf[e]);
+            if (!ALL) {
+                if (l < (int)q.cnt[e]) {
+                    const int o = q.from[e] + l;
+                    const uint64_t h = ((q.ctx[e] >> (2 * o)) | (q.own[e] << (2 * (k - 1 - o)))) & kmask;
+                    put(out, q.idx[e] + l, h, q.mn[e], q.n[e], o, q.pos0[e] + o, q.maf[e]);
+                }
+            } else {                                   // one record per offset and distinct node, nodes ascending per offset
+                const int nl = (int)q.nl[e], total = (int)q.cnt[e] * nl;
+                for (int t = l; t < total; t += 32) {
+                    const int o = q.from[e] + t / nl;
+                    const uint64_t h = ((q.ctx[e] >> (2 * o)) | (q.own[e] << (2 * (k - 1 - o)))) & kmask;
+                    put(out, q.idx[e] + t, h, q.nodes[e][t % nl], q.n[e], o, q.pos0[e] + o, q.maf[e]);
+                }
             }
         }
     }
@@ -414,17 +273,18 @@ struct LevelEmit {               // a suspended level of the emit walk
     uint8_t cum, vc, evf, evt;
 };
 
-template <bool HAS_LOSSY, int FMT>
+template <bool HAS_LOSSY, int FMT, bool ALL>
 __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
                                                            const uint32_t *__restrict__ bcount,
                                                            const int64_t *__restrict__ rec_base,
                                                            const int64_t *__restrict__ bnd_shift,
                                                            typename OutSel<FMT>::T out, int *__restrict__ err) {
-    __shared__ EvQueue<FMT> s_q[4];
+    __shared__ EvQueue<FMT, ALL> s_q[4];
     LevelEmit below[MAXN];
+    int32_t path[ALL ? MAXN : 1];          // all-nodes mode: the node of every level of the walk (level 0 = the end node)
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    EvQueue<FMT> &q = s_q[wib];
+    EvQueue<FMT, ALL> &q = s_q[wib];
     const int k = a.k;
     const uint64_t kmask = (1ull << (2 * k)) - 1ull;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -461,19 +321,20 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                     t_cur = wn.rev_begin; t_end = wn.rev_end; t_cum = 0; t_vc = v0; t_evf = t_evt = 0; t_ctx = 0;
                     t_mn = (int32_t)n; t_maf = wn.af;
                     own = gki_extract(g.seq2, wn.seq_start, hi);
+                    if (ALL) path[0] = (int32_t)n;
                     L = 1;
                 }
             }
         }
         while (__any(L > 0)) {
             bool ev = false;
-            int e_from = 0, e_to = 0;
+            int e_from = 0, e_to = 0, e_nl = 0;          // e_nl: nodes of the window = levels 0 .. e_nl-1 of `path`
             int32_t e_mn = 0;
             uint64_t e_ctx = 0;
             double e_maf = 0.0;
             if (L > 0) {
                 if (t_cur >= t_end) {                       // leave the level: its own step comes after its subtree
-                    if (t_evf < t_evt) { ev = true; e_from = t_evf; e_to = t_evt; e_ctx = t_ctx; e_mn = t_mn; e_maf = t_maf; }
+                    if (t_evf < t_evt) { ev = true; e_from = t_evf; e_to = t_evt; e_ctx = t_ctx; e_mn = t_mn; e_maf = t_maf; e_nl = L; }
                     L--;
                     if (L > 0) {
                         const LevelEmit b = below[L - 1];
@@ -489,6 +350,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                             *err = GKI_ERR_WINDOW_TOO_DEEP;
                         } else {
                             const int s = wq.size, c = t_cum;
+                            if (ALL) path[L] = qn;
                             const int32_t mn = qn < t_mn ? qn : t_mn;
                             const double maf = fmin(t_maf, wq.af);               // np.min, kmer_finder.py:143
                             bool deeper;
@@ -516,17 +378,32 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                                 t_ctx = cx; t_mn = mn; t_maf = maf;
                                 L++;
                             } else if (from < to) {
-                                ev = true; e_from = from; e_to = to; e_ctx = cx; e_mn = mn; e_maf = maf;
+                                ev = true; e_from = from; e_to = to; e_ctx = cx; e_mn = mn; e_maf = maf; e_nl = L + 1;
                             }
                         }
                     }
                 }
             }
+            if (ALL && ev && e_nl > NLQ) {
+                // a window over more nodes than the queue carries (rows of empty or 1-bp nodes): written by the lane
+                // alone, per offset the distinct nodes ascending
+                for (int o = e_from; o < e_to; o++) {
+                    const uint64_t h = ((e_ctx >> (2 * o)) | (own << (2 * (k - 1 - o)))) & kmask;
+                    int32_t last = INT_MIN;
+                    for (int r = 0; r < e_nl; r++) {
+                        int32_t best = INT_MAX;
+                        for (int j2 = 0; j2 < e_nl; j2++) { const int32_t v = path[j2]; if (v > last && v < best) best = v; }
+                        put(out, idx++, h, best, (int32_t)n, o, pos0 + o, e_maf);
+                        last = best;
+                    }
+                }
+                ev = false;
+            }
             const uint64_t pending = __ballot(ev);
             if (pending) {
                 const int n_new = __popcll(pending);
                 if (n_ev + n_new > EVQ) {                    // wave-uniform: make room first
-                    expand_queue<FMT>(q, n_ev, out, k, kmask, lane);
+                    expand_queue<FMT, ALL>(q, n_ev, out, k, kmask, lane);
                     n_ev = 0;
                 }
                 if (ev) {
@@ -534,13 +411,23 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                     q.ctx[slot] = e_ctx; q.own[slot] = own; q.idx[slot] = idx; q.pos0[slot] = pos0;
                     q.maf[slot] = e_maf; q.mn[slot] = e_mn; q.n[slot] = (int32_t)n;
                     q.from[slot] = (uint8_t)e_from; q.cnt[slot] = (uint8_t)(e_to - e_from);
+                    if (ALL) {
+                        q.nl[slot] = (uint8_t)e_nl;
+                        for (int a2 = 0; a2 < e_nl; a2++) {            // rank sort: the nodes of a path are distinct
+                            const int32_t v = path[a2];
+                            int rank = 0;
+                            for (int b2 = 0; b2 < e_nl; b2++) rank += path[b2] < v ? 1 : 0;
+                            q.nodes[slot][rank] = v;
+                        }
+                        idx += (int64_t)(e_to - e_from) * e_nl;
+                    } else
                     idx += e_to - e_from;
                 }
                 n_ev += n_new;
             }
         }
     }
-    if (n_ev > 0) expand_queue<FMT>(q, n_ev, out, k, kmask, lane);
+    if (n_ev > 0) expand_queue<FMT, ALL>(q, n_ev, out, k, kmask, lane);
 }
 
 // ------------------------------------------------------------------------------------ per-node constants
@@ -745,11 +632,11 @@ static int launch_boundary_fmt(gki_finder *f, const DevGraph &d, const FindArgs 
     const int64_t *base = a.split ? f->bnd_base : f->rec_base;
     const int64_t *shift = a.split ? f->rec_base + a.n1 : f->d_totals + 3;
     if (a.one_node) {
-        if (a.has_lossy) hipLaunchKernelGGL((k_emit_boundary_one<true, FMT>), grid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
-        else hipLaunchKernelGGL((k_emit_boundary_one<false, FMT>), grid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
+        if (a.has_lossy) hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, false>), grid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
+        else hipLaunchKernelGGL((k_emit_boundary_one<false, FMT, false>), grid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
     } else {
-        if (a.has_lossy) hipLaunchKernelGGL((k_emit_boundary<true, FMT>), grid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
-        else hipLaunchKernelGGL((k_emit_boundary<false, FMT>), grid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
+        if (a.has_lossy) hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, true>), grid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
+        else hipLaunchKernelGGL((k_emit_boundary_one<false, FMT, true>), grid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
     }
     HIP_TRY(hipGetLastError());
     return GKI_OK;
