@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
                 count += 1;
             }
             int hi = o_hi < k - 1 ? o_hi : k - 1;
-            if (HAS_LOSSY && cn >= 1 && cn < hi) hi = cn;
+            if (HAS_LOSSY && cn >= 0 && cn < hi) hi = cn;
             if (o_lo < hi) {
                 int32_t t_cur = wn.rev_begin, t_end = wn.rev_end;
                 int t_cum = 0, t_vc = v0;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
                         const int cq = HAS_LOSSY ? lossy_of(lossy, q) : -1;
                         if (HAS_LOSSY && cq >= 0) { const int min_ok = k - 1 - c - s + cq; if (from < min_ok) from = min_ok; }
                         if (from < to) count += (uint32_t)(to - from) * (a.one_node ? 1u : (uint32_t)(L + 1));
-                        deeper = (k - 1 - c - s > o_lo) && !(HAS_LOSSY && cq >= 1);
+                        deeper = (k - 1 - c - s > o_lo) && !(HAS_LOSSY && cq >= 0);
                         new_cum = c + s;
                     }
                     if (deeper) {
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                     put(out, idx++, gki_extract(g.seq2, wn.seq_start + o + 1 - k, k), (int32_t)n, (int32_t)n, o, pos0 + o, wn.af);
                 }
                 hi = o_hi < k - 1 ? o_hi : k - 1;
-                if (HAS_LOSSY && cn >= 1 && cn < hi) hi = cn;
+                if (HAS_LOSSY && cn >= 0 && cn < hi) hi = cn;
                 if (o_lo < hi) {
                     t_cur = wn.rev_begin; t_end = wn.rev_end; t_cum = 0; t_vc = v0; t_evf = t_evt = 0; t_ctx = 0;
                     t_mn = (int32_t)n; t_maf = wn.af;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                                 if (HAS_LOSSY && cq >= 0) { const int min_ok = k - 1 - c - s + cq; if (from < min_ok) from = min_ok; }
                                 const int tq = s < k - 1 - c ? s : k - 1 - c;
                                 cx = t_ctx | (gki_extract(g.seq2, wq.seq_start + s - tq, tq) << (2 * (k - 1 - c - tq)));
-                                deeper = (k - 1 - c - s > o_lo) && !(HAS_LOSSY && cq >= 1);
+                                deeper = (k - 1 - c - s > o_lo) && !(HAS_LOSSY && cq >= 0);
                                 new_cum = c + s;
                             }
                             if (deeper) {

@@ -62,14 +62,20 @@ def _check_supported_graph(g, k):
             raise NotImplementedError("chromosome start node %d is shorter than k" % s)
 
 
-def lossy_table(g, k, crit_nodes, crit_offsets):
-    """uint16[n_nodes] of critical offsets c with 0 < c < k-1 (SURVEY.md 8a' E1), or None."""
+def lossy_table(g, k, crit_nodes, crit_offsets, start_at=None, stop_at=None):
+    """uint16[n_nodes] of critical offsets c with 0 < c < k-1 (SURVEY.md 8a' E1), or None.  Raises for the critical
+    points THIS run restarts from (numbers [start_at, stop_at), kmer_finder.py:192-205) at which the reference's output
+    is undefined."""
     c = np.asarray(crit_offsets).astype(np.int64)
     n = np.asarray(crit_nodes).astype(np.int64)
     sel = (c > 0) & (c < k - 1)
     if not np.any(sel):
         return None
-    undefined = sel & (c >= 3) & (g.node_size[n] > 2 * k + 3)
+    number = np.arange(len(c))
+    if start_at is not None and stop_at is not None and start_at > stop_at:
+        stop_at = None                               # the stop point is already behind the run: never met (:220)
+    restarted = (number >= (0 if start_at is None else start_at)) & (number < (len(c) if stop_at is None else stop_at))
+    undefined = sel & restarted & (c >= 3) & (g.node_size[n] > 2 * k + 3)
     if np.any(undefined):
         raise ValueError(
             "critical point (%d, %d): a single-edge chain of %d bases precedes a node longer than 2k+3; the "
@@ -160,8 +166,14 @@ class DenseKmerFinder:
         cp = self._critical_graph_paths
         crit_nodes = np.asarray(cp.nodes).astype(np.int64)
         crit_offsets = np.asarray(cp.offsets).astype(np.int64)
-        lossy = lossy_table(g, k, crit_nodes, crit_offsets)
         start_at, stop_at = self._start_at_critical_path_number, self._stop_at_critical_path_number
+        lossy = lossy_table(g, k, crit_nodes, crit_offsets, start_at, stop_at)
+        if start_at is not None and 0 < start_at < len(crit_nodes) and crit_offsets[start_at] == 0:
+            # A run that STARTS at a critical point at offset 0 is not rewound either (:231-232): none of its windows
+            # reaches before that node.  (In a full run the previous search passes through the point and emits them.)
+            if lossy is None:
+                lossy = np.full(g.n_nodes, 0xFFFF, dtype=np.uint16)
+            lossy[int(crit_nodes[start_at])] = 0
         node_begin, off_begin, node_end, off_end = 0, 0, g.n_nodes, 0
         n_crit = len(crit_nodes)
         chunked = False
@@ -174,7 +186,19 @@ class DenseKmerFinder:
         if stop_at is not None and stop_at < n_crit:                  # :193-194
             if not (start_at is not None and start_at > stop_at):     # stop node already behind us: never met (:220)
                 chunked = True
+                # The last search of the run ends where it SEES a critical position ahead (`is_critical(node,
+                # offset + 1)`, :334-341), which a critical point at offset 0 never is: the run passes through it and
+                # ends at the next critical point with offset >= 1 (its records then overlap the next chunk's).
                 node_end, off_end = int(crit_nodes[stop_at]), int(crit_offsets[stop_at])
+                from_graph_start = (start_at or 0) == 0 and g.node_size[g.first_node] <= k \
+                    and g.first_node != node_end                      # the extra starting point of :208-211
+                if ((start_at or 0) < stop_at or from_graph_start) and off_end == 0:     # (an empty run stays empty)
+                    later = np.nonzero(crit_offsets[stop_at:] >= 1)[0]
+                    if len(later):
+                        stop_seen = stop_at + int(later[0])
+                        node_end, off_end = int(crit_nodes[stop_seen]), int(crit_offsets[stop_seen])
+                    else:
+                        node_end, off_end = g.n_nodes, 0              # no critical point is seen any more
         if chunked and len(g.edges):
             if "_ids_increase_along_edges" not in g.__dict__:
                 src = np.repeat(np.arange(g.n_nodes), np.diff(g.edge_start))

@@ -16,7 +16,13 @@ def critical_path_cuts(graph_arrays, critical_paths, n_shards):
     total = int(graph_arrays.seq_start[-1])
     targets = (np.arange(1, n_shards) * (total / n_shards)).astype(np.int64)
     cuts = np.searchsorted(pos, targets, side="left")
-    return [0] + [int(c) for c in cuts] + [n_crit]
+    # Never cut at a critical point at offset 0: the reference's run before it passes through such a point and the run
+    # starting there is not rewound, so the two chunks would overlap (kmer_finder.py:231-232, 334-341) -- shards must
+    # partition the records.  Move the cut to the next critical point with offset >= 1.
+    offsets = np.asarray(critical_paths.offsets).astype(np.int64)
+    seen = np.concatenate([np.nonzero(offsets >= 1)[0], [n_crit]])
+    cuts = [int(seen[np.searchsorted(seen, c, side="left")]) for c in cuts]
+    return [0] + cuts + [n_crit]
 
 
 def shard_range(graph_arrays, critical_paths, rank, world_size):

@@ -107,6 +107,30 @@ def toy_cases():
             add("rand_chunk_%d_%d_%d" % (i, a, b), seqs, edges, lin, k,
                 start_at_critical_path_number=a, stop_at_critical_path_number=b,
                 only_save_one_node_per_kmer=True, max_variant_nodes=5)
+    # critical points at offset 0 (a single-edge chain of exactly k-1 bases before a critical node): the run before such a
+    # point passes through it, the run starting there is not rewound (kmer_finder.py:231-232, 334-341) -- every chunk
+    # [a, b) of two such graphs
+    rng0 = np.random.default_rng(77)
+    letters = "ACGT"
+
+    def rand(n):
+        return "".join(letters[i] for i in rng0.integers(0, 4, size=n))
+    for gi, (k, sizes) in enumerate([(23, [22, 22, 1, 1, 77, 2, 0, 27]), (4, [3, 5, 1, 1, 9, 1, 0, 3, 6])]):
+        if gi == 0:
+            edges = {0: [1], 1: [3, 2], 2: [4], 3: [4], 4: [6, 5], 5: [7], 6: [7]}
+            lin = [0, 1, 2, 4, 5, 7]
+        else:
+            edges = {0: [1], 1: [2, 3], 2: [4], 3: [4], 4: [5, 6], 5: [7], 6: [7], 7: [8]}
+            lin = [0, 1, 2, 4, 5, 7, 8]
+        seqs = {n: rand(sz) for n, sz in enumerate(sizes)}
+        g = Graph.from_dicts(seqs, edges, lin)
+        n_crit = len(CriticalGraphPaths.from_graph(g, k))
+        for a in range(n_crit + 1):
+            for b in range(a, n_crit + 1):
+                for one in (True, False):
+                    add("chunk_offset0_%d_%d_%d_%d" % (gi, a, b, int(one)), seqs, edges, lin, k,
+                        start_at_critical_path_number=a, stop_at_critical_path_number=b,
+                        only_save_one_node_per_kmer=one, max_variant_nodes=2)
     return cases
 
 

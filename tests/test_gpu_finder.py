@@ -203,7 +203,7 @@ def test_chunked_find_partitions_the_records():
 
 def test_golden_chunk_cases():
     for case in TOY:
-        if not case["name"].startswith("rand_chunk_"):
+        if not case["name"].startswith(("rand_chunk_", "chunk_offset0_")):
             continue
         g = graph_of(case)
         f = DenseKmerFinder(g, case["k"], **case["kw"])
