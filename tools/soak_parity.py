@@ -33,11 +33,100 @@ def make_graph(rng, k):
                                        p_del=float(rng.uniform(0, 0.4)), p_ins=float(rng.uniform(0, 0.4)))
 
 
+def soak_forward(args):
+    """find_only_kmers_starting_at_position (batched), reference order, with only_follow / only_store node sets."""
+    t_end = time.time() + args.seconds
+    it = checked = 0
+    while time.time() < t_end:
+        seed = args.seed * 1_000_003 + it
+        it += 1
+        rng = np.random.default_rng(seed)
+        k = int(rng.integers(2, 32))
+        M = int(rng.choice([0, 1, 2, 3, 4, 5, 100]))
+        one = bool(rng.integers(0, 2))
+        try:
+            mode, g = make_graph(rng, k)
+        except AssertionError:
+            continue
+        kw = {}
+        if rng.random() < 0.5:
+            variant = np.nonzero(g.is_ref == 0)[0]
+            if len(variant):
+                chosen = set(int(x) for x in rng.choice(variant, size=min(len(variant), int(rng.integers(1, 4))), replace=False))
+                kw = dict(only_store_nodes=chosen, only_follow_nodes=chosen) if rng.random() < 0.5 else dict(only_follow_nodes=chosen)
+        nodes = rng.integers(0, g.n_nodes, size=16)
+        offs = [int(rng.integers(0, max(1, g.node_size[n]))) for n in nodes]
+        try:
+            exp = [oracle.find_from_position(g, k, int(n), int(o), one, M, **kw) for n, o in zip(nodes, offs)]
+        except oracle.OracleError:
+            continue
+        exp = {key: np.concatenate([e[key] for e in exp]) for key in exp[0]}
+        f = DenseKmerFinder(g, k, only_save_one_node_per_kmer=one, max_variant_nodes=M, **kw)
+        try:
+            f.find_kmers_starting_at_positions(nodes, offs)
+        except NotImplementedError:
+            continue
+        try:
+            assert_same_records(finder_cols(f), exp, exact_order=True)
+        except AssertionError as e:
+            print("MISMATCH forward: seed %d %s k=%d M=%d one=%s %s" % (seed, mode, k, M, one, kw), e); sys.exit(1)
+        f.close()
+        checked += 1
+    print("soak forward ok: %d graphs x 16 start positions" % checked)
+
+
+def soak_index(args):
+    """from_flat_kmers element-wise against the oracle's stable build; get / batched getters against loops of get."""
+    from graph_kmer_index_amd import CollisionFreeKmerIndex, FlatKmers
+    t_end = time.time() + args.seconds
+    it = 0
+    while time.time() < t_end:
+        seed = args.seed * 1_000_003 + it
+        it += 1
+        rng = np.random.default_rng(seed)
+        n = int(rng.integers(1, 30000))
+        modulo = int(rng.choice([1, 2, 3, 97, 1009, 65537, 452930477]))
+        pool = rng.integers(0, 4 ** int(rng.integers(1, 32)), size=int(rng.integers(1, n + 1)), dtype=np.int64)
+        kmers = pool[rng.integers(0, len(pool), size=n)]
+        nodes = rng.integers(0, 1000, size=n).astype(np.uint32)
+        refs = rng.integers(0, int(rng.integers(1, 50)), size=n).astype(np.uint64)
+        af = rng.random(n).astype(np.float32)
+        skip_freq, skip_single = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        desc = "seed %d n=%d modulo=%d skip_freq=%s skip_singletons=%s" % (seed, n, modulo, skip_freq, skip_single)
+        idx = CollisionFreeKmerIndex.from_flat_kmers(FlatKmers(kmers, nodes, refs, af), modulo=modulo, skip_frequencies=skip_freq,
+                                                     skip_singletons=skip_single)
+        orc = oracle.index_build(kmers, nodes, refs, af, modulo=modulo, skip_frequencies=skip_freq, skip_singletons=skip_single)
+        for name in ("_hashes_to_index", "_n_kmers", "_kmers", "_nodes", "_ref_offsets", "_allele_frequencies"):
+            if not np.array_equal(np.asarray(getattr(idx, name)).astype(np.int64) if name != "_allele_frequencies" else getattr(idx, name),
+                                  np.asarray(orc[name]).astype(np.int64) if name != "_allele_frequencies" else orc[name]):
+                print("MISMATCH index build", name, desc); sys.exit(1)
+        if not skip_freq and not np.array_equal(idx._frequencies, orc["_frequencies"]):
+            print("MISMATCH frequencies", desc); sys.exit(1)
+        queries = np.concatenate([pool[rng.integers(0, len(pool), size=200)], rng.integers(0, 4 ** 31, size=50, dtype=np.int64)])
+        max_hits = int(rng.choice([1, 2, 10, 2 ** 62]))
+        got_nodes, got_refs, got_q, got_af = idx.get_nodes_and_ref_offsets_from_multiple_kmers(queries.astype(np.uint64), max_hits=max_hits) \
+            if hasattr(idx, "get_nodes_and_ref_offsets_from_multiple_kmers") else (None,) * 4
+        e_nodes, e_refs = [], []
+        for q in queries:
+            r = oracle.index_get(orc, int(q), max_hits)
+            if r[0] is not None:
+                e_nodes.append(np.asarray(r[0])); e_refs.append(np.asarray(r[1]))
+        e_nodes = np.concatenate(e_nodes) if e_nodes else np.zeros(0, np.uint32)
+        e_refs = np.concatenate(e_refs) if e_refs else np.zeros(0, np.uint64)
+        if got_nodes is not None and not (np.array_equal(np.asarray(got_nodes).astype(np.int64), e_nodes.astype(np.int64))
+                                          and np.array_equal(np.asarray(got_refs).astype(np.int64), e_refs.astype(np.int64))):
+            print("MISMATCH batched get", desc, "max_hits", max_hits); sys.exit(1)
+    print("soak index ok: %d indexes" % it)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--what", choices=["find", "forward", "index"], default="find")
     args = ap.parse_args()
+    if args.what != "find":
+        return {"forward": soak_forward, "index": soak_index}[args.what](args)
     t_end = time.time() + args.seconds
     it = checked = refused = 0
     while time.time() < t_end:
