@@ -199,26 +199,59 @@ __global__ __launch_bounds__(256) void k_probe_lookup(ProbeDev t, const uint64_t
 // the whitelist test of DenseKmerFinder._add_kmer / _process_whole_node (kmer_finder.py:130-132, 362-365).
 __global__ __launch_bounds__(256) void k_probe_contains(ProbeDev t, const uint64_t *__restrict__ queries, int64_t q,
                                                         uint8_t *__restrict__ flags) {
+    __shared__ uint4 s_cand[4][CQ];
+    __shared__ int64_t s_qi[4][CQ];
+    const int lane = threadIdx.x & 63;
+    uint4 *qe = s_cand[threadIdx.x >> 6];
+    int64_t *qi = s_qi[threadIdx.x >> 6];
+    int n_c = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += stride) {
-        const uint64_t km = queries[i];
-        const uint64_t b = bucket_of(t, km);
-        uint8_t found = 0;
-        if (b < t.n_buckets) {
-            const uint2 d = t.dir[b];
-            const uint32_t c16 = d.y & 0xFFFFu;
-            if (c16 != 0u && ((d.y >> 16) & fp_bit(km)) != 0u) {
-                const int64_t m = c16 == CNT_SAT ? (int64_t)t.nk[b] : (int64_t)c16;
-                for (int64_t j = d.x; j < (int64_t)d.x + m && !found; j++) {
+    // survivors of the directory word (~5 %) are parked and scanned 64 at a time, as in k_probe_kmers
+    auto drain = [&](bool all) {
+        __builtin_amdgcn_wave_barrier();
+        while (n_c >= 64 || (all && n_c > 0)) {
+            const int first = n_c >= 64 ? n_c - 64 : 0;
+            const int mine = first + lane;
+            if (mine < n_c) {
+                const uint4 e = qe[mine];
+                const uint64_t km = ((uint64_t)e.y << 32) | e.x;
+                bool found = false;
+                for (int64_t j = e.z; j < (int64_t)e.z + (int64_t)e.w && !found; j++) {
                     const uint4 r = t.rows[j];
-                    found = ((((uint64_t)r.y << 32) | r.x) == km) ? 1 : 0;
+                    found = (((uint64_t)r.y << 32) | r.x) == km;
                 }
+                if (found) flags[qi[mine]] = 1;
+            }
+            n_c = first;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (int64_t w0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); w0 < q; w0 += stride) {
+        const int64_t i = w0 + lane;
+        bool cand = false;
+        uint64_t km = 0;
+        uint32_t start = 0, cnt = 0;
+        if (i < q) {
+            km = queries[i];
+            flags[i] = 0;
+            const uint64_t b = bucket_of(t, km);
+            if (b < t.n_buckets) {
+                const uint2 d = t.dir[b];
+                cand = cand_of(t, km, b, d, cnt);
+                start = d.x;
             }
         }
-        flags[i] = found;
+        const uint64_t m = __ballot(cand);
+        if (cand) {
+            const int slot = n_c + __popcll(m & ((1ull << lane) - 1ull));
+            qe[slot] = make_uint4((uint32_t)km, (uint32_t)(km >> 32), start, cnt);
+            qi[slot] = i;
+        }
+        n_c += __popcll(m);
+        drain(false);
     }
+    drain(true);
 }
-
 
 // 32 low bits -> even bit positions
 __device__ __forceinline__ uint64_t spread32(uint64_t x) {
