@@ -47,21 +47,51 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(sample_bases, k, max_variant_nodes):
-    """The oracle (scalar C restatement of the reference's DFS, 1 core) on a down-scaled graph from the same
-    generator and seed -- a reported baseline, not the thing measured above."""
+_CPU = {}
+
+
+def _cpu_chunk(rng_):
+    from oracle import oracle
+    a, b = rng_
+    out = oracle.find(_CPU["g"], _CPU["k"], _CPU["crit"], True, _CPU["M"], start_at_critical_path_number=a,
+                      stop_at_critical_path_number=b)
+    return len(out["kmers"])
+
+
+def cpu_baseline(sample_bases, k, max_variant_nodes, cores):
+    """The oracle (scalar C restatement of the reference's DFS) on a down-scaled graph from the same generator and seed,
+    spread over `cores` processes the way the reference spreads its own work: contiguous ranges of critical-path
+    numbers (command_line_interface.py:588-614).  A reported baseline, not the thing measured below.  Runs BEFORE the
+    GPU is touched (the workers are forked)."""
+    import multiprocessing as mp
     from graph_kmer_index_amd.graph import synthetic_snp_graph
+    from graph_kmer_index_amd.sharding import critical_path_cuts
+    from graph_kmer_index_amd.critical_graph_paths import CriticalGraphPaths
     from oracle import oracle
     sites = max(1, sample_bases // 600)
     g = synthetic_snp_graph(sample_bases, sites, k=k, seed=1234)
     crit = oracle.critical_paths(g, k)
-    t0 = time.perf_counter()
-    out = oracle.find(g, k, crit, True, max_variant_nodes)
-    dt = time.perf_counter() - t0
-    n = len(out["kmers"])
-    return {"value": n / dt, "unit": "k-mers/s", "cores": 1, "kind": "port",
+    # many more chunks than processes: the DFS's visited set makes a chunk's cost superlinear in its size, and small
+    # chunks balance the load
+    cuts = critical_path_cuts(g, CriticalGraphPaths(crit[0], crit[1]), 16 * cores)
+    chunks = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+    _CPU.update(g=g, k=k, crit=crit, M=max_variant_nodes)
+    if cores > 1:
+        with mp.get_context("fork").Pool(cores) as pool:
+            pool.map(_cpu_chunk, chunks[:cores], chunksize=1)          # untimed: workers up, graph pages touched
+            t0 = time.perf_counter()
+            counts = pool.map(_cpu_chunk, chunks, chunksize=1)
+            dt = time.perf_counter() - t0
+    else:
+        t0 = time.perf_counter()
+        counts = [_cpu_chunk(c) for c in chunks]
+        dt = time.perf_counter() - t0
+    n = int(sum(counts))
+    _CPU.clear()
+    return {"value": n / dt, "unit": "k-mers/s", "cores": cores, "kind": "port",
             "sample": "oracle/gki_oracle.c DenseKmerFinder restatement (find + v2 columns), same generator/seed, "
-                      "%d ref bases + %d SNP bubbles, %d records in %.1f s" % (sample_bases, sites, n, dt)}
+                      "%d ref bases + %d SNP bubbles, %d records in %.1f s wall on %d processes (critical-path chunks)"
+                      % (sample_bases, sites, n, dt, cores)}
 
 
 def main():
@@ -73,7 +103,8 @@ def main():
     ap.add_argument("--sites", type=float, default=5e6, help="SNP bubbles")
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--max-variant-nodes", type=int, default=5)      # CLI `index` default, command_line_interface.py:637
-    ap.add_argument("--cpu-sample-bases", type=float, default=2e8)     # ~13 s of one host core
+    ap.add_argument("--cpu-sample-bases", type=float, default=6e8)     # ~20 CPU-seconds on the GPU box
+    ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the CPU baseline (0: the host's share, at most 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--linear", action="store_true", help="diagnostic: linear chain graph without variants (BASELINE configs[1] shape)")
     ap.add_argument("--indels", type=float, default=0.0, help="diagnostic: this fraction of the sites each become 1-bp "
@@ -88,6 +119,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log("WORLD_SIZE=%d but --gpus=%d; using WORLD_SIZE" % (world, args.gpus))
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:       # N=1 only, and before anything touches the GPU
+        cores = args.cpu_cores or min(16, len(os.sched_getaffinity(0)))
+        cpu = cpu_baseline(int(args.cpu_sample_bases), args.k, args.max_variant_nodes, cores)
+        log("cpu baseline: %.3g k-mers/s on %d cores" % (cpu["value"], cpu["cores"]))
     dist = None
     if world > 1:
         import torch.distributed as dist            # gloo: barrier + max of a scalar only
@@ -201,8 +237,7 @@ def main():
         }
         if checks is not None:
             res["verify"] = checks
-        if not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(int(args.cpu_sample_bases), k, args.max_variant_nodes)
+        res["cpu_baseline"] = cpu
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
