@@ -14,6 +14,16 @@ from gpu_util import assert_same_records, finder_cols
 from oracle import oracle
 
 
+_last = [time.time()]
+
+
+def progress(msg):
+    """one line a minute: a silent GPU job is taken to be hung"""
+    if time.time() - _last[0] > 45:
+        _last[0] = time.time()
+        print(msg, flush=True)
+
+
 def make_graph(rng, k):
     mode = rng.choice(["bubble", "overlap", "chain", "indel"])
     if mode == "bubble":
@@ -40,6 +50,7 @@ def soak_forward(args):
     while time.time() < t_end:
         seed = args.seed * 1_000_003 + it
         it += 1
+        progress("... %d drawn, %d compared" % (it, checked))
         rng = np.random.default_rng(seed)
         k = int(rng.integers(2, 32))
         M = int(rng.choice([0, 1, 2, 3, 4, 5, 100]))
@@ -83,6 +94,7 @@ def soak_index(args):
     while time.time() < t_end:
         seed = args.seed * 1_000_003 + it
         it += 1
+        progress("... %d indexes" % it)
         rng = np.random.default_rng(seed)
         n = int(rng.integers(1, 30000))
         modulo = int(rng.choice([1, 2, 3, 97, 1009, 65537, 452930477]))
@@ -132,6 +144,7 @@ def main():
     while time.time() < t_end:
         seed = args.seed * 1_000_003 + it
         it += 1
+        progress("... %d drawn, %d compared" % (it, checked))
         rng = np.random.default_rng(seed)
         k = int(rng.integers(2, 32))
         M = int(rng.choice([0, 1, 2, 3, 4, 5, 100]))
