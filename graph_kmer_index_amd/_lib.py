@@ -46,6 +46,7 @@ SYMBOLS = {
     "gki_memset": (_I32, [_P, _I32, _I64]),
     "gki_device_synchronize": (_I32, []),
     "gki_mem_info": (_I32, [C.POINTER(_I64), C.POINTER(_I64)]),
+    "gki_flag_repeated_kmers": (_I32, [_P, _I64, _P]),
     "gki_compact_flat": (_I32, [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I64, C.POINTER(_I64)]),
     "gki_column_checksum": (_I32, [_P, _I64, _I32, C.POINTER(_U64), C.POINTER(_U64)]),
     "gki_hash_sequence": (_I32, [_P, _I64, _I32, _P]),

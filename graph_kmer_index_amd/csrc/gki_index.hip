@@ -410,6 +410,22 @@ __global__ void k_part_starts(const uint32_t *__restrict__ keys, int64_t n, int 
     start[p] = lo;
 }
 
+// FlatKmers.get_new_without_singletons (flat_kmers.py:98-125): a record is kept iff an EARLIER record carries the same
+// hash.  After the stable sort by bucket the records of a bucket are in input order, so "earlier" = an earlier position
+// of the bucket's run; the flag goes back to the record's original position.
+__global__ __launch_bounds__(256) void k_flag_repeats(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ perm,
+                                                      const uint64_t *__restrict__ kmers, int64_t n,
+                                                      const int32_t *__restrict__ first_of_bucket, uint8_t *__restrict__ flags) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        const uint32_t me = perm[p];
+        const uint64_t km = kmers[me];
+        bool seen = false;
+        for (int64_t j = first_of_bucket[keys[p]]; j < p && !seen; j++) seen = kmers[perm[j]] == km;
+        flags[me] = seen ? 1 : 0;
+    }
+}
+
 // ------------------------------------------------------------------------------------ reverse index
 // ReverseKmerIndex.from_flat_kmers (reverse_kmer_index.py:47-60): records stably sorted by node,
 // nodes_to_index_positions[node] = first record (uint32), nodes_to_n_hashes[node] = run length (uint16, wraps
@@ -621,6 +637,51 @@ int gki_partition_by_bucket_range(const void *d_kmers, const void *d_nodes, cons
 done:
     for (int i = 0; i < 2; i++) { (void)gki_dev_free(keys[i]); (void)gki_dev_free(vals[i]); }
     (void)gki_dev_free(hist); (void)gki_dev_free(offs); (void)gki_dev_free(tmp); (void)gki_dev_free(rows); (void)gki_dev_free(pstart);
+#undef HIP_G
+    return rc;
+}
+
+int gki_flag_repeated_kmers(const void *d_kmers, int64_t n, void *d_flags) {
+    if (n <= 0) return GKI_OK;
+    if (n >= (1ll << 31)) return gki_set_error(GKI_ERR_OVERFLOW, "%lld records: at most 2^31-1 at a time", (long long)n);
+    // a bucket table about twice as large as the input keeps the runs short; its size only has to be odd-ish
+    uint64_t modulo = (uint64_t)n * 2 + 1;
+    if (modulo > 0xFFFFFFFBull) modulo = 0xFFFFFFFBull;
+    hipStream_t s = 0;
+    const int64_t hist_n = (int64_t)RBINS * ceil_div(n, RTILE);
+    const int64_t tmp_bytes = gki_scan_tmp_bytes(hist_n);
+    uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *hist = nullptr, *offs = nullptr, *cnt = nullptr;
+    int32_t *first = nullptr;
+    void *tmp = nullptr;
+    int rc = GKI_OK;
+#define HIP_G(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = gki_set_error(GKI_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); goto done; } } while (0)
+    {
+        for (int i = 0; i < 2; i++) {
+            HIP_G(gki_dev_malloc((void **)&keys[i], (size_t)n * 4));
+            HIP_G(gki_dev_malloc((void **)&vals[i], (size_t)n * 4));
+        }
+        HIP_G(gki_dev_malloc((void **)&hist, (size_t)hist_n * 4));
+        HIP_G(gki_dev_malloc((void **)&offs, (size_t)(hist_n + 1) * 4));
+        HIP_G(gki_dev_malloc(&tmp, (size_t)tmp_bytes));
+        HIP_G(gki_dev_malloc((void **)&first, (size_t)modulo * 4));
+        HIP_G(gki_dev_malloc((void **)&cnt, (size_t)modulo * 4));
+        int *bad = (int *)hist;
+        hipLaunchKernelGGL(k_bucket_keys, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const uint64_t *)d_kmers, n, modulo,
+                           (uint64_t)0, modulo, keys[0], vals[0], bad);
+        HIP_G(hipGetLastError());
+        int cur = 0;
+        rc = radix_sort_pairs(keys, vals, n, key_bits(modulo - 1), hist, offs, tmp, tmp_bytes, s, &cur);
+        if (rc != GKI_OK) goto done;
+        hipLaunchKernelGGL(k_directory, dim3(stream_grid(n, 256)), dim3(256), 0, s, keys[cur], n, first, cnt);
+        HIP_G(hipGetLastError());
+        hipLaunchKernelGGL(k_flag_repeats, dim3(stream_grid(n, 256)), dim3(256), 0, s, keys[cur], vals[cur],
+                           (const uint64_t *)d_kmers, n, first, (uint8_t *)d_flags);
+        HIP_G(hipGetLastError());
+        HIP_G(hipStreamSynchronize(s));
+    }
+done:
+    for (int i = 0; i < 2; i++) { (void)gki_dev_free(keys[i]); (void)gki_dev_free(vals[i]); }
+    (void)gki_dev_free(hist); (void)gki_dev_free(offs); (void)gki_dev_free(tmp); (void)gki_dev_free(first); (void)gki_dev_free(cnt);
 #undef HIP_G
     return rc;
 }

@@ -114,6 +114,14 @@ class DeviceFlatKmers:
                    _lib.DeviceArray.from_host(np.asarray(flat._ref_offsets).astype(np.uint64)),
                    _lib.DeviceArray.from_host(np.asarray(flat._allele_frequencies).astype(np.float32)))
 
+    def get_new_without_singletons(self):
+        """flat_kmers.py:98-125 on the device: the 2nd and later occurrences of every hash, original order."""
+        flags = _lib.DeviceArray(max(self.n, 1), np.uint8)
+        _lib.check(_lib.load().gki_flag_repeated_kmers(self.hashes.ptr, self.n, flags.ptr))
+        out = self.compacted(flags)
+        flags.free()
+        return out
+
     def compacted(self, flags):
         """Records whose flag (DeviceArray uint8, one per record) is set, order kept (gki_compact_flat)."""
         import ctypes as C

@@ -53,6 +53,9 @@ int gki_mem_info(int64_t *free_bytes, int64_t *total_bytes);
 /* Order-independent checksums of a device column of n elements of 1, 2, 4 or 8 bytes (zero-extended): sum mod 2^64 and
  * xor.  Lets a caller check that two layouts / a set of shards hold the same multiset without copying it back. */
 int gki_column_checksum(const void *d_column, int64_t n, int elem_bytes, uint64_t *sum, uint64_t *xor_fold);
+/* FlatKmers.get_new_without_singletons (flat_kmers.py:98-125): d_flags uint8[n] = 1 for every record whose hash also
+ * occurs at an earlier position (the first occurrence of each hash gets 0); follow with gki_compact_flat. */
+int gki_flag_repeated_kmers(const void *d_kmers, int64_t n, void *d_flags);
 /* Stable compaction of FlatKmers columns: keeps record i iff d_flags[i] (uint8) != 0.  Output columns sized by the
  * caller (out_capacity records; the number of set flags is gki_column_checksum's sum for flags of 0/1). */
 int gki_compact_flat(const void *d_flags, int64_t n, const void *d_hashes, const void *d_nodes, const void *d_ref_offsets,

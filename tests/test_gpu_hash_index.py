@@ -452,3 +452,25 @@ def test_lookup_positions_probe_table_equals_reference_layout():
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
         assert len(a[1]) > 0
+
+
+def test_without_singletons_on_device_and_skip_singletons_build():
+    from graph_kmer_index_amd import DeviceFlatKmers
+    rng = np.random.default_rng(29)
+    for n, distinct in [(1, 1), (50000, 20000), (80000, 300), (30000, 30000)]:
+        pool = rng.integers(0, 4 ** 31, size=distinct, dtype=np.uint64)
+        flat = FlatKmers(pool[rng.integers(0, distinct, size=n)], rng.integers(0, 999, size=n).astype(np.uint32),
+                         np.arange(n, dtype=np.uint64), rng.random(n).astype(np.float32))
+        want = flat.get_new_without_singletons()
+        keep = oracle.without_singletons(flat._hashes)
+        assert np.array_equal(want._hashes, flat._hashes[keep])                 # host method == oracle
+        d = DeviceFlatKmers.from_flat_kmers(flat)
+        got = d.get_new_without_singletons().to_flat_kmers()
+        for name in ("_hashes", "_nodes", "_ref_offsets", "_allele_frequencies"):
+            assert np.array_equal(getattr(got, name), getattr(want, name)), (n, distinct, name)
+        if n > 1:
+            a = CollisionFreeKmerIndex.from_flat_kmers(d, modulo=10007, skip_singletons=True)
+            b = oracle.index_build(flat._hashes, flat._nodes, flat._ref_offsets, flat._allele_frequencies, modulo=10007,
+                                   skip_singletons=True)
+            assert np.array_equal(a._kmers, b["_kmers"]) and np.array_equal(a._frequencies, b["_frequencies"])
+            assert np.array_equal(a._hashes_to_index, b["_hashes_to_index"])
