@@ -55,11 +55,14 @@ def index(args):
                              only_save_one_node_per_kmer=True, whitelist=whitelist)      # :559-565
     dflat = finder.find_flat_on_device(split_layout=False)      # with a whitelist: membership probe + compaction in HBM
     finder.synchronize()
+    if args.include_reverse_complement:                                                    # :616-620, still in HBM
+        from .flat_kmers import DeviceFlatKmers
+        both = DeviceFlatKmers.from_multiple_flat_kmers([dflat, dflat.get_reverse_complement_flat_kmers(k)])
+        dflat.free()
+        dflat = both
     flat = dflat.to_flat_kmers()
     dflat.free()
     logging.info("N kmers in flat kmers: %d" % len(flat._hashes))
-    if args.include_reverse_complement:                                                    # :616-620
-        flat = FlatKmers.from_multiple_flat_kmers([flat, flat.get_reverse_complement_flat_kmers(k)])
     flat.to_file(args.out_file_name)
 
 

@@ -114,6 +114,28 @@ class DeviceFlatKmers:
                    _lib.DeviceArray.from_host(np.asarray(flat._ref_offsets).astype(np.uint64)),
                    _lib.DeviceArray.from_host(np.asarray(flat._allele_frequencies).astype(np.float32)))
 
+    def get_reverse_complement_flat_kmers(self, k):
+        """flat_kmers.py:127-131 on the device: reverse-complemented hashes, the other columns shared (views)."""
+        out = _lib.DeviceArray(max(self.n, 1), np.uint64)
+        _lib.check(_lib.load().gki_reverse_complement(self.hashes.ptr, self.n, int(k), out.ptr))
+        return DeviceFlatKmers(self.n, out, self.nodes.view(0, self.n), self.ref_offsets.view(0, self.n),
+                               self.allele_frequencies.view(0, self.n))
+
+    @classmethod
+    def from_multiple_flat_kmers(cls, parts):
+        """flat_kmers.py:71-90: concatenation, in HBM."""
+        total = sum(p.n for p in parts)
+        out = cls.allocate(total)
+        at = 0
+        lib = _lib.load()
+        for p in parts:
+            for src, dst in ((p.hashes, out.hashes), (p.nodes, out.nodes), (p.ref_offsets, out.ref_offsets),
+                             (p.allele_frequencies, out.allele_frequencies)):
+                if p.n:
+                    _lib.check(lib.gki_memcpy_d2d(dst.view(at, p.n).ptr, src.ptr, p.n * src.dtype.itemsize))
+            at += p.n
+        return out
+
     def get_new_without_singletons(self):
         """flat_kmers.py:98-125 on the device: the 2nd and later occurrences of every hash, original order."""
         flags = _lib.DeviceArray(max(self.n, 1), np.uint8)

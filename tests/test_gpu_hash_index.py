@@ -474,3 +474,17 @@ def test_without_singletons_on_device_and_skip_singletons_build():
                                    skip_singletons=True)
             assert np.array_equal(a._kmers, b["_kmers"]) and np.array_equal(a._frequencies, b["_frequencies"])
             assert np.array_equal(a._hashes_to_index, b["_hashes_to_index"])
+
+
+def test_device_flat_kmers_reverse_complement_and_concatenation():
+    from graph_kmer_index_amd import DeviceFlatKmers
+    rng = np.random.default_rng(30)
+    n = 20000
+    flat = FlatKmers(rng.integers(0, 4 ** 31, size=n, dtype=np.uint64), rng.integers(0, 99, size=n).astype(np.uint32),
+                     np.arange(n, dtype=np.uint64), rng.random(n).astype(np.float32))
+    d = DeviceFlatKmers.from_flat_kmers(flat)
+    both = DeviceFlatKmers.from_multiple_flat_kmers([d, d.get_reverse_complement_flat_kmers(31)]).to_flat_kmers()
+    want = FlatKmers.from_multiple_flat_kmers([flat, flat.get_reverse_complement_flat_kmers(31)])
+    assert np.array_equal(want._hashes[n:], oracle.reverse_complement(flat._hashes, 31))
+    for name in ("_hashes", "_nodes", "_ref_offsets", "_allele_frequencies"):
+        assert np.array_equal(getattr(both, name), getattr(want, name)), name
