@@ -17,7 +17,8 @@ int gki_set_error(int code, const char *fmt, ...) {
 // alloc/free rounds of that size the third hipMalloc was measured at 4.3 s (the frees are deferred and paid then).  The
 // build and probe paths allocate their temporaries per call, so every buffer of the library goes through a cache of
 // freed blocks instead: gki_dev_free parks the block, gki_dev_malloc reuses a parked block of at least the requested
-// size and at most 1/8 more.  When the device runs out, the cache is released and the allocation retried.
+// size and at most 1/8 more.  At most half of the device's memory is parked; when the device runs out, the cache is
+// released and the allocation retried.
 // gki_trim() releases it on demand; GKI_POOL=0 disables the cache.
 #include <map>
 #include <mutex>
@@ -26,11 +27,18 @@ namespace {
 std::mutex g_pool_mu;
 std::multimap<size_t, void *> g_pool_free;          // parked blocks by size
 std::unordered_map<void *, size_t> g_pool_live;     // size of every block handed out
+size_t g_pool_cached = 0;                           // bytes parked
+size_t pool_cap() {                                 // park at most half of the device's memory (other libraries allocate too)
+    static size_t cap = 0;
+    if (!cap) { size_t f = 0, t = 0; cap = hipMemGetInfo(&f, &t) == hipSuccess ? t / 2 : (size_t)64 << 30; }
+    return cap;
+}
 bool pool_enabled() { static const bool on = !(getenv("GKI_POOL") && atoi(getenv("GKI_POOL")) == 0); return on; }
 void pool_trim() {
     std::lock_guard<std::mutex> lock(g_pool_mu);
     for (auto &kv : g_pool_free) (void)hipFree(kv.second);
     g_pool_free.clear();
+    g_pool_cached = 0;
 }
 }  // namespace
 
@@ -52,6 +60,7 @@ hipError_t gki_dev_malloc(void **ptr, size_t bytes) {
         if (it != g_pool_free.end() && it->first <= bytes + bytes / 8) {
             *ptr = it->second;
             g_pool_live[*ptr] = it->first;
+            g_pool_cached -= it->first;
             g_pool_free.erase(it);
             return hipSuccess;
         }
@@ -78,8 +87,11 @@ hipError_t gki_dev_free(void *ptr) {
         std::lock_guard<std::mutex> lock(g_pool_mu);
         auto it = g_pool_live.find(ptr);
         if (it != g_pool_live.end()) {
-            g_pool_free.emplace(it->second, ptr);
+            const size_t bytes = it->second;
             g_pool_live.erase(it);
+            if (g_pool_cached + bytes > pool_cap()) return hipFree(ptr);
+            g_pool_free.emplace(bytes, ptr);
+            g_pool_cached += bytes;
             return hipSuccess;
         }
     }
