@@ -131,14 +131,79 @@ def soak_index(args):
     print("soak index ok: %d indexes" % it)
 
 
+def soak_reads(args):
+    """map_reads (fused read hashing + probe + node histogram), partitioned index slices and ReverseKmerIndex against
+    the oracle / NumPy on random indexes and reads (N, lower case, ragged lengths)."""
+    from graph_kmer_index_amd import CollisionFreeKmerIndex, FlatKmers, ReverseKmerIndex, DeviceFlatKmers
+    from graph_kmer_index_amd.collision_free_kmer_index import PartitionedDeviceIndex
+    comp = str.maketrans("ACGTacgt", "TGCAtgca")
+    t_end = time.time() + args.seconds
+    it = 0
+    while time.time() < t_end:
+        seed = args.seed * 1_000_003 + it
+        it += 1
+        progress("... %d rounds" % it)
+        rng = np.random.default_rng(seed)
+        k = int(rng.integers(1, 32))
+        L = int(rng.integers(k + 5, 4000))
+        genome = "".join("ACGT"[i] for i in rng.integers(0, 4, size=L))
+        hashes = oracle.hash_sequence(oracle.letter_sequence_to_numeric(genome), k).astype(np.int64)
+        n = len(hashes)
+        nodes = rng.integers(0, int(rng.integers(1, 300)), size=n).astype(np.uint32)
+        n_nodes = int(nodes.max()) + 1
+        refs = rng.integers(0, 20, size=n).astype(np.uint64)
+        af = np.ones(n, np.float32)
+        modulo = int(rng.choice([1, 7, 101, 10007, 452930477]))
+        idx = CollisionFreeKmerIndex.from_flat_kmers(FlatKmers(hashes, nodes, refs, af), modulo=modulo)
+        orc = oracle.index_build(hashes, nodes, refs, af, modulo=modulo)
+        reads = []
+        for _ in range(int(rng.integers(1, 40))):
+            a = int(rng.integers(0, L))
+            r = list(genome[a:a + int(rng.integers(0, 260))])
+            for p in rng.integers(0, max(1, len(r)), size=int(rng.integers(0, 4))):
+                if r:
+                    r[int(p)] = "NnacgtRYACGT"[int(rng.integers(0, 12))]
+            s_ = "".join(r)
+            reads.append(s_.translate(comp)[::-1] if rng.random() < 0.5 else s_)
+        max_hits = int(rng.choice([1, 3, 2 ** 62]))
+        both = bool(rng.integers(0, 2))
+        exp = np.zeros(n_nodes, np.int64)
+        for r in reads:
+            for strand_read in ([r, r.translate(comp)[::-1]] if both else [r]):
+                for q in oracle.read_kmers(strand_read, k):
+                    got = oracle.index_get(orc, int(q), max_hits)[0]
+                    if got is not None:
+                        np.add.at(exp, np.asarray(got, np.int64), 1)
+        desc = "seed %d k=%d modulo=%d max_hits=%d both=%s" % (seed, k, modulo, max_hits, both)
+        got = idx.map_reads(reads, k, n_nodes, max_hits=max_hits, include_reverse_complement=both)
+        if not np.array_equal(got, exp):
+            print("MISMATCH map_reads", desc); sys.exit(1)
+        # partitioned slices count like the whole index
+        parts = PartitionedDeviceIndex.build(DeviceFlatKmers.from_flat_kmers(FlatKmers(hashes, nodes, refs, af)), modulo,
+                                             int(rng.integers(1, min(modulo, 9) + 1)))
+        enc = [r.encode() for r in reads]
+        start = np.concatenate([[0], np.cumsum([len(e) for e in enc])]).astype(np.int64)
+        letters = np.frombuffer(b"".join(enc), np.uint8) if start[-1] else np.zeros(1, np.uint8)
+        c, _, _ = parts.count_nodes_from_reads(letters, start, k, n_nodes, 3 if both else 1, max_hits)
+        if not np.array_equal(c.to_host(n_nodes), exp):
+            print("MISMATCH partitioned map_reads", desc); sys.exit(1)
+        parts.free()
+        # reverse index
+        rev = ReverseKmerIndex.from_flat_kmers(FlatKmers(hashes, nodes, refs, af))
+        order = np.argsort(nodes, kind="stable")
+        if not (np.array_equal(rev.hashes, hashes[order]) and np.array_equal(rev.ref_positions, refs[order])):
+            print("MISMATCH reverse index", desc); sys.exit(1)
+    print("soak reads ok: %d rounds" % it)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--what", choices=["find", "forward", "index"], default="find")
+    ap.add_argument("--what", choices=["find", "forward", "index", "reads"], default="find")
     args = ap.parse_args()
     if args.what != "find":
-        return {"forward": soak_forward, "index": soak_index}[args.what](args)
+        return {"forward": soak_forward, "index": soak_index, "reads": soak_reads}[args.what](args)
     t_end = time.time() + args.seconds
     it = checked = refused = 0
     while time.time() < t_end:
