@@ -251,6 +251,20 @@ def main():
             assert_same_records(finder_cols(f), full)
         except AssertionError as e:
             print("MISMATCH:", desc, mode, kw, "whitelist" if wl else "", e); sys.exit(1)
+        if rng.random() < 0.35 and wl is None:
+            # the FlatKmers emit path (other kernels' format, split and by-node layouts) holds the same records
+            pos = g.position_id_base()[full["start_nodes"]] + full["start_offsets"]
+            want = (full["kmers"].astype(np.uint64), full["nodes"].astype(np.uint32), pos.astype(np.uint64),
+                    full["allele_frequencies"].astype(np.float32))
+            ow = np.lexsort((want[3], want[1], want[0], want[2]))
+            for split in (False, True):
+                d = f.find_flat_on_device(split_layout=split)
+                fl = d.to_flat_kmers()
+                got = (fl._hashes, fl._nodes, fl._ref_offsets, fl._allele_frequencies)
+                og = np.lexsort((got[3], got[1], got[0], got[2]))
+                if len(got[0]) != len(want[0]) or not all(np.array_equal(a_[og], b_[ow]) for a_, b_ in zip(got, want)):
+                    print("MISMATCH flat layout split=%s:" % split, desc, mode, kw); sys.exit(1)
+                d.free()
         f.close()
         checked += 1
     print("soak ok: %d graphs compared, %d refused (undefined in the reference / unsupported), %d drawn" % (checked, refused, it))
