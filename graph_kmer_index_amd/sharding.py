@@ -9,13 +9,18 @@ def critical_path_cuts(graph_arrays, critical_paths, n_shards):
     """Cut points 0 = c_0 <= c_1 <= ... <= c_n = len(critical_paths): shard i runs critical-path numbers
     [c_i, c_{i+1}) (start_at/stop_at of DenseKmerFinder), balanced by the number of bases covered."""
     n_crit = len(critical_paths)
-    if n_shards <= 1 or n_crit == 0:
-        return [0] + [n_crit] * max(1, n_shards)
+    if n_shards <= 1:
+        return [0, n_crit]
+    if n_crit == 0:
+        # no critical point: the run from the graph start is everything; (1, 1) starts past the last point = nothing
+        return [0] + [1] * n_shards
     pos = graph_arrays.seq_start[np.asarray(critical_paths.nodes).astype(np.int64)] + \
         np.asarray(critical_paths.offsets).astype(np.int64)
     total = int(graph_arrays.seq_start[-1])
     targets = (np.arange(1, n_shards) * (total / n_shards)).astype(np.int64)
-    cuts = np.searchsorted(pos, targets, side="left")
+    # Only the first shard may start at critical path 0: a run with start 0 also owns the search from the graph start
+    # (kmer_finder.py:208-211), a second one would emit it again.
+    cuts = np.maximum(1, np.searchsorted(pos, targets, side="left"))
     # Never cut at a critical point at offset 0: the reference's run before it passes through such a point and the run
     # starting there is not rewound, so the two chunks would overlap (kmer_finder.py:231-232, 334-341) -- shards must
     # partition the records.  Move the cut to the next critical point with offset >= 1.

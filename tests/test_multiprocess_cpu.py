@@ -71,3 +71,40 @@ def test_cuts_cover_all_critical_points():
                                      stop_at_critical_path_number=b)["kmers"]) if w <= 3 else 0
         if w <= 3:
             assert total == len(oracle.find(g, 31, (cp.nodes, cp.offsets), True, 5)["kmers"])
+
+
+def test_shards_partition_small_graphs_with_few_or_offset0_critical_points():
+    # found by tools/soak_parity.py: no critical point at all, a first critical point far into the graph (several cuts
+    # at 0) and critical points at offset 0 (chunks that overlap in the reference) must not break the partition
+    from collections import Counter
+    from graph_kmer_index_amd.graph import GraphArrays
+    from graphgen import random_bubble_graph
+    rng = np.random.default_rng(5)
+    seen_no_crit = seen_offset0 = 0
+    for it in range(300):
+        k = int(rng.integers(2, 12))
+        nv = int(rng.integers(1, 6))
+        seqs, edges, lin, af = random_bubble_graph(rng, n_var=nv, min_ref=1, max_ref=int(rng.integers(2, 3 * k + 3)), p_indel=0.3,
+                                                   chain_after={int(rng.integers(-1, nv)): int(rng.integers(1, k + 2))})
+        g = GraphArrays.from_dicts(seqs, edges, lin, af)
+        try:
+            crit = oracle.critical_paths(g, k)
+            full, flags = oracle.find(g, k, crit, True, 4, return_flags=True)
+        except oracle.OracleError:
+            continue
+        if flags:
+            continue
+        cp = CriticalGraphPaths(crit[0], crit[1])
+        seen_no_crit += len(cp) == 0
+        seen_offset0 += bool(np.any(np.asarray(crit[1]) == 0))
+        for world in (2, 3, 6):
+            cuts = critical_path_cuts(g, cp, world)
+            assert len(cuts) == world + 1 and cuts[0] == 0 and all(x <= y for x, y in zip(cuts[:-1], cuts[1:]))
+            rows = Counter()
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                o = oracle.find(g, k, crit, True, 4, start_at_critical_path_number=a, stop_at_critical_path_number=b)
+                rows.update(zip(o["kmers"].tolist(), o["start_nodes"].tolist(), o["start_offsets"].tolist(), o["nodes"].tolist()))
+            want = Counter(zip(full["kmers"].tolist(), full["start_nodes"].tolist(), full["start_offsets"].tolist(),
+                               full["nodes"].tolist()))
+            assert rows == want, (it, k, world, cuts)
+    assert seen_no_crit > 0 and seen_offset0 > 0

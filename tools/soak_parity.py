@@ -265,6 +265,27 @@ def main():
                 if len(got[0]) != len(want[0]) or not all(np.array_equal(a_[og], b_[ow]) for a_, b_ in zip(got, want)):
                     print("MISMATCH flat layout split=%s:" % split, desc, mode, kw); sys.exit(1)
                 d.free()
+        if not kw and wl is None and rng.random() < 0.25:
+            # the multi-GPU shards (sharding.critical_path_cuts) partition the full run
+            from graph_kmer_index_amd.sharding import critical_path_cuts
+            world = int(rng.integers(2, 7))
+            cuts = critical_path_cuts(g, cp, world)
+            parts = []
+            try:
+                for a_, b_ in zip(cuts[:-1], cuts[1:]):
+                    fs = DenseKmerFinder(g, k, critical_graph_paths=cp, only_save_one_node_per_kmer=one, max_variant_nodes=M,
+                                         start_at_critical_path_number=a_, stop_at_critical_path_number=b_)
+                    fs.find()
+                    parts.append(finder_cols(fs))
+                    fs.close()
+            except NotImplementedError:
+                parts = None                                      # chunking needs node ids increasing along edges
+            if parts:
+                cat = {key: np.concatenate([p_[key] for p_ in parts]) for key in parts[0]}
+                try:
+                    assert_same_records(cat, full)
+                except AssertionError as e:
+                    print("MISMATCH shards do not partition the run:", desc, mode, "world", world, cuts, e); sys.exit(1)
         f.close()
         checked += 1
     print("soak ok: %d graphs compared, %d refused (undefined in the reference / unsupported), %d drawn" % (checked, refused, it))
