@@ -236,6 +236,10 @@ def main():
         if len(full["kmers"]) and rng.random() < 0.25:
             wl = set(int(x) for x in full["kmers"][rng.random(len(full["kmers"])) < 0.5])
             full = oracle.find(g, k, crit, one, M, whitelist=wl, **kw)
+        elif rng.random() < 0.15:
+            osn = set(int(x) for x in np.nonzero(rng.random(g.n_nodes) < 0.4)[0])
+            kw = dict(kw, only_store_nodes=osn)                   # kmer_finder.py:153 (the bulk path ignores it, :370-374)
+            full = oracle.find(g, k, crit, one, M, **kw)
         cp = CriticalGraphPaths(crit[0], crit[1])
         f = DenseKmerFinder(g, k, critical_graph_paths=cp, only_save_one_node_per_kmer=one, max_variant_nodes=M, whitelist=wl, **kw)
         try:
@@ -251,7 +255,7 @@ def main():
             assert_same_records(finder_cols(f), full)
         except AssertionError as e:
             print("MISMATCH:", desc, mode, kw, "whitelist" if wl else "", e); sys.exit(1)
-        if rng.random() < 0.35 and wl is None:
+        if rng.random() < 0.35 and wl is None and "only_store_nodes" not in kw:
             # the FlatKmers emit path (other kernels' format, split and by-node layouts) holds the same records
             pos = g.position_id_base()[full["start_nodes"]] + full["start_offsets"]
             want = (full["kmers"].astype(np.uint64), full["nodes"].astype(np.uint32), pos.astype(np.uint64),
