@@ -21,7 +21,8 @@ class GkiError(RuntimeError):
 class FindParams(C.Structure):
     _fields_ = [("k", C.c_int32), ("max_variant_nodes", C.c_int32), ("one_node_per_kmer", C.c_int32),
                 ("layout", C.c_int32), ("node_begin", C.c_int64), ("off_begin", C.c_int64),
-                ("node_end", C.c_int64), ("off_end", C.c_int64), ("h_lossy_crit", C.c_void_p)]
+                ("node_end", C.c_int64), ("off_end", C.c_int64), ("h_lossy_crit", C.c_void_p),
+                ("h_node_rank", C.c_void_p)]
 
 
 class IndexView(C.Structure):
@@ -58,6 +59,7 @@ SYMBOLS = {
     "gki_graph_prepare": (_I32, [_P]),
     "gki_graph_destroy": (_I32, [_P]),
     "gki_graph_n_bases": (_I64, [_P]),
+    "gki_topological_rank": (_I32, [_I64, _P, _P, _P]),
     "gki_critical_paths": (_I32, [_I64, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, C.POINTER(_I64)]),
     "gki_finder_create": (_I32, [_P, C.POINTER(_P)]),
     "gki_finder_destroy": (_I32, [_P]),

@@ -38,9 +38,17 @@ struct FindArgs {
     int32_t k, M, one_node, has_lossy;
     int64_t node_begin, off_begin, node_end, off_end;
     int64_t n0, n1;          // nodes [n0, n1) are the only ones this run touches (per-shard cost, not per-graph)
+    const int32_t *rank;     // NULL, or a topological rank per node: the run is rank_begin <= rank[n] <= rank_end
+    int32_t rank_begin, rank_end;
     int32_t split, pad;      // output layout: 0 = by end node (boundary block, then interior run, per node);
                              // 1 = all interior records (by position) first, then all boundary records (by node)
 };
+
+// does node n belong to the run (critical-path chunk / shard)?
+__device__ __forceinline__ bool in_run(const FindArgs &a, int64_t n) {
+    if (a.rank) { const int32_t r = a.rank[n]; return r >= a.rank_begin && r <= a.rank_end; }
+    return n >= a.node_begin && n <= a.node_end;
+}
 
 struct OutFlat { uint64_t *hash; uint32_t *node; uint64_t *ref_offset; float *af; };
 struct OutV2 { int64_t *hash; int32_t *start_node; int16_t *start_offset; int32_t *node; double *af; };
@@ -88,7 +96,7 @@ __device__ __forceinline__ int lossy_of(const uint16_t *__restrict__ lossy, int3
 // Number of leading offsets of node n that are handled by the boundary walk.
 __device__ __forceinline__ int32_t bnd_len_of(const DevGraph &g, const FindArgs &a, const uint16_t *__restrict__ lossy,
                                               int64_t n, int32_t size) {
-    if (n < a.node_begin || n > a.node_end || size <= 0) return 0;
+    if (size <= 0 || !in_run(a, n)) return 0;
     int32_t reach = a.k - 1;                                          // offsets < k-1 look into predecessors
     if (a.has_lossy && lossy[n] != 0xFFFF) reach = lossy[n] + a.k - 1;      // E1 windows end up to c+k-2
     if (!g.is_ref[n] && a.M < 1) reach = size;                        // variant node, limit 0: nothing admissible
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
             }
         }
         uint32_t ic = 0;                              // interior offsets of this node in this run
-        if (n >= a.node_begin && n <= a.node_end && size > 0) {
+        if (size > 0 && in_run(a, n)) {
             int64_t lo = bl, hi2 = size;
             if (n == a.node_begin && a.off_begin > lo) lo = a.off_begin;
             if (n == a.node_end && a.off_end < hi2) hi2 = a.off_end;
@@ -440,7 +448,7 @@ __global__ __launch_bounds__(256) void k_node_emit(DevGraph g, FindArgs a, const
     for (int64_t n = a.n0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.n1; n += stride) {
         const int32_t size = g.node_size[n];
         if (size <= 0) continue;
-        const bool inside = n >= a.node_begin && n <= a.node_end;
+        const bool inside = in_run(a, n);
         int64_t lo = inside ? bnd_len_of(g, a, lossy, n, size) : 0;
         if (n == a.node_begin && a.off_begin > lo) lo = a.off_begin;
         const int64_t ss = g.seq_start[n];
@@ -567,7 +575,7 @@ __global__ __launch_bounds__(256) void k_emit_interior(DevGraph g, FindArgs a, c
         const int64_t p = w * 64 + lane;
         const uint32_t j = rank + (uint32_t)__popcll(mask & lane_mask) - 1u;
         const NodeEmit e = ne[j];
-        if (p < e.glo || p < p_begin || p >= p_end) continue;
+        if (p < e.glo || p >= e.glo + e.cnt || p < p_begin || p >= p_end) continue;      // (glo = INT64_MAX, cnt = 0: not in the run)
         const uint64_t h = gki_extract(g.seq2, p - (k - 1), k);
         if (FMT == 0) {
             put(out, p + e.D, h, e.node, e.node, 0, p + e.E, (double)e.af);
@@ -606,7 +614,8 @@ struct gki_finder {
     NodeEmit *ne;
     uint16_t *lossy;
     void *scan_tmp; int64_t scan_tmp_bytes;
-    int *d_err; int64_t *d_totals; unsigned long long *d_bsum; 
+    int *d_err; int64_t *d_totals; unsigned long long *d_bsum;
+    int32_t *d_rank;                  // topological ranks of the run in progress (non-topological node ids only)
     FindArgs args;
     int64_t n_records, n_boundary_records, n_interior_records;
     int64_t word_begin, word_end, p_begin, p_end;
@@ -759,7 +768,8 @@ int gki_finder_destroy(gki_finder *f) {
     if (!f) return GKI_OK;
     (void)hipStreamSynchronize(f->stream);
     (void)hipStreamSynchronize(f->stream2);
-    void *ptrs[] = {f->bcount, f->total, f->rec_base, f->bnd_base, f->ne, f->lossy, f->scan_tmp, f->d_err, f->d_totals, f->d_bsum};
+    void *ptrs[] = {f->bcount, f->total, f->rec_base, f->bnd_base, f->ne, f->lossy, f->scan_tmp, f->d_err, f->d_totals, f->d_bsum,
+                    f->d_rank};
     for (void *p : ptrs) if (p) (void)gki_dev_free(p);
     for (int i = 0; i < 8; i++) (void)hipEventDestroy(f->ev[i]);
     (void)hipEventDestroy(f->ev_ready);
@@ -776,7 +786,7 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
     const DevGraph &d = f->g->d;
     if (p->k < 1 || p->k > GKI_MAX_K) return gki_set_error(GKI_ERR_BAD_ARG, "k must be in 1..31 (got %d)", p->k);
     if (p->max_variant_nodes < 0) return gki_set_error(GKI_ERR_BAD_ARG, "max_variant_nodes < 0");
-    if (p->node_begin < 0 || p->node_end > d.n_nodes || p->node_begin > p->node_end)
+    if (p->node_begin < 0 || p->node_end > d.n_nodes || (!p->h_node_rank && p->node_begin > p->node_end))
         return gki_set_error(GKI_ERR_BAD_ARG, "bad node range [%lld, %lld]", (long long)p->node_begin, (long long)p->node_end);
     hipStream_t s = f->stream;
     FindArgs a;
@@ -787,6 +797,16 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
     a.n0 = p->node_begin < d.n_nodes ? p->node_begin : d.n_nodes;
     a.n1 = p->node_end < d.n_nodes ? p->node_end + 1 : d.n_nodes;
     a.split = p->layout == GKI_LAYOUT_SPLIT ? 1 : 0; a.pad = 0;
+    a.rank = nullptr; a.rank_begin = 0; a.rank_end = 0;
+    if (p->h_node_rank) {
+        // node ids are not topological: membership by rank, every node is looked at
+        if (!f->d_rank) HIP_TRY(gki_dev_malloc((void **)&f->d_rank, (size_t)d.n_nodes * 4));
+        HIP_TRY(hipMemcpyAsync(f->d_rank, p->h_node_rank, (size_t)d.n_nodes * 4, hipMemcpyHostToDevice, s));
+        a.rank = f->d_rank;
+        a.rank_begin = p->node_begin < d.n_nodes ? p->h_node_rank[p->node_begin] : INT_MAX;
+        a.rank_end = p->node_end < d.n_nodes ? p->h_node_rank[p->node_end] : INT_MAX;
+        a.n0 = 0; a.n1 = d.n_nodes;
+    }
     f->args = a;
     const int64_t n_run = a.n1 - a.n0;
     if (a.has_lossy) HIP_TRY(hipMemcpyAsync(f->lossy, p->h_lossy_crit, (size_t)d.n_nodes * 2, hipMemcpyHostToDevice, s));
@@ -834,7 +854,7 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
     f->n_interior_records = tot[0] - (int64_t)bsum;
     // words of the sequence covered by the node range
     int64_t p0 = 0, p1 = d.n_bases;
-    if (a.node_begin > 0 || a.node_end < d.n_nodes) {
+    if (!a.rank && (a.node_begin > 0 || a.node_end < d.n_nodes)) {
         int64_t nb = a.node_begin < d.n_nodes ? a.node_begin : d.n_nodes;
         HIP_TRY(hipMemcpy(&p0, d.seq_start + nb, 8, hipMemcpyDeviceToHost));
         if (a.node_end < d.n_nodes) {

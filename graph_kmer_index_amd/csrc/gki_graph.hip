@@ -211,6 +211,23 @@ int gki_graph_destroy(gki_graph *g) {
 int64_t gki_graph_n_bases(const gki_graph *g) { return g->d.n_bases; }
 
 // critical_graph_paths.py:42-104, host walk along the linear reference.
+int gki_topological_rank(int64_t n_nodes, const int64_t *edge_start, const int32_t *edges, int32_t *out_rank) {
+    std::vector<int32_t> indeg((size_t)n_nodes, 0), queue;
+    for (int64_t e = 0; e < edge_start[n_nodes]; e++) indeg[(size_t)edges[e]]++;
+    queue.reserve((size_t)n_nodes);
+    for (int64_t n = 0; n < n_nodes; n++) if (indeg[(size_t)n] == 0) queue.push_back((int32_t)n);
+    size_t head = 0;
+    int32_t next = 0;
+    while (head < queue.size()) {
+        const int32_t n = queue[head++];
+        out_rank[n] = next++;
+        for (int64_t e = edge_start[n]; e < edge_start[n + 1]; e++)
+            if (--indeg[(size_t)edges[e]] == 0) queue.push_back(edges[e]);
+    }
+    if ((int64_t)next != n_nodes) return gki_set_error(GKI_ERR_BAD_ARG, "the graph has a cycle");
+    return GKI_OK;
+}
+
 int gki_critical_paths(int64_t n_nodes, const int32_t *node_size, const int64_t *edge_start, const int32_t *edges,
                        const int64_t *rev_start, const uint8_t *is_ref, const int32_t *chrom_start, int n_chrom,
                        int k, uint32_t *out_nodes, uint16_t *out_offsets, int64_t *n_out) {

@@ -199,15 +199,25 @@ class DenseKmerFinder:
                         node_end, off_end = int(crit_nodes[stop_seen]), int(crit_offsets[stop_seen])
                     else:
                         node_end, off_end = g.n_nodes, 0              # no critical point is seen any more
+        rank = None
         if chunked and len(g.edges):
             if "_ids_increase_along_edges" not in g.__dict__:
                 src = np.repeat(np.arange(g.n_nodes), np.diff(g.edge_start))
                 g.__dict__["_ids_increase_along_edges"] = not np.any(g.edges <= src)
             if not g.__dict__["_ids_increase_along_edges"]:
-                raise NotImplementedError("chunked find() needs node ids that increase along every edge")
+                # the run is then not an id range: membership by topological rank (every node between two critical
+                # points lies between them in any topological order)
+                if "_topological_rank" not in g.__dict__:
+                    r = np.zeros(g.n_nodes, dtype=np.int32)
+                    _lib.check(_lib.load().gki_topological_rank(g.n_nodes, _lib.hptr(g.edge_start), _lib.hptr(g.edges),
+                                                                _lib.hptr(r)))
+                    g.__dict__["_topological_rank"] = r
+                rank = g.__dict__["_topological_rank"]
+                if not (start_at is not None and start_at > 0):
+                    node_begin, off_begin = int(np.argmin(rank)), 0   # "from the graph start" = from rank 0
         p = _lib.FindParams(k, self._max_variant_nodes, int(self._only_save_one_node_per_kmer), 0,
-                            node_begin, off_begin, node_end, off_end, _lib.hptr(lossy))
-        p._keep = lossy
+                            node_begin, off_begin, node_end, off_end, _lib.hptr(lossy), _lib.hptr(rank))
+        p._keep = (lossy, rank)
         if node_begin >= g.n_nodes:
             return None
         return p

@@ -147,7 +147,16 @@ typedef struct {
     /* per-node critical offset for lossy restarts (0 < c < k-1, SURVEY.md 8a' E1), uint16[n_nodes],
      * 0xFFFF = none; NULL when the graph has none. */
     const uint16_t *h_lossy_crit;
+    /* host int32[n_nodes] or NULL.  NULL: node ids increase along every edge and the run is the id range
+     * [node_begin, node_end].  Otherwise a topological rank of every node (gki_topological_rank): the run is the nodes
+     * whose rank lies between the ranks of node_begin and node_end (node_end == n_nodes: to the end); costs a pass
+     * over all nodes instead of over the run's. */
+    const int32_t *h_node_rank;
 } gki_find_params;
+
+/* Host: a topological rank of every node (Kahn; ties by node id), for gki_find_params.h_node_rank.  GKI_ERR_BAD_ARG if
+ * the graph has a cycle. */
+int gki_topological_rank(int64_t n_nodes, const int64_t *edge_start, const int32_t *edges, int32_t *out_rank);
 
 typedef struct gki_finder gki_finder;
 int gki_finder_create(gki_graph *g, gki_finder **out);

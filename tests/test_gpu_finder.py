@@ -201,6 +201,38 @@ def test_chunked_find_partitions_the_records():
     assert np.array_equal(np.sort(cat["start_nodes"], kind="stable"), cat["start_nodes"])
 
 
+def test_chunked_find_on_graphs_whose_node_ids_are_not_topological():
+    # overlapping alleles get the largest node id but sit in the middle of the graph: the run of a chunk is then a set of
+    # topological ranks, not an id range (gki_find_params.h_node_rank)
+    rng = np.random.default_rng(77)
+    checked = 0
+    for it in range(60):
+        k = int(rng.integers(3, 10))
+        seqs, edges, lin, af = overlapping_bubble_graph(rng, n_var=int(rng.integers(4, 12)), min_ref=2, max_ref=2 * k)
+        g = GraphArrays.from_dicts(seqs, edges, lin, af)
+        src = np.repeat(np.arange(g.n_nodes), np.diff(g.edge_start))
+        if not np.any(g.edges <= src):
+            continue
+        try:
+            crit = oracle.critical_paths(g, k)
+        except oracle.OracleError:
+            continue
+        n = len(crit[0])
+        one, M = bool(rng.integers(0, 2)), int(rng.choice([1, 2, 4]))
+        cp = CriticalGraphPaths(crit[0], crit[1])
+        for a, b in [(0, n // 2), (n // 2, n), (1, max(1, n - 1)), (0, 0), (n, n)]:
+            exp, flags = oracle.find(g, k, crit, one, M, start_at_critical_path_number=a, stop_at_critical_path_number=b,
+                                     return_flags=True)
+            if flags:
+                continue
+            f = DenseKmerFinder(g, k, critical_graph_paths=cp, only_save_one_node_per_kmer=one, max_variant_nodes=M,
+                                start_at_critical_path_number=a, stop_at_critical_path_number=b)
+            f.find()
+            assert_same_records(finder_cols(f), exp)
+            checked += 1
+    assert checked > 50
+
+
 def test_golden_chunk_cases():
     for case in TOY:
         if not case["name"].startswith(("rand_chunk_", "chunk_offset0_")):

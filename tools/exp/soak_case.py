@@ -31,3 +31,9 @@ if "gpu" in sys.argv:
     print("extra in gpu:", sorted((cg - ce).elements())); print("missing in gpu:", sorted((ce - cg).elements()))
 else:
     print(len(exp["kmers"]))
+if "gpu" in sys.argv:
+    for n in set(r[0] for r in (cg - ce)) | set(r[0] for r in (ce - cg)):
+        print("node", n, "seq", g.seq[g.seq_start[n]:g.seq_start[n + 1]].tolist(), "preds", g.rev_edges[g.rev_start[n]:g.rev_start[n + 1]].tolist())
+        print(" gpu records at node:", [r for r in ge if r[0] == n]); print(" exp records at node:", [r for r in ee if r[0] == n])
+    f2 = DenseKmerFinder(g, k, critical_graph_paths=CriticalGraphPaths(crit[0], crit[1]), only_save_one_node_per_kmer=one, max_variant_nodes=M)
+    f2.find(); full = rows(finder_cols(f2)); print(" full-run gpu records at those nodes:", [r for r in full if r[0] in set(x[0] for x in (cg - ce))])
