@@ -10,34 +10,41 @@ from .graph import GraphArrays
 
 
 class CriticalGraphPaths:
+    """nodes[i], offsets[i] = the i-th critical point in graph order.  `is_critical` answers from a node-sorted copy
+    by binary search; like the reference's dense table (critical_graph_paths.py:11-34) it reports offset 0 as critical
+    for every non-critical node up to the largest critical node id."""
+
     def __init__(self, nodes, offsets, index=None):
         self.nodes = nodes
         self.offsets = offsets
-        self._index = index
-
-    def _make_index(self):
-        if len(self.nodes) == 0:
-            self._index = np.zeros(0)
-            return
-        self._index = np.zeros(int(np.max(self.nodes)) + 1, dtype=np.uint16)
-        self._index[self.nodes] = self.offsets
+        self._index = index                    # accepted for signature compatibility; the lookup below does not use it
+        self._by_node = None
 
     @classmethod
     def empty(cls):
         return cls(np.array([]), np.array([]), np.array([]))
 
+    def _lookup(self):
+        if self._by_node is None:
+            nodes = np.asarray(self.nodes).astype(np.int64)
+            order = np.argsort(nodes, kind="stable")
+            # a node listed twice keeps its LAST offset, as the reference's table assignment does
+            self._by_node = (nodes[order], np.asarray(self.offsets).astype(np.int64)[order])
+        return self._by_node
+
     def is_critical(self, node, offset):
-        if self._index is None:
-            self._make_index()
-        if node >= len(self._index):
+        nodes, offsets = self._lookup()
+        if len(nodes) == 0 or node > nodes[-1]:
             return False
-        return self._index[node] == offset
+        hi = int(np.searchsorted(nodes, node, side="right"))
+        listed = hi > 0 and nodes[hi - 1] == node
+        return (int(offsets[hi - 1]) if listed else 0) == offset
+
+    def __iter__(self):
+        return iter(zip(self.nodes, self.offsets))
 
     def __len__(self):
         return len(self.nodes)
-
-    def __iter__(self):
-        return ((node, offset) for node, offset in zip(self.nodes, self.offsets))
 
     @classmethod
     def from_graph(cls, graph, k):

@@ -1,62 +1,84 @@
-"""Growable NumPy-backed list with the reference's semantics (nplist.py:4-69).
+"""Growable NumPy-backed list, the reference's `NpList` interface (nplist.py:4-69): append / extend / truncate
+(`set_n_elements`) / copy / comparison, contents as a NumPy view.
 
-The device path does not need it (output slots come from a count pass + prefix sums); it is kept
-because it is part of the reference's importable surface."""
+The device path does not need it (output slots come from a count pass + prefix sums); it exists because it is part
+of the reference's importable surface and `DenseKmerFinder` exposes such lists.  Storage is a power-of-two buffer
+that is re-allocated only when a write does not fit."""
 import numpy as np
+
+
+def _capacity_for(n):
+    cap = 64
+    while cap < n:
+        cap *= 2
+    return cap
 
 
 class NpList:
     def __init__(self, dtype=None):
         self._dtype = dtype
-        self._data = np.empty(0, dtype=dtype) if dtype is not None else np.empty(0)
-        self._n_elements = 0
+        self._buf = None if dtype is None else np.empty(64, dtype=dtype)
+        self._size = 0
 
-    def _reserve(self, n):
-        if n <= len(self._data):
-            return
-        grown = np.zeros(n, dtype=self._data.dtype)
-        grown[:self._n_elements] = self._data[:self._n_elements]
-        self._data = grown
+    # the reference's attribute names, read by its callers
+    @property
+    def _n_elements(self):
+        return self._size
+
+    @property
+    def _data(self):
+        return self._buf if self._buf is not None else np.empty(0)
+
+    def _room_for(self, extra, like):
+        if self._buf is None:                               # dtype from the first value, as the reference infers it
+            if self._dtype is None:
+                self._dtype = np.asarray(like).dtype
+            self._buf = np.empty(_capacity_for(extra), dtype=self._dtype)
+        need = self._size + extra
+        if need > len(self._buf):
+            bigger = np.empty(_capacity_for(need), dtype=self._buf.dtype)
+            bigger[:self._size] = self._buf[:self._size]
+            self._buf = bigger
 
     def append(self, element):
-        if len(self._data) == 0:
-            if self._dtype is None:
-                self._dtype = type(element)
-            self._data = np.zeros(100, dtype=self._dtype)
-        if self._n_elements == len(self._data):
-            self._reserve(int(len(self._data) * 1.5))
-        self._data[self._n_elements] = element
-        self._n_elements += 1
+        self._room_for(1, element)
+        self._buf[self._size] = element
+        self._size += 1
 
     def extend(self, elements):
-        m = len(elements)
-        if self._n_elements + m >= len(self._data):
-            self._reserve((self._n_elements + m) * 2)
-        self._data[self._n_elements:self._n_elements + m] = elements
-        self._n_elements += m
+        values = np.asarray(elements)
+        if values.size == 0:
+            return
+        self._room_for(values.size, values.ravel()[0])
+        self._buf[self._size:self._size + values.size] = values
+        self._size += values.size
+
+    def set_n_elements(self, n):
+        """Truncate (or re-expose) to n elements, like the reference: the buffer is not touched."""
+        self._size = int(n)
 
     def get_nparray(self):
-        return self._data[:self._n_elements]
+        if self._buf is None:
+            return np.empty(0) if self._dtype is None else np.empty(0, dtype=self._dtype)
+        return self._buf[:self._size]
 
     def __getitem__(self, item):
         return self.get_nparray()[item]
 
-    def set_n_elements(self, n):
-        self._n_elements = n
+    def __len__(self):
+        return self._size
 
     def copy(self):
-        new = NpList(dtype=self._dtype)
-        new.extend(self.get_nparray())
-        return new
+        twin = NpList(dtype=self._dtype)
+        twin.extend(self.get_nparray())
+        return twin
 
     def __eq__(self, other):
-        return bool(np.all(self.get_nparray() == other.get_nparray()))
-
-    def __len__(self):
-        return self._n_elements
+        mine, theirs = self.get_nparray(), other.get_nparray()
+        return len(mine) == len(theirs) and bool(np.all(mine == theirs))
 
     def __str__(self):
         return str(self.get_nparray())
 
     def __repr__(self):
-        return "NpList(" + str(self) + ")"
+        return "NpList(%s)" % self

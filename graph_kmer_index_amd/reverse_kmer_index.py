@@ -4,6 +4,7 @@
 Records of a node keep their input order (the reference's np.argsort leaves it unspecified).
 """
 import logging
+import os
 import numpy as np
 
 from . import _lib
@@ -18,6 +19,8 @@ def _as_u64(a, what):
 
 
 class ReverseKmerIndex:
+    """node -> the k-mers (and ref positions) of its records: records grouped by node, `nodes_to_index_positions[node]`
+    the first record of the group and `nodes_to_n_hashes[node]` its length (reverse_kmer_index.py:5-45)."""
     properties = {"nodes_to_index_positions", "nodes_to_n_hashes", "hashes", "ref_positions"}
 
     def __init__(self, nodes_to_index_positions=None, nodes_to_n_hashes=None, hashes=None, ref_positions=None):
@@ -26,42 +29,36 @@ class ReverseKmerIndex:
         self.hashes = hashes
         self.ref_positions = ref_positions
 
-    def __str__(self):
-        return ("Nodes to index positions: %s\nNodes to n hashes      : %s\nHashes:                  %s\n"
-                "Ref positions:                  %s\n" % (self.nodes_to_index_positions, self.nodes_to_n_hashes,
-                                                          self.hashes, self.ref_positions))
+    def _group(self, node):
+        """slice of the records of `node` (IndexError for a node beyond the table, as in the reference)"""
+        first = int(self.nodes_to_index_positions[node])
+        return slice(first, first + int(self.nodes_to_n_hashes[node]))
 
     def get_node_kmers(self, node):
-        """reverse_kmer_index.py:23-29"""
-        start = int(self.nodes_to_index_positions[node])
-        n = int(self.nodes_to_n_hashes[node])
-        if n == 0:
-            return []
-        return self.hashes[start:start + n]
+        group = self._group(node)
+        return self.hashes[group] if group.stop > group.start else []
 
     def get_node_kmers_and_ref_positions(self, node):
-        """reverse_kmer_index.py:31-42"""
         try:
-            start = int(self.nodes_to_index_positions[node])
+            group = self._group(node)
         except IndexError:
             logging.error("Invalid node %d" % node)
             raise
-        n = int(self.nodes_to_n_hashes[node])
-        if n == 0:
+        if group.stop == group.start:
             return [[], []]
-        return self.hashes[start:start + n], self.ref_positions[start:start + n]
+        return self.hashes[group], self.ref_positions[group]
+
+    def __str__(self):
+        return "\n".join("%s: %s" % (name, getattr(self, name)) for name in sorted(self.properties)) + "\n"
+
+    def to_file(self, file_name):
+        np.savez(file_name, **{name: getattr(self, name) for name in self.properties})
 
     @classmethod
     def from_file(cls, file_name):
-        try:
-            data = np.load(file_name)
-        except FileNotFoundError:
-            data = np.load(file_name + ".npz")
-        return cls(data["nodes_to_index_positions"], data["nodes_to_n_hashes"], data["hashes"], data["ref_positions"])
-
-    def to_file(self, file_name):
-        np.savez(file_name, nodes_to_index_positions=self.nodes_to_index_positions,
-                 nodes_to_n_hashes=self.nodes_to_n_hashes, hashes=self.hashes, ref_positions=self.ref_positions)
+        path = file_name if os.path.exists(file_name) else file_name + ".npz"
+        with np.load(path) as data:
+            return cls(**{name: data[name] for name in cls.properties})
 
     @classmethod
     def from_flat_kmers(cls, flat_kmers):
