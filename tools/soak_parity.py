@@ -206,6 +206,7 @@ def main():
         return {"forward": soak_forward, "index": soak_index, "reads": soak_reads}[args.what](args)
     t_end = time.time() + args.seconds
     it = checked = refused = 0
+    why = {}
     while time.time() < t_end:
         seed = args.seed * 1_000_003 + it
         it += 1
@@ -247,6 +248,9 @@ def main():
         except (ValueError, NotImplementedError) as e:
             if flags & oracle.ORC_FLAG_UNDEFINED_BULK or isinstance(e, NotImplementedError):
                 refused += 1
+                reason = type(e).__name__ + ": " + ("reference output undefined (bulk path entered with < k bases)"
+                                                    if isinstance(e, ValueError) else str(e)[:70])
+                why[reason] = why.get(reason, 0) + 1
                 continue
             print("UNEXPECTED refusal:", desc, mode, kw, e); sys.exit(1)
         if flags & oracle.ORC_FLAG_UNDEFINED_BULK:
@@ -293,6 +297,8 @@ def main():
         f.close()
         checked += 1
     print("soak ok: %d graphs compared, %d refused (undefined in the reference / unsupported), %d drawn" % (checked, refused, it))
+    for reason, count in sorted(why.items(), key=lambda kv: -kv[1]):
+        print("   refused %5d x %s" % (count, reason))
 
 
 if __name__ == "__main__":
