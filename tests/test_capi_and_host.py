@@ -208,3 +208,25 @@ def test_nested_variant_graphs_are_refused():
         else:
             check_supported_graph(g, 5)
     assert refused > 10
+
+
+def test_topological_rank_host_function():
+    # gki_topological_rank (host side of libgki_hip.so): ranks respect every edge; a cycle is refused
+    from graph_kmer_index_amd import _lib
+    import ctypes as C
+    from graphgen import overlapping_bubble_graph
+    lib = _lib.load()
+    rng = np.random.default_rng(4)
+    for _ in range(20):
+        seqs, edges, lin, af = overlapping_bubble_graph(rng, n_var=int(rng.integers(3, 9)))
+        g = GraphArrays.from_dicts(seqs, edges, lin, af)
+        rank = np.full(g.n_nodes, -1, dtype=np.int32)
+        assert lib.gki_topological_rank(g.n_nodes, _lib.hptr(g.edge_start), _lib.hptr(g.edges), _lib.hptr(rank)) == 0
+        assert sorted(rank.tolist()) == list(range(g.n_nodes))
+        src = np.repeat(np.arange(g.n_nodes), np.diff(g.edge_start))
+        assert np.all(rank[src] < rank[g.edges])
+    edge_start = np.array([0, 1, 2], dtype=np.int64)
+    cyc = np.array([1, 0], dtype=np.int32)
+    out = np.zeros(2, dtype=np.int32)
+    assert lib.gki_topological_rank(2, _lib.hptr(edge_start), _lib.hptr(cyc), _lib.hptr(out)) != 0
+    assert b"cycle" in C.c_char_p(lib.gki_last_error()).value
