@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
                                                         uint32_t *__restrict__ bcount, uint32_t *__restrict__ total,
                                                         int *__restrict__ err) {
     LevelLo below[MAXN];
+    LevelLo below0 = {0, 0, 0, 0};     // the first suspended level stays in registers (SNP/indel graphs never go deeper)
     const int k = a.k;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t n = a.n0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.n1; n += stride) {
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
                 while (L > 0) {
                     if (t_cur >= t_end) {
                         L--;
-                        if (L > 0) { const LevelLo b = below[L - 1]; t_cur = b.cur; t_end = b.end; t_cum = b.cum; t_vc = b.vc; }
+                        if (L > 0) { const LevelLo b = L == 1 ? below0 : below[L - 1]; t_cur = b.cur; t_end = b.end; t_cum = b.cum; t_vc = b.vc; }
                         continue;
                     }
                     const int32_t q = g.rev_edges[t_cur++];
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
                     }
                     if (deeper) {
                         LevelLo b; b.cur = t_cur; b.end = t_end; b.cum = (uint8_t)t_cum; b.vc = (uint8_t)t_vc;
-                        below[L - 1] = b;
+                        if (L == 1) below0 = b; else below[L - 1] = b;
                         t_cur = wq.rev_begin; t_end = wq.rev_end; t_cum = new_cum; t_vc = vq;
                         L++;
                     }
@@ -289,6 +290,8 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                                                            typename OutSel<FMT>::T out, int *__restrict__ err) {
     __shared__ EvQueue<FMT, ALL> s_q[4];
     LevelEmit below[MAXN];
+    LevelEmit below0;                  // the first suspended level stays in registers
+    below0.ctx = 0; below0.maf = 0.0; below0.cur = below0.end = below0.mn = 0; below0.cum = below0.vc = below0.evf = below0.evt = 0;
     int32_t path[ALL ? MAXN : 1];          // all-nodes mode: the node of every level of the walk (level 0 = the end node)
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                     if (t_evf < t_evt) { ev = true; e_from = t_evf; e_to = t_evt; e_ctx = t_ctx; e_mn = t_mn; e_maf = t_maf; e_nl = L; }
                     L--;
                     if (L > 0) {
-                        const LevelEmit b = below[L - 1];
+                        const LevelEmit b = L == 1 ? below0 : below[L - 1];
                         t_cur = b.cur; t_end = b.end; t_cum = b.cum; t_vc = b.vc; t_evf = b.evf; t_evt = b.evt;
                         t_ctx = b.ctx; t_mn = b.mn; t_maf = b.maf;
                     }
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                                 LevelEmit b;
                                 b.cur = t_cur; b.end = t_end; b.cum = (uint8_t)t_cum; b.vc = (uint8_t)t_vc;
                                 b.evf = (uint8_t)t_evf; b.evt = (uint8_t)t_evt; b.ctx = t_ctx; b.mn = t_mn; b.maf = t_maf;
-                                below[L - 1] = b;
+                                if (L == 1) below0 = b; else below[L - 1] = b;
                                 t_cur = wq.rev_begin; t_end = wq.rev_end; t_cum = new_cum; t_vc = vq;
                                 t_evf = from < to ? from : 0; t_evt = from < to ? to : 0;
                                 t_ctx = cx; t_mn = mn; t_maf = maf;
