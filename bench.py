@@ -76,13 +76,18 @@ def cpu_baseline(sample_bases, k, max_variant_nodes, cores):
     cuts = critical_path_cuts(g, CriticalGraphPaths(crit[0], crit[1]), 16 * cores)
     chunks = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
     _CPU.update(g=g, k=k, crit=crit, M=max_variant_nodes)
+    counts = None
     if cores > 1:
-        with mp.get_context("fork").Pool(cores) as pool:
-            pool.map(_cpu_chunk, chunks[:cores], chunksize=1)          # untimed: workers up, graph pages touched
-            t0 = time.perf_counter()
-            counts = pool.map(_cpu_chunk, chunks, chunksize=1)
-            dt = time.perf_counter() - t0
-    else:
+        try:
+            with mp.get_context("fork").Pool(cores) as pool:
+                pool.map(_cpu_chunk, chunks[:cores], chunksize=1)      # untimed: workers up, graph pages touched
+                t0 = time.perf_counter()
+                counts = pool.map(_cpu_chunk, chunks, chunksize=1)
+                dt = time.perf_counter() - t0
+        except (OSError, RuntimeError) as e:                           # no process pool here: one core, stated as such
+            log("cpu baseline: process pool unavailable (%s), using one core" % e)
+            cores = 1
+    if counts is None:
         t0 = time.perf_counter()
         counts = [_cpu_chunk(c) for c in chunks]
         dt = time.perf_counter() - t0
