@@ -18,11 +18,21 @@ class GkiError(RuntimeError):
         self.code = code
 
 
+class NotOneLinearRefSuccessor(GkiError, AssertionError):
+    """GKI_ERR_NOT_ONE_REF_SUCC: where the reference's `assert len(next_nodes) == 1` fails (kmer_finder.py:402)."""
+
+
 class FindParams(C.Structure):
-    _fields_ = [("k", C.c_int32), ("max_variant_nodes", C.c_int32), ("one_node_per_kmer", C.c_int32),
-                ("layout", C.c_int32), ("node_begin", C.c_int64), ("off_begin", C.c_int64),
-                ("node_end", C.c_int64), ("off_end", C.c_int64), ("h_lossy_crit", C.c_void_p),
-                ("h_node_rank", C.c_void_p)]
+    """gki_find_params (include/gki.h); struct_size is filled in by the constructor."""
+    _fields_ = [("struct_size", C.c_uint32), ("k", C.c_int32), ("max_variant_nodes", C.c_int32),
+                ("one_node_per_kmer", C.c_int32), ("layout", C.c_int32), ("node_begin", C.c_int64),
+                ("off_begin", C.c_int64), ("node_end", C.c_int64), ("off_end", C.c_int64),
+                ("h_lossy_crit", C.c_void_p), ("h_node_rank", C.c_void_p), ("h_node_flags", C.c_void_p)]
+
+    def __init__(self, k, max_variant_nodes, one_node_per_kmer, layout, node_begin, off_begin, node_end, off_end,
+                 h_lossy_crit=None, h_node_rank=None, h_node_flags=None):
+        super().__init__(C.sizeof(FindParams), k, max_variant_nodes, one_node_per_kmer, layout, node_begin, off_begin,
+                         node_end, off_end, h_lossy_crit, h_node_rank, h_node_flags)
 
 
 class IndexView(C.Structure):
@@ -60,6 +70,8 @@ SYMBOLS = {
     "gki_graph_destroy": (_I32, [_P]),
     "gki_graph_n_bases": (_I64, [_P]),
     "gki_topological_rank": (_I32, [_I64, _P, _P, _P]),
+    "gki_classify_nodes": (_I32, [_I64, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, C.POINTER(C.c_int32)]),
+    "gki_find_params_size": (_I64, []),
     "gki_critical_paths": (_I32, [_I64, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, C.POINTER(_I64)]),
     "gki_finder_create": (_I32, [_P, C.POINTER(_P)]),
     "gki_finder_destroy": (_I32, [_P]),
@@ -112,13 +124,17 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if lib.gki_find_params_size() != C.sizeof(FindParams):
+        raise ImportError("libgki_hip.so is stale: gki_find_params is %d bytes there, %d in this binding"
+                          % (lib.gki_find_params_size(), C.sizeof(FindParams)))
     _lib = lib
     return lib
 
 
 def check(code):
     if code != 0:
-        raise GkiError(code, load().gki_last_error().decode("utf-8", "replace"))
+        cls = NotOneLinearRefSuccessor if code == 7 else GkiError
+        raise cls(code, load().gki_last_error().decode("utf-8", "replace"))
 
 
 def device_count():

@@ -42,6 +42,7 @@ struct FindArgs {
     int32_t rank_begin, rank_end;
     int32_t split, pad;      // output layout: 0 = by end node (boundary block, then interior run, per node);
                              // 1 = all interior records (by position) first, then all boundary records (by node)
+    const uint8_t *nflags;   // NULL, or the GKI_NODE_* byte of every node (general graphs, include/gki.h)
 };
 
 // does node n belong to the run (critical-path chunk / shard)?
@@ -99,7 +100,8 @@ __device__ __forceinline__ int32_t bnd_len_of(const DevGraph &g, const FindArgs 
     if (size <= 0 || !in_run(a, n)) return 0;
     int32_t reach = a.k - 1;                                          // offsets < k-1 look into predecessors
     if (a.has_lossy && lossy[n] != 0xFFFF) reach = lossy[n] + a.k - 1;      // E1 windows end up to c+k-2
-    if (!g.is_ref[n] && a.M < 1) reach = size;                        // variant node, limit 0: nothing admissible
+    if (a.nflags) { if (a.nflags[n] & GKI_NODE_DEAD) reach = size; }  // general graphs: the search never enters the node
+    else if (!g.is_ref[n] && a.M < 1) reach = size;                   // variant node, limit 0: nothing admissible
     return size < reach ? size : reach;
 }
 
@@ -114,25 +116,122 @@ __device__ __forceinline__ int32_t bnd_len_of(const DevGraph &g, const FindArgs 
 struct LevelLo {                 // what a suspended level needs to resume
     int32_t cur, end;
     uint8_t cum, vc;
+    uint8_t a;                   // general graphs: variant count at the first non-free node of the path (0: none yet)
 };
 
-template <bool HAS_LOSSY>
+// ------------------------------------------------------------------------------------ general graphs
+// The search (kmer_finder.py:383-417) reaches a window iff SOME path to it took every step into a node that is
+// not free to enter (free: linear-ref(-dummy), or forced by only_follow_nodes :386-388) while the k bases before
+// that node held fewer than max_variant_nodes variant nodes.  For the nodes of the window itself that is a count
+// over the window: with v(i) = variant nodes from the end node back to level i, the step into the non-free node at
+// level i saw v(first node) - v(i) variant nodes, largest for the non-free node nearest the end -- `a` below is v
+// at that node, and a path is dropped as soon as v - a >= M.  What the history BEFORE the window's first node q adds
+// depends on q (include/gki.h): nothing if q is T or SIMPLE (an all-linear-ref history exists and dominates);
+// if q is NESTED, history_ok() enumerates the histories backwards until one is found that ends in a T / SIMPLE node,
+// or in a node inside which every open constraint closes -- what is left then is "that node is entered at all", which
+// gki_classify_nodes settled on the host (GKI_NODE_DEAD is exact).
+constexpr int HMAX = 40;         // nodes of one enumerated history (k-1 one-base nodes + slack)
+
+__device__ __noinline__ bool history_ok(const DevGraph &g, const uint8_t *__restrict__ nf, int k, int M,
+                                        const int32_t *path, int L, int *err) {
+    // open constraints of the window's nodes path[0..L] (end node .. q): the step into a non-free node y still sees
+    // the history nodes within t bases of q's entry and tolerates fewer than m variant nodes among them
+    int8_t ct[MAXN];
+    int16_t cm[MAXN];
+    int nc = 0;
+    {
+        int between = 0, c = 0;                  // bases / variant nodes of path[i+1..L]
+        for (int i = L; i >= 0; i--) {
+            const int32_t y = path[i];
+            const uint8_t fy = nf[y];
+            if (!(fy & (GKI_NODE_REF | GKI_NODE_FORCED))) {
+                const int m = M - c;
+                if (m <= 0) return false;
+                const int t = k - between;
+                if (t > 0) { ct[nc] = (int8_t)t; cm[nc] = (int16_t)(m > 30000 ? 30000 : m); nc++; }
+            }
+            const int sy = g.walk[y].size;
+            between = between + sy > k ? k : between + sy;
+            c += (fy & GKI_NODE_REF) ? 0 : 1;
+        }
+    }
+    int32_t hn[HMAX], hcur[HMAX], hend[HMAX], hd[HMAX], hsz[HMAX];     // history nodes, nearest first; hd = bases nearer than the node
+    uint8_t hf[HMAX];
+    {
+        const NodeWalk wq = g.walk[path[L]];
+        hcur[0] = wq.rev_begin; hend[0] = wq.rev_end;
+    }
+    int h = 0;
+    for (;;) {
+        if (hcur[h] >= hend[h]) { if (h == 0) return false; h--; continue; }
+        const int32_t p = g.rev_edges[hcur[h]++];
+        const uint8_t fp = nf[p];
+        if (fp & GKI_NODE_DEAD) continue;
+        const int32_t child = h == 0 ? path[L] : hn[h - 1];
+        if ((fp & GKI_NODE_HFS) && !(nf[child] & GKI_NODE_FORCED)) continue;      // edge removed by a forced sibling
+        const NodeWalk wp = g.walk[p];
+        hn[h] = p; hf[h] = fp;
+        hd[h] = h == 0 ? 0 : hd[h - 1] + hsz[h - 1];
+        hsz[h] = wp.size > (1 << 20) ? (1 << 20) : wp.size;
+        bool ok = true;
+        if (!(fp & GKI_NODE_REF)) {              // only a variant node changes a count
+            for (int j = 0; j < nc && ok; j++) {
+                int cnt = 0;
+                for (int x = 0; x <= h; x++) if (!(hf[x] & GKI_NODE_REF) && hd[x] < ct[j]) cnt++;
+                if (cnt >= cm[j]) ok = false;
+            }
+            for (int l = 0; l < h && ok; l++) {  // steps into the non-free nodes of the history itself
+                if (hf[l] & (GKI_NODE_REF | GKI_NODE_FORCED)) continue;
+                int cnt = 0;
+                for (int x = l + 1; x <= h; x++) if (!(hf[x] & GKI_NODE_REF) && hd[x] - hd[l + 1] < k) cnt++;
+                if (cnt >= M) ok = false;
+            }
+        }
+        if (!(fp & (GKI_NODE_REF | GKI_NODE_FORCED)) && M < 1) ok = false;
+        if (!ok) continue;
+        if (fp & (GKI_NODE_T | GKI_NODE_SIMPLE)) return true;     // beyond: an all-linear-ref history, no further variant node
+        {
+            const int end = hd[h] + hsz[h];                       // does every open constraint close inside p?
+            bool closed = true;
+            for (int j = 0; j < nc && closed; j++) if (ct[j] > end) closed = false;
+            for (int l = 0; l < h && closed; l++)
+                if (!(hf[l] & (GKI_NODE_REF | GKI_NODE_FORCED)) && end - hd[l + 1] < k) closed = false;
+            if (closed) return true;                              // p is not DEAD: some admissible history enters it
+        }
+        if (!(fp & GKI_NODE_NESTED)) continue;
+        if (h + 1 >= HMAX) { *err = GKI_ERR_WINDOW_TOO_DEEP; return false; }
+        h++;
+        hcur[h] = wp.rev_begin; hend[h] = wp.rev_end;
+    }
+}
+
+template <bool HAS_LOSSY, bool GEN>
 __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
                                                         uint32_t *__restrict__ bcount, uint32_t *__restrict__ total,
                                                         int *__restrict__ err) {
     LevelLo below[MAXN];
-    LevelLo below0 = {0, 0, 0, 0};     // the first suspended level stays in registers (SNP/indel graphs never go deeper)
+    LevelLo below0 = {0, 0, 0, 0, 0};  // the first suspended level stays in registers (SNP/indel graphs never go deeper)
+    int32_t path[GEN ? MAXN : 1];      // general graphs: the node of every level (level 0 = the end node)
     const int k = a.k;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t n = a.n0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.n1; n += stride) {
         const NodeWalk wn = g.walk[n];
         const int32_t size = wn.size;
+        const uint8_t fn = GEN ? a.nflags[n] : (uint8_t)0;
+        const bool reach_n = !(GEN && (fn & GKI_NODE_DEAD));
         const int32_t bl = bnd_len_of(g, a, lossy, n, size);
         uint32_t count = 0;
         const int o_lo = (n == a.node_begin) ? (int)(a.off_begin < bl ? a.off_begin : bl) : 0;
         const int o_hi = (n == a.node_end) ? (int)(a.off_end < bl ? a.off_end : bl) : bl;
-        const int v0 = wn.is_ref ? 0 : 1;
-        if (bl > 0 && o_lo < o_hi && v0 <= a.M) {
+        const int v0 = GEN ? ((fn & GKI_NODE_REF) ? 0 : 1) : (wn.is_ref ? 0 : 1);
+        const bool nonfree0 = GEN ? !(fn & (GKI_NODE_REF | GKI_NODE_FORCED)) : v0 != 0;
+        // kmer_finder.py:402: at the end of a node without exactly one linear-ref successor no reachable window may be
+        // at the limit.  The windows in question end at the node's last base (oc), for an empty node "before offset 0".
+        bool chk = GEN && (fn & GKI_NODE_CHECK) && reach_n && in_run(a, n);
+        const int oc = size - 1;
+        if (chk && size >= k) { if (v0 >= a.M) *err = GKI_ERR_NOT_ONE_REF_SUCC; chk = false; }
+        const bool chk_empty = chk && size == 0;
+        if (reach_n && ((bl > 0 && o_lo < o_hi) || chk_empty) && !(nonfree0 && a.M < 1)) {
             const int cn = HAS_LOSSY ? lossy_of(lossy, (int32_t)n) : -1;
             for (int o = o_lo > k - 1 ? o_lo : k - 1; o < o_hi; o++) {
                 if (HAS_LOSSY && cn >= 0 && o + 1 - k <= cn - 1 && cn <= o) continue;
@@ -140,39 +239,65 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
             }
             int hi = o_hi < k - 1 ? o_hi : k - 1;
             if (HAS_LOSSY && cn >= 0 && cn < hi) hi = cn;
-            if (o_lo < hi) {
+            const int w_lo = chk_empty ? -1 : o_lo;       // offset -1: the k bases before the node
+            if (chk_empty) hi = 0;
+            if (GEN && chk && wn.rev_begin == wn.rev_end && v0 >= a.M) *err = GKI_ERR_NOT_ONE_REF_SUCC;   // a root shorter than k
+            if (w_lo < hi) {
                 int32_t t_cur = wn.rev_begin, t_end = wn.rev_end;
-                int t_cum = 0, t_vc = v0;
+                int t_cum = 0, t_vc = v0, t_a = nonfree0 ? v0 : 0;
                 int L = 1;
+                if (GEN) path[0] = (int32_t)n;
                 while (L > 0) {
                     if (t_cur >= t_end) {
                         L--;
-                        if (L > 0) { const LevelLo b = L == 1 ? below0 : below[L - 1]; t_cur = b.cur; t_end = b.end; t_cum = b.cum; t_vc = b.vc; }
+                        if (L > 0) { const LevelLo b = L == 1 ? below0 : below[L - 1]; t_cur = b.cur; t_end = b.end; t_cum = b.cum; t_vc = b.vc; t_a = b.a; }
                         continue;
                     }
                     const int32_t q = g.rev_edges[t_cur++];
                     const NodeWalk wq = g.walk[q];
-                    const int vq = t_vc + (wq.is_ref ? 0 : 1);
-                    if (vq > a.M) continue;                          // kmer_finder.py:391-403 in order-free form
+                    const uint8_t fq = GEN ? a.nflags[q] : (uint8_t)0;
+                    if (GEN) {
+                        if (fq & GKI_NODE_DEAD) continue;
+                        if ((fq & GKI_NODE_HFS) && !(a.nflags[path[L - 1]] & GKI_NODE_FORCED)) continue;
+                    }
+                    const int vq = t_vc + (GEN ? ((fq & GKI_NODE_REF) ? 0 : 1) : (wq.is_ref ? 0 : 1));
+                    int aq = 0;
+                    if (!GEN) {
+                        if (vq > a.M) continue;                      // kmer_finder.py:391-403 in order-free form
+                    } else {
+                        aq = t_a ? t_a : ((fq & (GKI_NODE_REF | GKI_NODE_FORCED)) ? 0 : vq);
+                        if (aq && vq - aq >= a.M) continue;
+                    }
                     if (L >= MAXN - 1) { *err = GKI_ERR_WINDOW_TOO_DEEP; continue; }
+                    if (GEN) path[L] = q;
                     const int s = wq.size, c = t_cum;
                     bool deeper;
                     int new_cum;
                     if (s == 0) {                                    // empty node: in the node set, adds no base
                         deeper = true; new_cum = c;
                     } else {
-                        int from = k - 1 - c - s; if (from < o_lo) from = o_lo;
+                        int from = k - 1 - c - s; if (from < w_lo) from = w_lo;
                         int to = k - 1 - c; if (to > hi) to = hi;
                         const int cq = HAS_LOSSY ? lossy_of(lossy, q) : -1;
                         if (HAS_LOSSY && cq >= 0) { const int min_ok = k - 1 - c - s + cq; if (from < min_ok) from = min_ok; }
+                        if (GEN && from < to) {
+                            bool ok = true;                          // a history before the window's first node?
+                            if (!(fq & (GKI_NODE_T | GKI_NODE_SIMPLE)))
+                                ok = (fq & GKI_NODE_NESTED) ? history_ok(g, a.nflags, k, a.M, path, L, err) : false;
+                            if (ok && chk && from <= oc && oc < to && vq >= a.M) *err = GKI_ERR_NOT_ONE_REF_SUCC;
+                            if (!ok) to = from;
+                        }
+                        if (GEN && from < 0 && from < to) from = 0;      // offset -1 has no record
                         if (from < to) count += (uint32_t)(to - from) * (a.one_node ? 1u : (uint32_t)(L + 1));
-                        deeper = (k - 1 - c - s > o_lo) && !(HAS_LOSSY && cq >= 0);
+                        // the graph ends before the window of oc is complete (graph start): the search saw what there is
+                        if (GEN && chk && wq.rev_begin == wq.rev_end && c + s < k - 1 - oc && vq >= a.M) *err = GKI_ERR_NOT_ONE_REF_SUCC;
+                        deeper = (k - 1 - c - s > w_lo) && !(HAS_LOSSY && cq >= 0);
                         new_cum = c + s;
                     }
                     if (deeper) {
-                        LevelLo b; b.cur = t_cur; b.end = t_end; b.cum = (uint8_t)t_cum; b.vc = (uint8_t)t_vc;
+                        LevelLo b; b.cur = t_cur; b.end = t_end; b.cum = (uint8_t)t_cum; b.vc = (uint8_t)t_vc; b.a = (uint8_t)t_a;
                         if (L == 1) below0 = b; else below[L - 1] = b;
-                        t_cur = wq.rev_begin; t_end = wq.rev_end; t_cum = new_cum; t_vc = vq;
+                        t_cur = wq.rev_begin; t_end = wq.rev_end; t_cum = new_cum; t_vc = vq; t_a = aq;
                         L++;
                     }
                 }
@@ -214,7 +339,12 @@ struct EvQueue {
     int32_t nodes[ALL ? EVQ : 1][NLQ];         // ... and the nodes, ascending (np.unique, kmer_finder.py:134)
 };
 
-__device__ int g_dbg_skip_expand = 0;     // diagnostics only (GKI_DBG_SKIP_EXPAND): phase A alone
+#ifdef GKI_TUNING
+__device__ int g_dbg_skip_expand = 0;     // tools/exp builds only (make tuning): 1 = phase A alone, 2 = no sort
+#define GKI_DBG_SKIP_EXPAND_IS(v) (g_dbg_skip_expand == (v))
+#else
+#define GKI_DBG_SKIP_EXPAND_IS(v) false
+#endif
 
 // Expansion writes the queued steps in OUTPUT order.  Steps arrive in walk order, i.e. interleaved across the 64
 // nodes of the wave; written that way every cache line of the wave's output block is touched several microseconds
@@ -224,7 +354,7 @@ __device__ int g_dbg_skip_expand = 0;     // diagnostics only (GKI_DBG_SKIP_EXPA
 template <int FMT, bool ALL>
 __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, typename OutSel<FMT>::T out, int k, uint64_t kmask,
                                              int lane) {
-    if (g_dbg_skip_expand == 1) return;
+    if (GKI_DBG_SKIP_EXPAND_IS(1)) return;
     static_assert(EVQ == 128, "two steps per lane");
     // smallest first-record slot of the queue
     int64_t mn_idx = INT64_MAX;
@@ -239,7 +369,7 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, typ
     }
     // bitonic sort of 128 keys, one compare-exchange per lane and step (a wave executes in lockstep; LDS ops of one
     // wave are ordered)
-    for (int size = 2; size <= (g_dbg_skip_expand == 2 ? 0 : EVQ); size <<= 1) {
+    for (int size = 2; size <= (GKI_DBG_SKIP_EXPAND_IS(2) ? 0 : EVQ); size <<= 1) {
         for (int str = size >> 1; str > 0; str >>= 1) {
             const int lo = ((lane / str) * (str << 1)) + (lane % str);
             const int hi = lo + str;
@@ -282,7 +412,7 @@ struct LevelEmit {               // a suspended level of the emit walk
     uint8_t cum, vc, evf, evt;
 };
 
-template <bool HAS_LOSSY, int FMT, bool ALL>
+template <bool HAS_LOSSY, int FMT, bool ALL, bool GEN>
 __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
                                                            const uint32_t *__restrict__ bcount,
                                                            const int64_t *__restrict__ rec_base,
@@ -292,7 +422,8 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
     LevelEmit below[MAXN];
     LevelEmit below0;                  // the first suspended level stays in registers
     below0.ctx = 0; below0.maf = 0.0; below0.cur = below0.end = below0.mn = 0; below0.cum = below0.vc = below0.evf = below0.evt = 0;
-    int32_t path[ALL ? MAXN : 1];          // all-nodes mode: the node of every level of the walk (level 0 = the end node)
+    int32_t path[(ALL || GEN) ? MAXN : 1]; // all-nodes mode / general graphs: the node of every level of the walk (level 0 = the end node)
+    uint8_t lvl_a[GEN ? MAXN : 1];         // general graphs: `a` of the suspended levels (see history_ok)
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     EvQueue<FMT, ALL> &q = s_q[wib];
@@ -311,16 +442,19 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
         int t_cum = 0, t_vc = 0, t_evf = 0, t_evt = 0;
         uint64_t t_ctx = 0;
         double t_maf = 0.0;
+        int t_a = 0;
         if (n < a.n1 && bcount[n] > 0) {
             const NodeWalk wn = g.walk[n];
+            const uint8_t fn = GEN ? a.nflags[n] : (uint8_t)0;
             const int32_t bl = bnd_len_of(g, a, lossy, n, wn.size);
             idx = rec_base[n] + *bnd_shift;
             pos0 = g.pos_base[n];
             o_lo = (n == a.node_begin) ? (int)(a.off_begin < bl ? a.off_begin : bl) : 0;
             const int o_hi = (n == a.node_end) ? (int)(a.off_end < bl ? a.off_end : bl) : bl;
-            const int v0 = wn.is_ref ? 0 : 1;
+            const int v0 = GEN ? ((fn & GKI_NODE_REF) ? 0 : 1) : (wn.is_ref ? 0 : 1);
+            const bool nonfree0 = GEN ? !(fn & (GKI_NODE_REF | GKI_NODE_FORCED)) : v0 != 0;
             const int cn = HAS_LOSSY ? lossy_of(lossy, (int32_t)n) : -1;
-            if (o_lo < o_hi && v0 <= a.M) {
+            if (o_lo < o_hi && !(nonfree0 && a.M < 1)) {
                 // windows inside the node itself (lossy-restart nodes only; rare, written by the lane alone)
                 for (int o = o_lo > k - 1 ? o_lo : k - 1; o < o_hi; o++) {
                     if (HAS_LOSSY && cn >= 0 && o + 1 - k <= cn - 1 && cn <= o) continue;
@@ -332,7 +466,8 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                     t_cur = wn.rev_begin; t_end = wn.rev_end; t_cum = 0; t_vc = v0; t_evf = t_evt = 0; t_ctx = 0;
                     t_mn = (int32_t)n; t_maf = wn.af;
                     own = gki_extract(g.seq2, wn.seq_start, hi);
-                    if (ALL) path[0] = (int32_t)n;
+                    if (ALL || GEN) path[0] = (int32_t)n;
+                    t_a = nonfree0 ? v0 : 0;
                     L = 1;
                 }
             }
@@ -351,17 +486,28 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                         const LevelEmit b = L == 1 ? below0 : below[L - 1];
                         t_cur = b.cur; t_end = b.end; t_cum = b.cum; t_vc = b.vc; t_evf = b.evf; t_evt = b.evt;
                         t_ctx = b.ctx; t_mn = b.mn; t_maf = b.maf;
+                        if (GEN) t_a = lvl_a[L];
                     }
                 } else {
                     const int32_t qn = g.rev_edges[t_cur++];
                     const NodeWalk wq = g.walk[qn];
-                    const int vq = t_vc + (wq.is_ref ? 0 : 1);
-                    if (vq <= a.M) {
+                    const uint8_t fq = GEN ? a.nflags[qn] : (uint8_t)0;
+                    const int vq = t_vc + (GEN ? ((fq & GKI_NODE_REF) ? 0 : 1) : (wq.is_ref ? 0 : 1));
+                    bool take;
+                    int aq = 0;
+                    if (!GEN) {
+                        take = vq <= a.M;
+                    } else {
+                        aq = t_a ? t_a : ((fq & (GKI_NODE_REF | GKI_NODE_FORCED)) ? 0 : vq);
+                        take = !(fq & GKI_NODE_DEAD) && !(aq && vq - aq >= a.M) &&
+                               !((fq & GKI_NODE_HFS) && !(a.nflags[path[L - 1]] & GKI_NODE_FORCED));
+                    }
+                    if (take) {
                         if (L >= MAXN - 1) {
                             *err = GKI_ERR_WINDOW_TOO_DEEP;
                         } else {
                             const int s = wq.size, c = t_cum;
-                            if (ALL) path[L] = qn;
+                            if (ALL || GEN) path[L] = qn;
                             const int32_t mn = qn < t_mn ? qn : t_mn;
                             const double maf = fmin(t_maf, wq.af);               // np.min, kmer_finder.py:143
                             bool deeper;
@@ -374,6 +520,10 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                                 to = k - 1 - c; if (to > hi) to = hi;
                                 const int cq = HAS_LOSSY ? lossy_of(lossy, qn) : -1;
                                 if (HAS_LOSSY && cq >= 0) { const int min_ok = k - 1 - c - s + cq; if (from < min_ok) from = min_ok; }
+                                if (GEN && from < to && !(fq & (GKI_NODE_T | GKI_NODE_SIMPLE))) {      // a history before q?
+                                    const bool ok = (fq & GKI_NODE_NESTED) ? history_ok(g, a.nflags, k, a.M, path, L, err) : false;
+                                    if (!ok) to = from;
+                                }
                                 const int tq = s < k - 1 - c ? s : k - 1 - c;
                                 cx = t_ctx | (gki_extract(g.seq2, wq.seq_start + s - tq, tq) << (2 * (k - 1 - c - tq)));
                                 deeper = (k - 1 - c - s > o_lo) && !(HAS_LOSSY && cq >= 0);
@@ -384,6 +534,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                                 b.cur = t_cur; b.end = t_end; b.cum = (uint8_t)t_cum; b.vc = (uint8_t)t_vc;
                                 b.evf = (uint8_t)t_evf; b.evt = (uint8_t)t_evt; b.ctx = t_ctx; b.mn = t_mn; b.maf = t_maf;
                                 if (L == 1) below0 = b; else below[L - 1] = b;
+                                if (GEN) { lvl_a[L] = (uint8_t)t_a; t_a = aq; }
                                 t_cur = wq.rev_begin; t_end = wq.rev_end; t_cum = new_cum; t_vc = vq;
                                 t_evf = from < to ? from : 0; t_evt = from < to ? to : 0;
                                 t_ctx = cx; t_mn = mn; t_maf = maf;
@@ -616,6 +767,7 @@ struct gki_finder {
     int64_t *rec_base, *bnd_base;     // by-node layout: rec_base only; split layout: interior bases / boundary bases
     NodeEmit *ne;
     uint16_t *lossy;
+    uint8_t *nflags;                  // general graphs only (gki_find_params.h_node_flags), allocated on first use
     void *scan_tmp; int64_t scan_tmp_bytes;
     int *d_err; int64_t *d_totals; unsigned long long *d_bsum;
     int32_t *d_rank;                  // topological ranks of the run in progress (non-topological node ids only)
@@ -628,30 +780,47 @@ struct gki_finder {
     bool ev_valid[4];
 };
 
+// Launch parameters are fixed in the product; `make tuning` (-DGKI_TUNING, used by tools/exp) reads them from the
+// environment for A/B runs.
+#ifdef GKI_TUNING
+static int tuning_int(const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; }
+#define GKI_KNOB(name, dflt) tuning_int(name, dflt)
+#else
+#define GKI_KNOB(name, dflt) (dflt)
+#endif
+
+template <int FMT, bool ALL>
+static int launch_boundary_mode(gki_finder *f, const DevGraph &d, const FindArgs &a, typename OutSel<FMT>::T out, hipStream_t s2,
+                                const dim3 grid, const dim3 block, const int64_t *base, const int64_t *shift) {
+    if (a.nflags)          // general graphs always carry a lossy table (0xFFFF everywhere when there is none)
+        hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, true>), grid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
+    else if (a.has_lossy)
+        hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, false>), grid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
+    else
+        hipLaunchKernelGGL((k_emit_boundary_one<false, FMT, ALL, false>), grid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
+    HIP_TRY(hipGetLastError());
+    return GKI_OK;
+}
+
 template <int FMT>
 static int launch_boundary_fmt(gki_finder *f, const DevGraph &d, const FindArgs &a, typename OutSel<FMT>::T out, hipStream_t s2) {
+#ifdef GKI_TUNING
     static bool dbg_set = false;
     if (!dbg_set) {
-        int v = getenv("GKI_DBG_SKIP_EXPAND") ? atoi(getenv("GKI_DBG_SKIP_EXPAND")) : 0;   // 1: no expansion, 2: no sort
+        int v = GKI_KNOB("GKI_DBG_SKIP_EXPAND", 0);
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_skip_expand), &v, sizeof(int)));
         dbg_set = true;
     }
-    static const int bnd_blocks = getenv("GKI_BND_BLOCKS") ? atoi(getenv("GKI_BND_BLOCKS")) : 0;   // tuning knob
+#endif
+    const int bnd_blocks = GKI_KNOB("GKI_BND_BLOCKS", 0);
     int gb = stream_grid(a.n1 - a.n0, 256);
     if (bnd_blocks > 0 && gb > bnd_blocks) gb = bnd_blocks;
     const dim3 grid(gb), block(256);
     // split layout: boundary block of node n starts at (number of interior records) + bnd_base[n]
     const int64_t *base = a.split ? f->bnd_base : f->rec_base;
     const int64_t *shift = a.split ? f->rec_base + a.n1 : f->d_totals + 3;
-    if (a.one_node) {
-        if (a.has_lossy) hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, false>), grid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
-        else hipLaunchKernelGGL((k_emit_boundary_one<false, FMT, false>), grid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
-    } else {
-        if (a.has_lossy) hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, true>), grid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
-        else hipLaunchKernelGGL((k_emit_boundary_one<false, FMT, true>), grid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
-    }
-    HIP_TRY(hipGetLastError());
-    return GKI_OK;
+    if (a.one_node) return launch_boundary_mode<FMT, false>(f, d, a, out, s2, grid, block, base, shift);
+    return launch_boundary_mode<FMT, true>(f, d, a, out, s2, grid, block, base, shift);
 }
 static int launch_boundary(gki_finder *f, const DevGraph &d, const FindArgs &a, OutFlat out, hipStream_t s2) {
     if (out.hash && out.node && out.ref_offset && out.af) {
@@ -667,22 +836,25 @@ static int launch_boundary(gki_finder *f, const DevGraph &d, const FindArgs &a, 
 static int launch_interior(gki_finder *f, const DevGraph &d, const FindArgs &a, OutFlat out, unsigned blocks) {
     hipStream_t s = f->stream;
     if (out.hash && out.node && out.ref_offset && out.af) {
-        {
-            static const int swt = getenv("GKI_SW") ? atoi(getenv("GKI_SW")) : 64;       // A/B knob: bases per wave trip / 64
-            static const int rb = getenv("GKI_RUN_BLOCKS") ? atoi(getenv("GKI_RUN_BLOCKS")) : 256 * 5;
-            const int64_t n_words = f->word_end - f->word_begin;
-            unsigned gb = (unsigned)ceil_div(ceil_div(n_words, swt), 4);
-            if (gb > (unsigned)rb) gb = (unsigned)rb;
-            static const int cap = getenv("GKI_NE_CAP") ? atoi(getenv("GKI_NE_CAP")) : 128;
-            if (swt == 128)
-                hipLaunchKernelGGL((k_emit_interior_runs<128, 128>), dim3(gb), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end, f->p_begin, f->p_end);
-            else if (cap == 64)      // 16.7 KB of LDS per block: 8 blocks per CU
-                hipLaunchKernelGGL((k_emit_interior_runs<64, 64>), dim3(gb), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end, f->p_begin, f->p_end);
-            else if (cap == 32)
-                hipLaunchKernelGGL((k_emit_interior_runs<64, 32>), dim3(gb), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end, f->p_begin, f->p_end);
-            else     // 29 KB of LDS per block: 5 blocks per CU are resident
-                hipLaunchKernelGGL((k_emit_interior_runs<64, 128>), dim3(gb), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end, f->p_begin, f->p_end);
-        }
+        const int swt = GKI_KNOB("GKI_SW", 64);                 // bases per wave trip / 64
+        const int rb = GKI_KNOB("GKI_RUN_BLOCKS", 256 * 5);
+        const int cap = GKI_KNOB("GKI_NE_CAP", 128);
+        const int64_t n_words = f->word_end - f->word_begin;
+        unsigned gb = (unsigned)ceil_div(ceil_div(n_words, swt), 4);
+        if (gb > (unsigned)rb) gb = (unsigned)rb;
+#ifdef GKI_TUNING
+        if (swt == 128)
+            hipLaunchKernelGGL((k_emit_interior_runs<128, 128>), dim3(gb), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end, f->p_begin, f->p_end);
+        else if (cap == 64)      // 16.7 KB of LDS per block: 8 blocks per CU
+            hipLaunchKernelGGL((k_emit_interior_runs<64, 64>), dim3(gb), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end, f->p_begin, f->p_end);
+        else if (cap == 32)
+            hipLaunchKernelGGL((k_emit_interior_runs<64, 32>), dim3(gb), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end, f->p_begin, f->p_end);
+        else
+#else
+        (void)cap;
+#endif
+        // 29 KB of LDS per block: 5 blocks per CU are resident
+        hipLaunchKernelGGL((k_emit_interior_runs<64, 128>), dim3(gb), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end, f->p_begin, f->p_end);
     }
     else
         hipLaunchKernelGGL(k_emit_interior<0>, dim3(blocks), dim3(256), 0, s, d, a, f->ne, out, f->word_begin, f->word_end,
@@ -705,9 +877,9 @@ static int emit_impl(gki_finder *f, typename OutSel<FMT>::T out) {
     const FindArgs a = f->args;
     // Measured on MI355X (3 Gbp graph): running the boundary and interior kernels on two streams is ~4% slower
     // than back to back (both press on the same write path), so one stream is the default.
-    static const bool overlap = getenv("GKI_OVERLAP_EMIT") != nullptr;
+    const bool overlap = GKI_KNOB("GKI_OVERLAP_EMIT", 0) != 0;
     if (!overlap) s2 = s;
-    static const bool boundary_first = getenv("GKI_BOUNDARY_FIRST") != nullptr;     // tuning knob
+    const bool boundary_first = GKI_KNOB("GKI_BOUNDARY_FIRST", 0) != 0;
     HIP_TRY(hipEventRecord(f->ev_ready, s));
     HIP_TRY(hipStreamWaitEvent(s2, f->ev_ready, 0));
     auto run_boundary = [&]() -> int {
@@ -721,7 +893,7 @@ static int emit_impl(gki_finder *f, typename OutSel<FMT>::T out) {
         if (f->n_interior_records > 0 && f->word_end > f->word_begin) {
             int64_t n_words = f->word_end - f->word_begin;
             int64_t blocks = ceil_div(ceil_div(n_words, SW), 4);
-            static const int int_blocks = getenv("GKI_INT_BLOCKS") ? atoi(getenv("GKI_INT_BLOCKS")) : INTERIOR_MAX_BLOCKS;   // tuning knob
+            const int int_blocks = GKI_KNOB("GKI_INT_BLOCKS", INTERIOR_MAX_BLOCKS);
             if (blocks > int_blocks) blocks = int_blocks;
             GKI_TRY(launch_interior(f, d, a, out, (unsigned)blocks));
         }
@@ -772,7 +944,7 @@ int gki_finder_destroy(gki_finder *f) {
     (void)hipStreamSynchronize(f->stream);
     (void)hipStreamSynchronize(f->stream2);
     void *ptrs[] = {f->bcount, f->total, f->rec_base, f->bnd_base, f->ne, f->lossy, f->scan_tmp, f->d_err, f->d_totals, f->d_bsum,
-                    f->d_rank};
+                    f->d_rank, f->nflags};
     for (void *p : ptrs) if (p) (void)gki_dev_free(p);
     for (int i = 0; i < 8; i++) (void)hipEventDestroy(f->ev[i]);
     (void)hipEventDestroy(f->ev_ready);
@@ -787,6 +959,9 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
     *n_records = 0;
     f->counted = false;
     const DevGraph &d = f->g->d;
+    if (p->struct_size != sizeof(gki_find_params))
+        return gki_set_error(GKI_ERR_BAD_ARG, "gki_find_params.struct_size is %u, this library expects %u: the binding was "
+                             "written against another version of include/gki.h", p->struct_size, (unsigned)sizeof(gki_find_params));
     if (p->k < 1 || p->k > GKI_MAX_K) return gki_set_error(GKI_ERR_BAD_ARG, "k must be in 1..31 (got %d)", p->k);
     if (p->max_variant_nodes < 0) return gki_set_error(GKI_ERR_BAD_ARG, "max_variant_nodes < 0");
     if (p->node_begin < 0 || p->node_end > d.n_nodes || (!p->h_node_rank && p->node_begin > p->node_end))
@@ -801,6 +976,13 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
     a.n1 = p->node_end < d.n_nodes ? p->node_end + 1 : d.n_nodes;
     a.split = p->layout == GKI_LAYOUT_SPLIT ? 1 : 0; a.pad = 0;
     a.rank = nullptr; a.rank_begin = 0; a.rank_end = 0;
+    a.nflags = nullptr;
+    if (p->h_node_flags) {
+        if (!f->nflags) HIP_TRY(gki_dev_malloc((void **)&f->nflags, (size_t)d.n_nodes));
+        HIP_TRY(hipMemcpyAsync(f->nflags, p->h_node_flags, (size_t)d.n_nodes, hipMemcpyHostToDevice, s));
+        a.nflags = f->nflags;
+        if (!a.has_lossy) HIP_TRY(hipMemsetAsync(f->lossy, 0xFF, (size_t)d.n_nodes * 2, s));   // the general kernels always read it
+    }
     if (p->h_node_rank) {
         // node ids are not topological: membership by rank, every node is looked at
         if (!f->d_rank) HIP_TRY(gki_dev_malloc((void **)&f->d_rank, (size_t)d.n_nodes * 4));
@@ -818,11 +1000,14 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
 
     HIP_TRY(hipEventRecord(f->ev[0], s));
     if (n_run > 0) {
-        if (a.has_lossy)
-            hipLaunchKernelGGL(k_count_boundary<true>, dim3(stream_grid(n_run, 256)), dim3(256), 0, s, d, a, f->lossy,
+        if (a.nflags)
+            hipLaunchKernelGGL((k_count_boundary<true, true>), dim3(stream_grid(n_run, 256)), dim3(256), 0, s, d, a, f->lossy,
+                               f->bcount, f->total, f->d_err);
+        else if (a.has_lossy)
+            hipLaunchKernelGGL((k_count_boundary<true, false>), dim3(stream_grid(n_run, 256)), dim3(256), 0, s, d, a, f->lossy,
                                f->bcount, f->total, f->d_err);
         else
-            hipLaunchKernelGGL(k_count_boundary<false>, dim3(stream_grid(n_run, 256)), dim3(256), 0, s, d, a, f->lossy,
+            hipLaunchKernelGGL((k_count_boundary<false, false>), dim3(stream_grid(n_run, 256)), dim3(256), 0, s, d, a, f->lossy,
                                f->bcount, f->total, f->d_err);
         HIP_TRY(hipGetLastError());
     }
@@ -849,8 +1034,11 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
     HIP_TRY(hipMemcpyAsync(tot, f->d_totals, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&bsum, f->d_bsum, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (tot[1] == GKI_ERR_NOT_ONE_REF_SUCC)
+        return gki_set_error(GKI_ERR_NOT_ONE_REF_SUCC, "a window at the variant limit ends a node that does not have exactly one "
+                             "linear-ref successor: the reference asserts here (kmer_finder.py:402); raise max_variant_nodes");
     if (tot[1] != 0)
-        return gki_set_error((int)tot[1], "a k-window crosses more than %d nodes (too many empty nodes in a row)", MAXN - 2);
+        return gki_set_error((int)tot[1], "a k-window (or the history that decides it) crosses more than %d nodes", MAXN - 2);
     if (a.split) bsum = (unsigned long long)tot[2];
     f->n_records = tot[0];
     f->n_boundary_records = (int64_t)bsum;
@@ -903,5 +1091,7 @@ int gki_finder_kernel_ms(gki_finder *f, int which, float *ms) {
 }
 
 int64_t gki_finder_interior_records(const gki_finder *f) { return f->n_interior_records; }
+
+int64_t gki_find_params_size(void) { return (int64_t)sizeof(gki_find_params); }
 
 }  // extern "C"

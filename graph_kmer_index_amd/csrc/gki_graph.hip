@@ -228,6 +228,156 @@ int gki_topological_rank(int64_t n_nodes, const int64_t *edge_start, const int32
     return GKI_OK;
 }
 
+// Node classes for the order-free form of the variant limit on arbitrary DAGs (include/gki.h GKI_NODE_*;
+// kmer_finder.py:383-417).  One pass in topological order.
+namespace {
+// Is the non-free node n entered by the search at all: is there a backward path over alive edges through reachable
+// (already classified) nodes on which every step into a non-free node saw fewer than M variant nodes in the k bases
+// before it?  Same enumeration as history_ok() of gki_finder.hip for a window that is just the node.
+bool host_node_has_history(const int32_t *node_size, const int64_t *rev_start, const int32_t *rev_edges, const uint8_t *flags,
+                           int k, int M, int32_t n, int *too_deep) {
+    if (M < 1) return false;
+    constexpr int HMAXH = 4096;
+    std::vector<int32_t> hn, hd, hsz;
+    std::vector<int64_t> hcur, hend;
+    std::vector<uint8_t> hf;
+    hcur.push_back(rev_start[n]); hend.push_back(rev_start[n + 1]);
+    size_t h = 0;                                      // nodes of the current history = h (slot h is being filled)
+    for (;;) {
+        if (hcur[h] >= hend[h]) {
+            if (h == 0) return false;
+            hcur.pop_back(); hend.pop_back(); hn.pop_back(); hd.pop_back(); hsz.pop_back(); hf.pop_back();
+            h--;
+            continue;
+        }
+        const int32_t p = rev_edges[hcur[h]++];
+        const uint8_t fp = flags[p];
+        if (fp & GKI_NODE_DEAD) continue;
+        const int32_t child = h == 0 ? n : hn[h - 1];
+        if ((fp & GKI_NODE_HFS) && !(flags[child] & GKI_NODE_FORCED)) continue;
+        const int32_t d = h == 0 ? 0 : hd[h - 1] + hsz[h - 1];
+        const int32_t sz = node_size[p] > (1 << 20) ? (1 << 20) : node_size[p];
+        // counts with p appended at slot h
+        auto nonref = [&](size_t x) { return x == h ? !(fp & GKI_NODE_REF) : !(hf[x] & GKI_NODE_REF); };
+        auto dist = [&](size_t x) { return x == h ? d : hd[x]; };
+        bool ok = true;
+        if (!(fp & GKI_NODE_REF)) {
+            int cnt = 0;                               // the node itself: reach k, budget M
+            for (size_t x = 0; x <= h; x++) if (nonref(x) && dist(x) < k) cnt++;
+            if (cnt >= M) ok = false;
+            for (size_t l = 0; l < h && ok; l++) {
+                if (hf[l] & (GKI_NODE_REF | GKI_NODE_FORCED)) continue;
+                int c2 = 0;
+                for (size_t x = l + 1; x <= h; x++) if (nonref(x) && dist(x) - dist(l + 1) < k) c2++;
+                if (c2 >= M) ok = false;
+            }
+        }
+        if (!ok) continue;
+        if (fp & (GKI_NODE_T | GKI_NODE_SIMPLE)) return true;
+        const int32_t end = d + sz;                    // every open constraint closes inside p?
+        bool closed = end >= k;
+        for (size_t l = 0; l < h && closed; l++)
+            if (!(hf[l] & (GKI_NODE_REF | GKI_NODE_FORCED)) && end - dist(l + 1) < k) closed = false;
+        if (closed) return true;
+        if (!(fp & GKI_NODE_NESTED)) continue;
+        if (h + 1 >= (size_t)HMAXH) { *too_deep = 1; return false; }
+        hn.push_back(p); hd.push_back(d); hsz.push_back(sz); hf.push_back(fp);
+        hcur.push_back(rev_start[p]); hend.push_back(rev_start[p + 1]);
+        h++;
+    }
+}
+}  // namespace
+
+int gki_classify_nodes(int64_t n_nodes, const int32_t *node_size, const int64_t *edge_start, const int32_t *edges,
+                       const int64_t *rev_start, const int32_t *rev_edges, const uint8_t *is_ref, const uint8_t *follow,
+                       const int32_t *roots, int n_roots, int k, int max_variant_nodes, uint8_t *out, int32_t *general) {
+    *general = 0;
+    if (n_nodes <= 0) return GKI_OK;
+    bool ids_topological = true;
+    for (int64_t n = 0; n < n_nodes && ids_topological; n++)
+        for (int64_t e = edge_start[n]; e < edge_start[n + 1]; e++)
+            if (edges[e] <= n) { ids_topological = false; break; }
+    std::vector<int32_t> order;
+    if (!ids_topological) {
+        std::vector<int32_t> rank((size_t)n_nodes);
+        GKI_TRY(gki_topological_rank(n_nodes, edge_start, edges, rank.data()));
+        order.resize((size_t)n_nodes);
+        for (int64_t n = 0; n < n_nodes; n++) order[(size_t)rank[(size_t)n]] = (int32_t)n;
+    }
+    std::vector<uint8_t> is_root((size_t)n_nodes, 0);
+    for (int i = 0; i < n_roots; i++) if (roots[i] >= 0 && roots[i] < n_nodes) is_root[(size_t)roots[i]] = 1;
+    const int64_t INF = (int64_t)1 << 40;
+    std::vector<int64_t> clean((size_t)n_nodes, 0);   // linear-ref bases of the best history right before the node
+    for (int64_t n = 0; n < n_nodes; n++) {
+        uint8_t f = is_ref[n] ? GKI_NODE_REF : 0;
+        if (follow && follow[n]) f |= GKI_NODE_FORCED;
+        const int64_t e0 = edge_start[n], e1 = edge_start[n + 1];
+        bool hfs = false;
+        int n_ref = 0;
+        for (int64_t e = e0; e < e1; e++) {
+            if (follow && follow[edges[e]]) hfs = true;
+            if (is_ref[edges[e]]) n_ref++;
+        }
+        if (hfs) f |= GKI_NODE_HFS;
+        if (e1 > e0 && !hfs && n_ref != 1) f |= GKI_NODE_CHECK;
+        out[n] = f;
+    }
+    bool gen = false;
+    int too_deep = 0;
+    for (int64_t i = 0; i < n_nodes; i++) {
+        const int64_t n = ids_topological ? i : order[(size_t)i];
+        uint8_t f = out[n];
+        const int64_t r0 = rev_start[n], r1 = rev_start[n + 1];
+        if (is_root[(size_t)n] && r1 == r0) {
+            clean[(size_t)n] = INF;
+            out[n] = f | GKI_NODE_T;
+            if (f & (GKI_NODE_CHECK | GKI_NODE_HFS | GKI_NODE_FORCED)) gen = true;
+            continue;
+        }
+        bool any_pred = false, any_t = false;
+        int64_t best = 0;
+        for (int64_t r = r0; r < r1; r++) {
+            const int32_t p = rev_edges[r];
+            const uint8_t fp = out[p];
+            if (fp & GKI_NODE_DEAD) continue;
+            if ((fp & GKI_NODE_HFS) && !(f & GKI_NODE_FORCED)) continue;       // edge removed by a forced sibling
+            any_pred = true;
+            if (fp & GKI_NODE_T) any_t = true;
+            if (fp & GKI_NODE_REF) {
+                int64_t c = clean[(size_t)p] + node_size[p];
+                if (c > INF) c = INF;
+                if (c > best) best = c;
+            }
+        }
+        const bool has_edges = r1 > r0 || edge_start[n + 1] > edge_start[n];
+        if (!any_pred) {
+            out[n] = f | GKI_NODE_DEAD;
+            if (has_edges) gen = true;
+            continue;
+        }
+        if (f & GKI_NODE_REF) {
+            clean[(size_t)n] = best;
+            if (best >= k) f |= GKI_NODE_T;
+        }
+        if (!(f & GKI_NODE_T)) f |= any_t ? GKI_NODE_SIMPLE : GKI_NODE_NESTED;
+        out[n] = f;
+        if (!(f & (GKI_NODE_REF | GKI_NODE_FORCED))) {       // not free to enter: does an admissible history exist?
+            if (max_variant_nodes < 1 ||
+                (!any_t && !host_node_has_history(node_size, rev_start, rev_edges, out, k, max_variant_nodes, (int32_t)n, &too_deep))) {
+                f = (uint8_t)((f & ~(GKI_NODE_SIMPLE | GKI_NODE_NESTED)) | GKI_NODE_DEAD);
+                out[n] = f;
+                // with limit 0 on a graph of the simple class the fast kernels skip variant nodes by themselves
+                if ((f & GKI_NODE_CHECK) || !any_t) gen = true;
+                continue;
+            }
+        }
+        if (f & (GKI_NODE_NESTED | GKI_NODE_CHECK | GKI_NODE_HFS | GKI_NODE_FORCED)) gen = true;
+    }
+    if (too_deep) return gki_set_error(GKI_ERR_WINDOW_TOO_DEEP, "classify: a history crosses more than 4096 nodes");
+    *general = gen ? 1 : 0;
+    return GKI_OK;
+}
+
 int gki_critical_paths(int64_t n_nodes, const int32_t *node_size, const int64_t *edge_start, const int32_t *edges,
                        const int64_t *rev_start, const uint8_t *is_ref, const int32_t *chrom_start, int n_chrom,
                        int k, uint32_t *out_nodes, uint16_t *out_offsets, int64_t *n_out) {

@@ -6,9 +6,13 @@ position and every backward k-base window with at most `max_variant_nodes` non-l
 one record per distinct window node.  Record ORDER differs from the reference's depth-first order
 on branching graphs (it is by end position); on linear graphs it is identical.
 
-Graphs outside the class where that statement was verified against the reference raise instead of
-silently diverging:
-  * a node none of whose predecessors is a linear-ref(-dummy) node      -> NotImplementedError
+On graphs with nodes that have no linear-ref predecessor (a variant inside an alternative allele, multi-node
+alleles) and with `only_follow_nodes`, the variant limit also depends on the history before the window; the
+kernels then enumerate those histories (`classify_nodes`, include/gki.h GKI_NODE_*).  Where the reference's
+`assert len(next_nodes) == 1` (kmer_finder.py:402) fails, find() raises `_lib.NotOneLinearRefSuccessor`
+(an AssertionError).
+
+Still refused:
   * a chromosome other than the first starting with a node shorter than k -> NotImplementedError
   * a critical point (N, c) with 3 <= c < k-1 on a node longer than 2k+3: the reference itself
     emits meaningless hashes there (SURVEY.md 8a' E1 + bulk path)        -> ValueError
@@ -34,32 +38,37 @@ def update_hash(current_base, current_hash, first_base, k, only_add=False):
 
 
 def check_supported_graph(g, k):
-    """Raises for graphs outside the established equivalence.  O(nodes + edges): the verdict is kept on
-    the graph object, finders over the same graph (shards, chunks) do not repeat it."""
-    done = g.__dict__.setdefault("_supported_for_k", set())
-    if k in done:
-        return
-    _check_supported_graph(g, k)
-    done.add(k)
-
-
-def _check_supported_graph(g, k):
-    indeg = np.diff(g.rev_start)
-    has_pred = indeg > 0
-    if len(g.rev_edges):
-        ref_pred = np.add.reduceat(g.is_ref[g.rev_edges].astype(np.int64),
-                                   np.minimum(g.rev_start[:-1], len(g.rev_edges) - 1))
-        ref_pred[~has_pred] = 0
-        bad = np.nonzero(has_pred & (ref_pred == 0))[0]
-        if len(bad):
-            raise NotImplementedError(
-                "node %d has predecessors but none of them is a linear-ref(-dummy) node; the order-free "
-                "form of the variant limit (kmer_finder.py:391-403) is only established for graphs where "
-                "every node has a linear-ref predecessor" % int(bad[0]))
-    starts = list(g.chromosome_start_nodes.values())
-    for s in starts:
+    """Raises for the one graph shape the kernels do not cover: a second chromosome that starts with a node shorter
+    than k (its first windows would need the reference's extra start point :208-211 per chromosome)."""
+    for s in g.chromosome_start_nodes.values():
         if s != g.first_node and g.node_size[s] < k:
             raise NotImplementedError("chromosome start node %d is shorter than k" % s)
+
+
+def classify_nodes(g, k, max_variant_nodes, only_follow_nodes=None):
+    """(uint8[n_nodes] GKI_NODE_* flags, general) -- gki_classify_nodes (include/gki.h): which nodes the order-free
+    form of the variant limit (kmer_finder.py:383-417) can stop at when it looks for a history.  `general` False
+    means "at most max_variant_nodes variant nodes in the window" is the whole rule for this graph and the kernels run
+    without the flags.  Host pass in topological order; kept on the graph object per (k, limit, follow set)."""
+    follow = None
+    if only_follow_nodes is not None:
+        follow = np.zeros(g.n_nodes, dtype=np.uint8)
+        ids = np.fromiter((int(x) for x in only_follow_nodes), dtype=np.int64)
+        follow[ids[(ids >= 0) & (ids < g.n_nodes)]] = 1
+    key = (int(k), min(int(max_variant_nodes), 64), None if follow is None else follow.tobytes())
+    cache = g.__dict__.setdefault("_node_classes", {})
+    if key not in cache:
+        if len(cache) > 8:
+            cache.clear()
+        roots = np.ascontiguousarray(list(g.chromosome_start_nodes.values()) + [g.first_node], dtype=np.int32)
+        flags = np.zeros(g.n_nodes, dtype=np.uint8)
+        general = C.c_int32(0)
+        _lib.check(_lib.load().gki_classify_nodes(
+            g.n_nodes, _lib.hptr(g.node_size), _lib.hptr(g.edge_start), _lib.hptr(g.edges), _lib.hptr(g.rev_start),
+            _lib.hptr(g.rev_edges), _lib.hptr(g.is_ref), _lib.hptr(follow), _lib.hptr(roots), len(roots), int(k),
+            min(int(max_variant_nodes), 64), _lib.hptr(flags), C.byref(general)))
+        cache[key] = (flags, bool(general.value))
+    return cache[key]
 
 
 def lossy_table(g, k, crit_nodes, crit_offsets, start_at=None, stop_at=None):
@@ -109,8 +118,7 @@ class DenseKmerFinder:
         self._stop_at_critical_path_number = stop_at_critical_path_number
         self._whitelist = whitelist
         self._only_store_nodes = only_store_nodes
-        self._only_follow_nodes = only_follow_nodes   # honoured by find_only_kmers_starting_at_position (its only caller,
-        # unique_variant_kmers.py:91-96); find() with forced traversal raises
+        self._only_follow_nodes = only_follow_nodes   # kmer_finder.py:386-388 (unique_variant_kmers.py:91-96)
         self._params_cache = None
         self._whitelist_device = None
         self._cols = None          # host columns after find()
@@ -155,11 +163,9 @@ class DenseKmerFinder:
         return self._params_cache[0]
 
     def _make_params(self):
-        if self._only_follow_nodes is not None:
-            raise NotImplementedError("find() with only_follow_nodes (forced traversal, kmer_finder.py:386-388) is not "
-                                      "implemented; find_only_kmers_starting_at_position honours it")
         g, k = self._arrays, self._k
         check_supported_graph(g, k)
+        flags, general = classify_nodes(g, k, self._max_variant_nodes, self._only_follow_nodes)
         if self._critical_graph_paths is None:
             logging.info("Making critical graph paths since it's not specified.")
             self._critical_graph_paths = CriticalGraphPaths.from_graph(g, k)
@@ -216,8 +222,9 @@ class DenseKmerFinder:
                 if not (start_at is not None and start_at > 0):
                     node_begin, off_begin = int(np.argmin(rank)), 0   # "from the graph start" = from rank 0
         p = _lib.FindParams(k, self._max_variant_nodes, int(self._only_save_one_node_per_kmer), 0,
-                            node_begin, off_begin, node_end, off_end, _lib.hptr(lossy), _lib.hptr(rank))
-        p._keep = (lossy, rank)
+                            node_begin, off_begin, node_end, off_end, _lib.hptr(lossy), _lib.hptr(rank),
+                            _lib.hptr(flags) if general else None)
+        p._keep = (lossy, rank, flags)
         if node_begin >= g.n_nodes:
             return None
         return p
@@ -337,7 +344,6 @@ class DenseKmerFinder:
         """Batched form of the above (one kernel launch for many start positions)."""
         lib = _lib.load()
         g = self._arrays
-        check_supported_graph(g, self._k)
         graph = self._device_graph()
         n_pos = len(nodes)
         d_nodes = _lib.DeviceArray.from_host(np.ascontiguousarray(nodes, dtype=np.int32))

@@ -30,6 +30,8 @@ extern "C" {
 #define GKI_ERR_WINDOW_TOO_DEEP 4 /* a k-window crosses more than GKI_MAX_WINDOW_NODES nodes */
 #define GKI_ERR_STATE 5          /* call order violated (e.g. emit before count) */
 #define GKI_ERR_OVERFLOW 6       /* a count does not fit the reference's dtype (e.g. int32 directory) */
+#define GKI_ERR_NOT_ONE_REF_SUCC 7 /* the reference's AssertionError kmer_finder.py:402: a reachable window at the
+                                     variant limit ends a node that does not have exactly one linear-ref successor */
 
 #define GKI_MAX_WINDOW_NODES 48
 #define GKI_MAX_K 31             /* kmer_hashing.py:25 `assert k <= 31` */
@@ -135,7 +137,33 @@ int gki_critical_paths(int64_t n_nodes, const int32_t *h_node_size,
  * streams, which is what the writes like best; meant for consumers that sort anyway (the index build). */
 #define GKI_LAYOUT_BY_NODE 0
 #define GKI_LAYOUT_SPLIT 1
+/* Per-node flag byte of gki_find_params.h_node_flags, computed by gki_classify_nodes (host).  The search of
+ * kmer_finder.py:383-417 reaches a window iff SOME history satisfied the variant limit at every step into a node whose
+ * entry is not free (free: linear-ref(-dummy) node, or a forced `only_follow_nodes` successor :386-388).  Walking
+ * backwards, a history need not be enumerated past a node with GKI_NODE_T: a linear-ref node reachable through >= k
+ * linear-ref bases (or from a chromosome start) -- that history adds no variant node to any later window and is always
+ * allowed, so it dominates every other one. */
+#define GKI_NODE_REF 1       /* is_linear_ref_node_or_linear_ref_dummy_node: not counted by the variant limit */
+#define GKI_NODE_FORCED 2    /* member of only_follow_nodes */
+#define GKI_NODE_T 4         /* see above */
+#define GKI_NODE_SIMPLE 8    /* not T, but a predecessor is: the history through that predecessor dominates */
+#define GKI_NODE_NESTED 16   /* not T, no T predecessor: histories are enumerated through its predecessors */
+#define GKI_NODE_CHECK 32    /* has successors, none of them forced, and not exactly one linear-ref successor (:402) */
+#define GKI_NODE_HFS 64      /* has a forced successor: its edges to other successors do not exist for the search */
+#define GKI_NODE_DEAD 128    /* exact: the search never enters the node (no alive edge from an entered node, or no history
+                                within the limit): no records, never stepped on */
+/* Host, one pass in topological order, O(nodes + edges) plus a backward enumeration for every non-free NESTED node.
+ * h_follow: uint8[n_nodes] membership of only_follow_nodes or NULL; h_roots: chromosome start nodes (search roots).
+ * h_out_flags uint8[n_nodes].  *general = 1 if any node is NESTED / CHECK / HFS / FORCED or cut off, i.e.
+ * gki_finder_count needs the flags; 0 = the graph is in the class where "at most max_variant_nodes variant nodes in
+ * the window" is the whole rule and h_node_flags may stay NULL.  GKI_ERR_BAD_ARG if the graph has a cycle. */
+int gki_classify_nodes(int64_t n_nodes, const int32_t *h_node_size, const int64_t *h_edge_start, const int32_t *h_edges,
+                       const int64_t *h_rev_start, const int32_t *h_rev_edges, const uint8_t *h_is_ref,
+                       const uint8_t *h_follow, const int32_t *h_roots, int n_roots, int k, int max_variant_nodes,
+                       uint8_t *h_out_flags, int32_t *general);
+
 typedef struct {
+    uint32_t struct_size;         /* sizeof(gki_find_params): a binding built against another layout is refused */
     int32_t k;                    /* 1..31 */
     int32_t max_variant_nodes;    /* kmer_finder.py:42 */
     int32_t one_node_per_kmer;    /* only_save_one_node_per_kmer :145-146 */
@@ -152,7 +180,11 @@ typedef struct {
      * whose rank lies between the ranks of node_begin and node_end (node_end == n_nodes: to the end); costs a pass
      * over all nodes instead of over the run's. */
     const int32_t *h_node_rank;
+    /* host uint8[n_nodes] from gki_classify_nodes, or NULL when it reported general == 0. */
+    const uint8_t *h_node_flags;
 } gki_find_params;
+/* sizeof(gki_find_params) of this build, for bindings to check at load time. */
+int64_t gki_find_params_size(void);
 
 /* Host: a topological rank of every node (Kahn; ties by node id), for gki_find_params.h_node_rank.  GKI_ERR_BAD_ARG if
  * the graph has a cycle. */

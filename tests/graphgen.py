@@ -124,3 +124,56 @@ def nested_bubble_graph(rng, n_var=4, min_ref=2, max_ref=10, p_nest=0.6):
         edges[alt_out] = [head]
         tail = head
     return seqs, edges, linear, None
+
+
+def deep_nested_graph(rng, n_var=4, max_depth=2, min_ref=1, max_ref=8, p_nest=0.5, max_allele=3):
+    """Bubbles nested to `max_depth`: an alternative allele is a chain  segment -> bubble -> segment ...  whose inner
+    bubbles have two non-linear alleles (either may be empty, or complex again).  Gives multi-node alleles, nodes
+    with no linear-ref predecessor several levels deep, empty nodes inside alleles and successor lists in random
+    order.  Returns (node_sequences, edges, linear_ref_nodes, None)."""
+    seqs, edges, linear = {}, {}, []
+    nid = 0
+
+    def add(seq, is_lin):
+        nonlocal nid
+        seqs[nid] = seq
+        if is_lin:
+            linear.append(nid)
+        nid += 1
+        return nid - 1
+
+    def link(a, b):
+        edges.setdefault(a, []).append(b)
+
+    def allele(depth, allow_empty):
+        """a non-linear allele: returns (entry node, exit node)"""
+        if depth < max_depth and rng.random() < p_nest:
+            first = add(_rand_seq(rng, int(rng.integers(1, max_allele + 2))), False)
+            tail = first
+            for _ in range(int(rng.integers(1, 3))):
+                a_in, a_out = allele(depth + 1, True)
+                b_in, b_out = allele(depth + 1, seqs[a_in] != "" or a_in != a_out)
+                succ = [a_in, b_in] if rng.random() < 0.5 else [b_in, a_in]
+                for s in succ:
+                    link(tail, s)
+                tail = add(_rand_seq(rng, int(rng.integers(1, max_allele + 2))), False)
+                link(a_out, tail)
+                link(b_out, tail)
+            return first, tail
+        lo = 0 if allow_empty else 1
+        n = add(_rand_seq(rng, int(rng.integers(lo, max_allele + 1))), False)
+        return n, n
+
+    tail = add(_rand_seq(rng, int(rng.integers(min_ref, max_ref + 1))), True)
+    for _ in range(n_var):
+        ref_len = int(rng.integers(0, max_allele + 1))
+        ref_a = add(_rand_seq(rng, ref_len), ref_len > 0)          # empty: a linear-ref dummy, not listed as linear
+        alt_in, alt_out = allele(0, ref_len > 0)
+        succ = [ref_a, alt_in] if rng.random() < 0.5 else [alt_in, ref_a]
+        for s in succ:
+            link(tail, s)
+        head = add(_rand_seq(rng, int(rng.integers(min_ref, max_ref + 1))), True)
+        link(ref_a, head)
+        link(alt_out, head)
+        tail = head
+    return seqs, edges, linear, None

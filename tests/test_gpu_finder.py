@@ -247,15 +247,25 @@ def test_golden_chunk_cases():
         assert_same_records(finder_cols(f), exp)
 
 
-def test_unsupported_graphs_raise():
-    # a variant node whose only predecessor is a variant node
+def test_formerly_unsupported_graphs_match_the_oracle():
+    # a variant node whose only predecessor is a variant node (a two-node alternative allele)
     g = GraphArrays.from_dicts({0: "ACGTACGT", 1: "A", 2: "C", 3: "G", 4: "TTTTTTTT"},
                                {0: [1, 2], 2: [3], 1: [4], 3: [4]}, [0, 1, 4])
-    with pytest.raises(NotImplementedError):
-        DenseKmerFinder(g, 4).find()
+    for M in (1, 2, 4):
+        f = DenseKmerFinder(g, 4, max_variant_nodes=M)
+        if M == 1:          # the reference asserts at node 2: window at the limit, its only successor is not linear-ref
+            with pytest.raises(AssertionError):
+                f.find()
+            with pytest.raises(oracle.OracleError):
+                oracle.find(g, 4, max_variant_nodes=M)
+            continue
+        f.find()
+        assert_same_records(finder_cols(f), oracle.find(g, 4, max_variant_nodes=M))
     g2 = GraphArrays.from_dicts({0: "ACGTACGT", 1: "A", 2: "C", 3: "TTTTTTTT"}, {0: [1, 2], 1: [3], 2: [3]}, [0, 1, 3])
-    with pytest.raises(NotImplementedError):
-        DenseKmerFinder(g2, 4, only_follow_nodes={2}).find()
+    f = DenseKmerFinder(g2, 4, only_follow_nodes={2})
+    f.find()
+    assert_same_records(finder_cols(f), oracle.find(g2, 4, only_follow_nodes={2}))
+    assert 1 not in set(finder_cols(f)["nodes"].tolist())        # the forced allele hides its sibling (:386-388)
 
 
 def test_whitelist_and_only_store_nodes_filters():

@@ -1,0 +1,185 @@
+"""-m gpu: DenseKmerFinder.find() on graphs OUTSIDE the simple class -- nodes with no linear-ref predecessor
+(variants inside alternative alleles, multi-node alleles), `only_follow_nodes`, and the reference's
+`assert len(next_nodes) == 1` (kmer_finder.py:402) -- against the oracle and the reference-generated fixtures."""
+import json
+import os
+import numpy as np
+import pytest
+
+from gpu_util import finder_cols, assert_same_records
+from graph_kmer_index_amd import DenseKmerFinder, GraphArrays, CriticalGraphPaths, _lib
+from graph_kmer_index_amd.kmer_finder import classify_nodes
+from graphgen import nested_bubble_graph, deep_nested_graph, random_bubble_graph, overlapping_bubble_graph
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def run_case(g, k, M, one, follow=None, chunk=None, store=None):
+    """GPU find() vs oracle.find() incl. the assertion; returns 'ok' / 'assert' / 'skip'."""
+    try:
+        cn, co = oracle.critical_paths(g, k)
+    except oracle.OracleError:
+        return "skip"
+    kw = {}
+    if chunk is not None:
+        kw = dict(start_at_critical_path_number=chunk[0], stop_at_critical_path_number=chunk[1])
+    try:
+        exp, flags = oracle.find(g, k, (cn, co), one, M, only_follow_nodes=follow, only_store_nodes=store,
+                                 return_flags=True, **kw)
+        err = None
+    except oracle.OracleError as e:
+        exp, flags, err = None, 0, e.code
+    if err not in (None, 3) or flags & oracle.ORC_FLAG_UNDEFINED_BULK:
+        return "skip"
+    f = DenseKmerFinder(g, k, critical_graph_paths=CriticalGraphPaths(cn, co), only_save_one_node_per_kmer=one,
+                        max_variant_nodes=M, only_follow_nodes=follow, only_store_nodes=store, **kw)
+    if err == 3:
+        with pytest.raises(AssertionError):
+            f.find()
+        return "assert"
+    f.find()
+    assert_same_records(finder_cols(f), exp)
+    return "ok"
+
+
+GENERATORS = {
+    "nested": lambda r: nested_bubble_graph(r, n_var=int(r.integers(2, 6)), p_nest=0.7),
+    "deep": lambda r: deep_nested_graph(r, n_var=int(r.integers(1, 4)), max_depth=int(r.integers(1, 4))),
+    "deep_long": lambda r: deep_nested_graph(r, n_var=int(r.integers(1, 4)), max_depth=2, min_ref=3, max_ref=40,
+                                             max_allele=12),
+    "bubble": lambda r: random_bubble_graph(r),
+    "overlap": lambda r: overlapping_bubble_graph(r, n_var=int(r.integers(3, 7))),
+}
+
+
+@pytest.mark.parametrize("gen,n,seed,kmax", [("nested", 60, 31, 9), ("deep", 60, 32, 9), ("deep_long", 50, 33, 31),
+                                             ("nested", 30, 34, 31)])
+def test_nested_graphs_against_oracle(gen, n, seed, kmax):
+    rng = np.random.default_rng(seed)
+    seen = {"ok": 0, "assert": 0, "skip": 0}
+    general = 0
+    for _ in range(n):
+        seqs, edges, lin, af = GENERATORS[gen](rng)
+        g = GraphArrays.from_dicts(seqs, edges, lin, af)
+        for _ in range(4):
+            k = int(rng.integers(3, kmax + 1))
+            M = int(rng.choice([0, 1, 2, 3, 4, 5, 100]))
+            one = bool(rng.integers(0, 2))
+            general += classify_nodes(g, k, M)[1]
+            seen[run_case(g, k, M, one)] += 1
+    assert seen["ok"] > n and seen["assert"] > 0 and general > n, (seen, general)
+
+
+@pytest.mark.parametrize("gen,n,seed", [("bubble", 40, 41), ("nested", 40, 42), ("deep", 40, 43), ("overlap", 30, 44)])
+def test_only_follow_nodes_in_find(gen, n, seed):
+    """kmer_finder.py:386-388 in find(): forced successors bypass the limit and hide their siblings."""
+    rng = np.random.default_rng(seed)
+    seen = {"ok": 0, "assert": 0, "skip": 0}
+    for _ in range(n):
+        seqs, edges, lin, af = GENERATORS[gen](rng)
+        g = GraphArrays.from_dicts(seqs, edges, lin, af)
+        cand = [x for x in seqs if not g.is_ref[x] or rng.random() < 0.15]
+        if not cand:
+            continue
+        for _ in range(4):
+            k = int(rng.integers(3, 10))
+            M = int(rng.choice([0, 1, 2, 3, 100]))
+            follow = set(int(x) for x in rng.choice(cand, size=int(rng.integers(1, len(cand) // 2 + 2)), replace=False)
+                         if True)
+            seen[run_case(g, k, M, bool(rng.integers(0, 2)), follow=follow)] += 1
+    assert seen["ok"] > n, seen
+
+
+def test_chunked_runs_and_store_filter_on_nested_graphs():
+    rng = np.random.default_rng(51)
+    ok = 0
+    for _ in range(40):
+        seqs, edges, lin, af = deep_nested_graph(rng, n_var=int(rng.integers(3, 7)), max_depth=2, min_ref=2, max_ref=12)
+        g = GraphArrays.from_dicts(seqs, edges, lin, af)
+        k = int(rng.integers(3, 8))
+        try:
+            n_crit = len(oracle.critical_paths(g, k)[0])
+        except oracle.OracleError:
+            continue
+        a = int(rng.integers(0, n_crit + 1))
+        b = int(rng.integers(a, n_crit + 2))
+        ok += run_case(g, k, 100, bool(rng.integers(0, 2)), chunk=(a, b)) == "ok"
+        store = set(int(x) for x in rng.choice(list(seqs), size=max(1, len(seqs) // 3), replace=False))
+        ok += run_case(g, k, 100, False, store=store) == "ok"
+    assert ok > 40
+
+
+def test_flat_layouts_on_nested_graphs():
+    """find_flat_on_device (both layouts) = find() on general graphs too."""
+    rng = np.random.default_rng(52)
+    done = 0
+    for _ in range(30):
+        seqs, edges, lin, af = deep_nested_graph(rng, n_var=int(rng.integers(2, 6)), max_depth=2, min_ref=2, max_ref=30,
+                                                 max_allele=8)
+        g = GraphArrays.from_dicts(seqs, edges, lin, af)
+        k = int(rng.integers(3, 20))
+        one = bool(rng.integers(0, 2))
+        try:
+            cn, co = oracle.critical_paths(g, k)
+            exp, flags = oracle.find(g, k, (cn, co), one, 100, return_flags=True)
+        except oracle.OracleError:
+            continue
+        if flags & oracle.ORC_FLAG_UNDEFINED_BULK:
+            continue
+        pos = g.position_id_base()[exp["start_nodes"]] + exp["start_offsets"]
+        want = sorted(zip(exp["kmers"].tolist(), exp["nodes"].tolist(), pos.tolist(),
+                          exp["allele_frequencies"].astype(np.float32).tolist()))
+        for split in (True, False):
+            f = DenseKmerFinder(g, k, critical_graph_paths=CriticalGraphPaths(cn, co), only_save_one_node_per_kmer=one,
+                                max_variant_nodes=100)
+            d = f.find_flat_on_device(split_layout=split)
+            f.synchronize()
+            fl = d.to_flat_kmers()
+            got = sorted(zip(fl._hashes.astype(np.int64).tolist(), fl._nodes.astype(np.int64).tolist(),
+                             fl._ref_offsets.astype(np.int64).tolist(), fl._allele_frequencies.tolist()))
+            assert got == want
+            d.free()
+        done += 1
+    assert done > 15
+
+
+def test_reference_fixtures_for_nested_graphs():
+    """Records the Python reference produced for nested graphs (tests/golden/make_golden.py -> finder_nested.json);
+    cases where it raised its AssertionError are recorded as such."""
+    with open(os.path.join(GOLD, "finder_nested.json")) as fh:
+        cases = json.load(fh)
+    assert len(cases) >= 40
+    n_assert = 0
+    for case in cases:
+        seqs = {int(a): b for a, b in case["seqs"].items()}
+        edges = {int(a): b for a, b in case["edges"].items()}
+        g = GraphArrays.from_dicts(seqs, edges, case["linear"])
+        follow = None if case.get("follow") is None else set(case["follow"])
+        f = DenseKmerFinder(g, case["k"], only_save_one_node_per_kmer=case["one"], max_variant_nodes=case["M"],
+                            only_follow_nodes=follow)
+        if case["raises"]:
+            with pytest.raises(AssertionError):
+                f.find()
+            n_assert += 1
+            continue
+        f.find()
+        exp = dict(kmers=np.array(case["kmers"], np.int64), nodes=np.array(case["nodes"], np.int32),
+                   start_nodes=np.array(case["start_nodes"], np.int32),
+                   start_offsets=np.array(case["start_offsets"], np.int16),
+                   allele_frequencies=np.array(case["allele_frequencies"], np.float64))
+        assert_same_records(finder_cols(f), exp)
+    assert 0 < n_assert < len(cases)
+
+
+def test_struct_size_guard():
+    """A binding built against another gki_find_params layout is refused, not read out of bounds."""
+    import ctypes as C
+    g = GraphArrays.from_dicts({0: "ACGTACGT"}, {}, [0])
+    f = DenseKmerFinder(g, 3)
+    p = _lib.FindParams(3, 4, 0, 0, 0, 0, g.n_nodes, 0)
+    p.struct_size = 72
+    n = C.c_int64(0)
+    assert _lib.load().gki_finder_count(f._finder_handle(), C.byref(p), C.byref(n)) == 2
+    assert b"struct_size" in _lib.load().gki_last_error()

@@ -113,3 +113,60 @@ def test_indel_generator_graphs_match_reference():
         assert np.array_equal(o["kmers"], fl._hashes) and np.array_equal(o["nodes"], fl._nodes)
         assert np.array_equal(o["start_nodes"], fl._start_nodes) and np.array_equal(o["start_offsets"], fl._start_offsets)
         assert np.array_equal(o["allele_frequencies"], fl._allele_frequencies)
+
+
+@pytest.mark.parametrize("mode,n,seed", [("nested", 80, 5), ("deep", 80, 6), ("follow", 60, 7)])
+def test_nested_graphs_oracle_and_general_spec_match_reference(mode, n, seed):
+    """Graphs with nodes that have no linear-ref predecessor, and find() with only_follow_nodes (kmer_finder.py:386-388):
+    the reference itself, the oracle (exact order) and the order-free general rule the kernels implement
+    (tests/spec_general.py), including where the reference's `assert len(next_nodes) == 1` (:402) fires."""
+    from graphgen import nested_bubble_graph, deep_nested_graph
+    import spec_general
+    rng = np.random.default_rng(seed)
+    n_rows = n_assert = 0
+    for it in range(n):
+        k = int(rng.integers(3, 8))
+        M = int(rng.choice([0, 1, 2, 3, 4, 100]))
+        one = bool(rng.integers(0, 2))
+        if mode == "deep":
+            seqs, edges, lin, af = deep_nested_graph(rng, n_var=int(rng.integers(1, 4)), max_depth=int(rng.integers(1, 4)))
+        elif mode == "nested" or it % 2:
+            seqs, edges, lin, af = nested_bubble_graph(rng, n_var=int(rng.integers(2, 5)), p_nest=0.7)
+        else:
+            seqs, edges, lin, af = random_bubble_graph(rng)
+        g = GraphArrays.from_dicts(seqs, edges, lin, af)
+        rg = Graph.from_dicts(seqs, edges, lin, af)
+        follow = None
+        if mode == "follow":
+            cand = [x for x in seqs if not g.is_ref[x]]
+            follow = set(int(x) for x in rng.choice(cand, size=max(1, len(cand) // 3), replace=False))
+        try:
+            cp = CriticalGraphPaths.from_graph(rg, k)
+        except (OverflowError, AssertionError):
+            continue
+        crit = {int(a): int(b) for a, b in zip(cp.nodes, cp.offsets)}
+        f = DenseKmerFinder(rg, k, critical_graph_paths=cp, max_variant_nodes=M, only_save_one_node_per_kmer=one,
+                            only_follow_nodes=None if follow is None else set(follow))
+        try:
+            f.find()
+        except AssertionError:
+            with pytest.raises(oracle.OracleError):
+                oracle.find(g, k, (cp.nodes, cp.offsets), one, M, only_follow_nodes=follow)
+            with pytest.raises(spec_general.SpecError):
+                spec_general.spec_rows_general(g, k, M, one, critical=crit, follow=follow)
+            n_assert += 1
+            continue
+        fl = f.get_flat_kmers()
+        o, flags = oracle.find(g, k, (cp.nodes, cp.offsets), one, M, only_follow_nodes=follow, return_flags=True)
+        if follow is None:                         # with a follow set the reference iterates a Python set: order unpinned
+            assert np.array_equal(o["kmers"], fl._hashes) and np.array_equal(o["nodes"], fl._nodes)
+            assert np.array_equal(o["start_nodes"], fl._start_nodes) and np.array_equal(o["start_offsets"], fl._start_offsets)
+        ref_rows = Counter(zip(fl._hashes.tolist(), fl._start_nodes.tolist(), fl._start_offsets.tolist(),
+                               fl._nodes.tolist(), fl._allele_frequencies.tolist()))
+        assert Counter(zip(o["kmers"].tolist(), o["start_nodes"].tolist(), o["start_offsets"].tolist(),
+                           o["nodes"].tolist(), o["allele_frequencies"].tolist())) == ref_rows
+        if flags & oracle.ORC_FLAG_UNDEFINED_BULK:
+            continue
+        assert spec_general.spec_rows_general(g, k, M, one, critical=crit, follow=follow) == ref_rows
+        n_rows += 1
+    assert n_rows > n // 3 and (mode == "follow" or n_assert > 0)
