@@ -218,3 +218,13 @@ def test_topological_rank_host_function():
     out = np.zeros(2, dtype=np.int32)
     assert lib.gki_topological_rank(2, _lib.hptr(edge_start), _lib.hptr(cyc), _lib.hptr(out)) != 0
     assert b"cycle" in C.c_char_p(lib.gki_last_error()).value
+
+
+def test_product_library_has_no_tuning_or_debug_switches():
+    """The A/B knobs and the expansion-skipping diagnostic exist only in `make tuning` builds (-DGKI_TUNING)."""
+    from graph_kmer_index_amd import _lib
+    with open(_lib.LIB_PATH, "rb") as fh:
+        blob = fh.read()
+    for name in (b"GKI_DBG", b"GKI_SW", b"GKI_NE_CAP", b"GKI_RUN_BLOCKS", b"GKI_BND_BLOCKS", b"GKI_INT_BLOCKS",
+                 b"GKI_OVERLAP_EMIT", b"GKI_BOUNDARY_FIRST", b"g_dbg_skip_expand"):
+        assert name not in blob, name

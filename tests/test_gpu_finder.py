@@ -428,3 +428,14 @@ def test_many_empty_nodes_in_a_row():
     f = DenseKmerFinder(g, 31, max_variant_nodes=100)
     with pytest.raises(_lib.GkiError):
         f.find()
+
+
+def test_environment_switches_do_not_change_find(monkeypatch):
+    # round 1 shipped a diagnostic (GKI_DBG_SKIP_EXPAND) that dropped the boundary records when set
+    for name, val in (("GKI_DBG_SKIP_EXPAND", "1"), ("GKI_BND_BLOCKS", "1"), ("GKI_SW", "128"), ("GKI_OVERLAP_EMIT", "1")):
+        monkeypatch.setenv(name, val)
+    g = synthetic_snp_graph(60000, 700, k=31, seed=77)
+    for one in (True, False):
+        f = DenseKmerFinder(g, 31, only_save_one_node_per_kmer=one, max_variant_nodes=5)
+        f.find()
+        assert_same_records(finder_cols(f), oracle.find(g, 31, None, one, 5))

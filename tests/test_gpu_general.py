@@ -183,3 +183,32 @@ def test_struct_size_guard():
     n = C.c_int64(0)
     assert _lib.load().gki_finder_count(f._finder_handle(), C.byref(p), C.byref(n)) == 2
     assert b"struct_size" in _lib.load().gki_last_error()
+
+
+def test_integration_stub_runs():
+    """Executes the binding INTEGRATION.md section B shows to a maintainer of the reference, verbatim, against the built
+    library: README toy graph (BASELINE configs[0]) through graph_to_device + find, compared with the records the
+    reference produced for it (tests/golden/finder_toy.json `readme_c1`)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "INTEGRATION.md")) as fh:
+        text = fh.read()
+    blocks = re.findall(r"```python\n(# graph_kmer_index/_gki\.py.*?)```", text, flags=re.S)
+    assert len(blocks) == 1
+    os.environ["GKI_LIB"] = _lib.LIB_PATH
+    ns = {}
+    exec(compile(blocks[0], "INTEGRATION.md#B", "exec"), ns)
+    with open(os.path.join(GOLD, "finder_toy.json")) as fh:
+        case = [c for c in json.load(fh) if c["name"] == "readme_c1"][0]
+    g = GraphArrays.from_dicts({int(a): b for a, b in case["seqs"].items()}, {int(a): b for a, b in case["edges"].items()},
+                               case["linear"])
+    h = ns["graph_to_device"](g.node_size, g.seq, g.edge_start, g.edges, g.rev_start, g.rev_edges, g.is_ref, g.allele_freq)
+    kmers, start_nodes, start_offsets, nodes, af = ns["find"](h, case["k"], 4, False, g.n_nodes)
+    got = dict(kmers=kmers, nodes=nodes, start_nodes=start_nodes, start_offsets=start_offsets, allele_frequencies=af)
+    exp = dict(kmers=np.array(case["kmers"], np.int64), nodes=np.array(case["nodes"], np.int32),
+               start_nodes=np.array(case["start_nodes"], np.int32), start_offsets=np.array(case["start_offsets"], np.int16),
+               allele_frequencies=np.array(case["allele_frequencies"], np.float64))
+    assert len(kmers) == 26
+    assert_same_records(got, exp)
+    # the stub refuses a library with another struct layout
+    assert "gki_find_params_size" in blocks[0]
