@@ -5,13 +5,18 @@ bubbles (BASELINE.json configs[2]), DenseKmerFinder -> FlatKmers columns residen
 
     python bench.py --gpus N --steps K --warmup W
 
-One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the environment under torch.distributed.run).  Every rank
-holds the whole graph and runs the critical-path range `sharding.shard_range` gives it (strong scaling: the 3 Gbp
-graph is fixed); there is no collective in the timed region.  torch.distributed (gloo) is used only for the barrier
-and the max-over-ranks of the timing -- the compute path is libgki_hip.so through ctypes.
+One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the environment, as
+torch.distributed.run exports them).  Every rank holds the whole graph and runs the critical-path range
+`sharding.shard_range` gives it (strong scaling: the 3 Gbp graph is fixed); there is no collective in the timed
+region.  The barrier and the max-over-ranks of the timing go over `parallel.SocketControlPlane` (plain TCP to rank 0);
+neither torch nor any other framework is imported -- the compute path is libgki_hip.so through ctypes.
 
 A step = gki_finder_count (boundary count kernel + prefix sums) + gki_finder_emit_flat (interior + boundary emit
-kernels) over the rank's shard, inputs (graph arrays) already in HBM.  Rank 0 prints one JSON line.
+kernels) over the rank's shard, inputs (graph arrays) already in HBM.  Rank 0 prints one JSON line.  At N=1 the same
+line carries two secondary records measured after the timed region on the step's own output: `index_build`
+(CollisionFreeKmerIndex.from_flat_kmers of the variant index, collision_free_kmer_index.py:423-467) and `read_mapping`
+(BASELINE configs[4]: reads -> k-mers of both strands -> CollisionFreeKmerIndex.get -> node counts,
+read_kmers.py:67-70, collision_free_kmer_index.py:303-315).
 """
 import argparse
 import json
@@ -45,6 +50,79 @@ def pmc_traffic(n_ref_bases, n_sites, k):
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def secondary_records(lib, _lib, g, k, finder, out, n_reads, modulo=452930477, max_hits=10):
+    """Index build and read mapping on the step's output (N=1, after the timed region).  Index = the records whose
+    window crosses a node boundary, i.e. the KAGE-like variant index of SURVEY.md 8(d) C5 = the boundary section of
+    the split layout."""
+    import ctypes as C
+    from graph_kmer_index_amd.flat_kmers import DeviceFlatKmers
+    from graph_kmer_index_amd.collision_free_kmer_index import DeviceIndex
+    from graph_kmer_index_amd.graph import synthetic_haplotype_sequence
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_reads import make_reads
+
+    def sync():
+        _lib.check(lib.gki_device_synchronize())
+
+    n_int = finder.interior_records()
+    nb = out.n - n_int
+    bnd = DeviceFlatKmers(nb, out.hashes.view(n_int, nb), out.nodes.view(n_int, nb), out.ref_offsets.view(n_int, nb),
+                          out.allele_frequencies.view(n_int, nb))
+    idx = None
+    for _ in range(2):                                   # the second build is the measurement (first: pool warm-up)
+        if idx is not None:
+            idx.free()
+        sync()
+        t = time.perf_counter()
+        idx = DeviceIndex.build(bnd, modulo)
+        sync()
+        dt = time.perf_counter() - t
+    passes = -(-int(modulo - 1).bit_length() // 8)
+    # algorithmic bytes of the build as implemented (csrc/gki_index.hip), per record: bucket keys 8 R + 8 W; per radix
+    # pass 4 R (histogram) + 8 R + 8 W (ranked scatter of key/index pairs); row pack 24 R + 32 W; row gather 4 + 32 R +
+    # 24 W; directory 4 R; frequencies 16 R + 2 W; plus the directory itself, 2 x 4 B x modulo written once
+    per_record = 16 + 20 * passes + 56 + 60 + 4 + 18
+    moved = per_record * nb + 8 * modulo
+    index_build = {"records": int(nb), "ms": 1e3 * dt, "records_per_s": nb / dt, "modulo": modulo, "radix_passes": passes,
+                   "frequencies": True, "bytes_moved_model": int(moved), "bytes_per_record_model": per_record,
+                   "achieved_GBps": moved / dt / 1e9, "frac_of_hbm_peak": moved / dt / 1e9 / HBM_PEAK_GBS,
+                   "timed": "wall clock around DeviceIndex.build incl. its allocations, device synchronised"}
+    log("index build: %d records in %.1f ms" % (nb, 1e3 * dt))
+
+    t = time.perf_counter()
+    letters = make_reads(synthetic_haplotype_sequence(g), n_reads, np.random.default_rng(99))
+    t_reads = time.perf_counter() - t
+    d_letters = _lib.DeviceArray.from_host(letters)
+    d_start = _lib.DeviceArray.from_host(np.arange(n_reads + 1, dtype=np.int64) * 150)
+    table = idx.probe_table()
+    counts = _lib.DeviceArray(g.n_nodes, np.uint32)
+    nk, nh = C.c_int64(0), C.c_int64(0)
+    for _ in range(3):                                   # the last launch is the measurement
+        counts.zero()
+        sync()
+        t = time.perf_counter()
+        _lib.check(lib.gki_probe_reads_count_nodes(table, d_letters.ptr, d_start.ptr, n_reads, k, 3, max_hits, counts.ptr,
+                                                   g.n_nodes, C.byref(nk), C.byref(nh)))
+        sync()
+        dt_map = time.perf_counter() - t
+    rate = C.c_double(0.0)
+    _lib.check(lib.gki_measure_random_loads(2 << 30, 1 << 31, C.byref(rate)))       # ~40 ms on a 2 GB table
+    sectors = nk.value + nh.value                        # one directory sector per k-mer + at least one row sector per hit
+    read_mapping = {"reads": n_reads, "read_length": 150, "strands": 2, "kmers": nk.value, "hits": nh.value,
+                    "ms": 1e3 * dt_map, "kmers_per_s": nk.value / dt_map, "reads_per_s": n_reads / dt_map,
+                    "sectors_per_s_lower_bound": sectors / dt_map, "random_loads_per_s_measured": rate.value,
+                    "frac_of_random_request_rate": sectors / dt_map / rate.value if rate.value else None,
+                    "index_records": int(nb), "kernel": "k_probe_reads (letters -> both strands -> probe -> node counts, fused)",
+                    "note": "BASELINE configs[4] names 1e8 reads; %d are mapped here so that the default run stays within "
+                            "minutes (their host-side simulation takes %.0f s); the rate does not depend on the count"
+                            % (n_reads, t_reads)}
+    log("read mapping: %d reads, %.3g k-mers/s; random-request rate %.3g/s" % (n_reads, nk.value / dt_map, rate.value))
+    for b in (d_letters, d_start, counts):
+        b.free()
+    idx.free()
+    return index_build, read_mapping
 
 
 _CPU = {}
@@ -117,6 +195,7 @@ def main():
     ap.add_argument("--all-nodes", action="store_true", help="diagnostic: only_save_one_node_per_kmer=False")
     ap.add_argument("--pretend-shard", default=None, help="diagnostic: R/W -> run only rank R's shard of W on this one GPU")
     ap.add_argument("--verify", action="store_true", help="size-independent checks on the full output (slow)")
+    ap.add_argument("--reads", type=float, default=4e6, help="reads of the read_mapping record (0: skip the secondary records)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,20 +208,8 @@ def main():
         cores = args.cpu_cores or min(16, len(os.sched_getaffinity(0)))
         cpu = cpu_baseline(int(args.cpu_sample_bases), args.k, args.max_variant_nodes, cores)
         log("cpu baseline: %.3g k-mers/s on %d cores" % (cpu["value"], cpu["cores"]))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist            # gloo: barrier + max of a scalar only
-        # gloo prints its connection banner on stdout; keep stdout clean for the one JSON line
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-            dist.barrier()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
+    from graph_kmer_index_amd.parallel import SocketControlPlane
+    plane = SocketControlPlane(rank, world)           # barrier + max / sum of two scalars; a no-op at world 1
 
     from graph_kmer_index_amd import _lib, DenseKmerFinder, CriticalGraphPaths, DeviceGraph
     from graph_kmer_index_amd.graph import synthetic_snp_graph, synthetic_linear_graph, synthetic_indel_graph
@@ -182,8 +249,7 @@ def main():
 
     def barrier():
         _lib.check(lib.gki_device_synchronize())
-        if dist is not None:
-            dist.barrier()
+        plane.barrier()
 
     out = None
     interior_ms = []
@@ -202,20 +268,16 @@ def main():
     kern = {name: finder.kernel_ms(i) for i, name in enumerate(["count_boundary", "emit_interior", "emit_boundary", "setup_scans"])}
     n_interior = finder.interior_records()
 
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt[0])
-        nn = torch.tensor([n_local], dtype=torch.int64)
-        dist.all_reduce(nn, op=dist.ReduceOp.SUM)
-        n_total = int(nn[0])
-    else:
-        n_total = n_local
+    elapsed = max(plane.allgather_float(elapsed))
+    n_total = sum(plane.allgather_int(n_local))
 
     checks = None
     if args.verify:
         checks = verify(out, g, k, n_interior)
+    secondary = None
+    if (world == 1 and args.reads > 0 and not (args.linear or args.indels or args.all_nodes or args.pretend_shard)
+            and out.n - n_interior > 0):
+        secondary = secondary_records(lib, _lib, g, k, finder, out, int(args.reads))
 
     if rank == 0:
         ms_step = 1000.0 * elapsed / args.steps
@@ -225,6 +287,8 @@ def main():
         traffic, traffic_src = pmc_traffic(G, S, k) if world == 1 and not args.linear and not args.indels else (None, None)
         res = {
             "metric": "k-mers hashed+indexed per second (k=31, 3 Gbp graph)", "value": value, "unit": "k-mers/s",
+            "timed_region": "enumerate + hash + FlatKmers rows in HBM (gki_finder_count + gki_finder_emit_flat); the index "
+                            "build and the read side are the separate records index_build / read_mapping below",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: synthetic %.3g bp linear-ref obgraph + %.3g SNP bubbles, k=%d, "
@@ -242,11 +306,12 @@ def main():
         }
         if checks is not None:
             res["verify"] = checks
+        if secondary is not None:
+            res["index_build"], res["read_mapping"] = secondary
         res["cpu_baseline"] = cpu
         print(json.dumps(res), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    plane.barrier()
+    plane.close()
 
 
 def verify(out, g, k, n_interior):

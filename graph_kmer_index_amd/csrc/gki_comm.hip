@@ -98,6 +98,7 @@ int gki_comm_allgather_flat(gki_comm *c, const int64_t *h_counts, const void *d_
     void *outp[4] = {d_out_hashes, d_out_nodes, d_out_ref_offsets, d_out_af32};
     const size_t esz[4] = {8, 4, 8, 4};
     hipStream_t s = c->stream;
+    HIP_TRY(hipDeviceSynchronize());                  // the columns were produced on other streams (finder, partition)
     // own shard: device-to-device copy
     for (int col = 0; col < 4; col++)
         if (h_counts[me] > 0)
@@ -137,6 +138,7 @@ int gki_comm_alltoall_flat(gki_comm *c, const int64_t *h_send_start, const void 
     void *outp[4] = {d_out_hashes, d_out_nodes, d_out_ref_offsets, d_out_af32};
     const size_t esz[4] = {8, 4, 8, 4};
     hipStream_t s = c->stream;
+    HIP_TRY(hipDeviceSynchronize());                  // the columns were produced on other streams (finder, partition)
     const int64_t own = h_send_start[me + 1] - h_send_start[me];
     for (int col = 0; col < 4; col++)
         if (own > 0)

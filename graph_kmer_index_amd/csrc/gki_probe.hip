@@ -470,3 +470,50 @@ int gki_probe_lookup_emit(gki_probe *p, const void *d_queries, int64_t q, int64_
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------ random-request rate
+// What bounds a probe is not bytes but 64-byte requests that miss L2.  This measures the rate the
+// device sustains right now: independent random 8-byte loads from a table of `table_bytes`, 4 in flight per lane.
+namespace {
+__device__ __forceinline__ uint64_t rr_mix(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
+__global__ __launch_bounds__(256) void k_random_loads(const uint64_t *__restrict__ table, uint64_t n_entries, int64_t n_loads,
+                                                      uint64_t *__restrict__ sink) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint64_t acc = 0;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n_loads; i0 += stride * 4) {
+        uint64_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = table[__umul64hi(rr_mix((uint64_t)(i0 + u * stride)), n_entries)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc ^= v[u];
+    }
+    if (acc == 0x1234567ull) sink[0] = acc;
+}
+}  // namespace
+
+extern "C" int gki_measure_random_loads(int64_t table_bytes, int64_t n_loads, double *loads_per_s) {
+    *loads_per_s = 0.0;
+    if (table_bytes < 4096 || n_loads < 1) return gki_set_error(GKI_ERR_BAD_ARG, "measure_random_loads: bad sizes");
+    uint64_t *table = nullptr, *sink = nullptr;
+    HIP_TRY(gki_dev_malloc((void **)&table, (size_t)table_bytes));
+    HIP_TRY(gki_dev_malloc((void **)&sink, 8));
+    HIP_TRY(hipMemset(table, 1, (size_t)table_bytes));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    float ms = 0.f;
+    for (int rep = 0; rep < 2; rep++) {              // the second launch is the measurement
+        HIP_TRY(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_random_loads, dim3(2048), dim3(256), 0, 0, table, (uint64_t)(table_bytes / 8), n_loads, sink);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(e1, 0));
+        HIP_TRY(hipEventSynchronize(e1));
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)gki_dev_free(table); (void)gki_dev_free(sink);
+    if (ms > 0.f) *loads_per_s = (double)n_loads / ((double)ms * 1e-3);
+    return GKI_OK;
+}

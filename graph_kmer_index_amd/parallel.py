@@ -4,10 +4,18 @@ all-gather(v) of the finished FlatKmers columns over xGMI, then the CollisionFre
 Mirrors the reference's CLI `index` + `make_from_flat` pair (command_line_interface.py:553-622, 156-174) where a
 process pool runs `DenseKmerFinder` per chunk and the results are concatenated in chunk order.
 
-The control plane (exchange of the RCCL id and of the per-rank record counts) is any object with
-`broadcast_bytes(b, src)` and `allgather_int(x)`; `TorchControlPlane` implements it over torch.distributed (gloo).
-torch is never used for compute or GPU memory."""
+The control plane (exchange of the RCCL id and of the per-rank record counts: 128 bytes and a few integers) is any
+object with `rank`, `world`, `broadcast_bytes(b, src)`, `allgather_int(x)` and `allgather_ints(xs)`.
+`SocketControlPlane` is the product's: plain TCP to rank 0 at MASTER_ADDR:MASTER_PORT, no third-party package.
+`TorchControlPlane` is an optional adapter for callers that already run under torch.distributed.
+`LoopbackWorld` runs all ranks of a build in ONE process on ONE GPU (threads; the exchanges become device copies): the
+bucket-partitioned build on a single GPU for indexes past the reference's 2^31-record limit, and the way the
+multi-rank logic is tested without a multi-GPU node."""
 import ctypes as C
+import os
+import socket
+import struct
+import threading
 import numpy as np
 
 from . import _lib
@@ -15,7 +23,123 @@ from .flat_kmers import DeviceFlatKmers
 from .sharding import shard_range
 
 
+class _GatherControlPlane:
+    """Everything a control plane offers, on top of one primitive: `_allgather_bytes(payload) -> [payload of rank 0,
+    ..., payload of rank world-1]` on every rank."""
+    rank = 0
+    world = 1
+
+    def _allgather_bytes(self, payload):
+        raise NotImplementedError
+
+    def broadcast_bytes(self, b, src=0):
+        return self._allgather_bytes(b if self.rank == src and b is not None else b"")[src]
+
+    def allgather_int(self, x):
+        return [struct.unpack("<q", p)[0] for p in self._allgather_bytes(struct.pack("<q", int(x)))]
+
+    def allgather_ints(self, xs):
+        """Every rank's list of integers -> the matrix (row r = rank r's list)."""
+        xs = [int(x) for x in xs]
+        rows = self._allgather_bytes(struct.pack("<%dq" % len(xs), *xs))
+        return [list(struct.unpack("<%dq" % (len(p) // 8), p)) for p in rows]
+
+    def allgather_float(self, x):
+        return [struct.unpack("<d", p)[0] for p in self._allgather_bytes(struct.pack("<d", float(x)))]
+
+    def barrier(self):
+        self._allgather_bytes(b"")
+
+
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("control plane: peer closed the connection")
+        buf += chunk
+    return bytes(buf)
+
+
+def _send_msg(sock, payload):
+    sock.sendall(struct.pack("<q", len(payload)) + payload)
+
+
+def _recv_msg(sock):
+    return _recv_exact(sock, struct.unpack("<q", _recv_exact(sock, 8))[0])
+
+
+class SocketControlPlane(_GatherControlPlane):
+    """Star over TCP: rank 0 listens on (addr, port), every other rank keeps one connection to it.  A gather is
+    "everyone sends to rank 0, rank 0 sends the list back".  Defaults come from the launcher's environment
+    (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT, as torch.distributed.run and mpirun wrappers export them)."""
+
+    def __init__(self, rank=None, world=None, addr=None, port=None, timeout=120.0):
+        self.rank = int(os.environ.get("RANK", 0)) if rank is None else int(rank)
+        self.world = int(os.environ.get("WORLD_SIZE", 1)) if world is None else int(world)
+        addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        # one above the launcher's port: torch.distributed.run's own rendezvous store listens on MASTER_PORT itself
+        port = int(port) if port is not None else int(os.environ.get("MASTER_PORT", 29400)) + 1
+        self._peers, self._sock, self._server = [], None, None
+        if self.world == 1:
+            return
+        if self.rank == 0:
+            self._server = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            self._server.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            self._server.bind((addr, port))
+            self._server.listen(self.world)
+            self._server.settimeout(timeout)
+            peers = {}
+            while len(peers) < self.world - 1:
+                conn, _ = self._server.accept()
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                conn.settimeout(timeout)
+                peers[struct.unpack("<q", _recv_exact(conn, 8))[0]] = conn
+            self._peers = [peers[r] for r in range(1, self.world)]
+        else:
+            import time
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    self._sock = socket.create_connection((addr, port), timeout=timeout)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.05)
+            self._sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            self._sock.sendall(struct.pack("<q", self.rank))
+
+    def _allgather_bytes(self, payload):
+        payload = bytes(payload)
+        if self.world == 1:
+            return [payload]
+        if self.rank == 0:
+            parts = [payload] + [_recv_msg(c) for c in self._peers]
+            blob = b"".join(struct.pack("<q", len(p)) + p for p in parts)
+            for c in self._peers:
+                _send_msg(c, blob)
+            return parts
+        _send_msg(self._sock, payload)
+        blob, parts, off = _recv_msg(self._sock), [], 0
+        for _ in range(self.world):
+            n = struct.unpack_from("<q", blob, off)[0]
+            parts.append(blob[off + 8:off + 8 + n])
+            off += 8 + n
+        return parts
+
+    def close(self):
+        for c in self._peers + [x for x in (self._sock, self._server) if x is not None]:
+            try:
+                c.close()
+            except OSError:
+                pass
+        self._peers, self._sock, self._server = [], None, None
+
+
 class TorchControlPlane:
+    """Optional adapter: the same interface over an initialised torch.distributed process group."""
+
     def __init__(self, group=None):
         import torch.distributed as dist
         self._dist, self._group = dist, group
@@ -44,6 +168,107 @@ class TorchControlPlane:
         out = [torch.zeros(len(xs), dtype=torch.int64) for _ in range(self.world)]
         self._dist.all_gather(out, mine, group=self._group)
         return [[int(v) for v in o] for o in out]
+
+
+class LoopbackWorld:
+    """All `world` ranks in this process, on this GPU: `run(fn)` calls fn(comm) once per rank, each in its own thread,
+    with a `LoopbackComm` whose collectives rendezvous between the threads and move the data with device copies.  The
+    kernels, the partition, the slice builds and the probes are the real ones; only ncclSend/ncclRecv/ncclAllReduce are
+    replaced."""
+
+    def __init__(self, world):
+        self.world = int(world)
+        self._barrier = threading.Barrier(self.world)
+        self._slots = [None] * self.world
+
+    def exchange(self, rank, item):
+        """Every rank deposits an item; returns the list of all of them (valid until the next exchange)."""
+        self._barrier.wait()                      # the previous round's readers are done
+        self._slots[rank] = item
+        self._barrier.wait()
+        return list(self._slots)
+
+    def run(self, fn):
+        results, errors = [None] * self.world, []
+
+        def work(r):
+            try:
+                results[r] = fn(LoopbackComm(self, r))
+            except BaseException as e:            # noqa: BLE001 -- re-raised in the caller's thread
+                errors.append(e)
+                self._barrier.abort()
+        threads = [threading.Thread(target=work, args=(r,)) for r in range(self.world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            real = [e for e in errors if not isinstance(e, threading.BrokenBarrierError)]
+            raise (real or errors)[0]
+        return results
+
+
+class _LoopbackControl(_GatherControlPlane):
+    def __init__(self, world_obj, rank):
+        self._w, self.rank, self.world = world_obj, rank, world_obj.world
+
+    def _allgather_bytes(self, payload):
+        return self._w.exchange(self.rank, bytes(payload))
+
+
+class LoopbackComm:
+    """`Comm`'s interface for one rank of a LoopbackWorld."""
+
+    def __init__(self, world_obj, rank):
+        self._w = world_obj
+        self.control = _LoopbackControl(world_obj, rank)
+
+    @staticmethod
+    def _copy(dst, dst_off, src, src_off, n):
+        if n > 0:
+            sz = dst.dtype.itemsize
+            _lib.check(_lib.load().gki_memcpy_d2d(C.c_void_p(dst.ptr.value + dst_off * sz),
+                                                  C.c_void_p(src.ptr.value + src_off * sz), n * sz))
+
+    def allgather_flat(self, dflat):
+        _lib.check(_lib.load().gki_device_synchronize())
+        parts = self._w.exchange(self.control.rank, dflat)
+        counts = [p.n for p in parts]
+        out = DeviceFlatKmers.allocate(sum(counts))
+        off = 0
+        for p in parts:
+            for col in ("hashes", "nodes", "ref_offsets", "allele_frequencies"):
+                self._copy(getattr(out, col), off, getattr(p, col), 0, p.n)
+            off += p.n
+        out.n = off
+        _lib.check(_lib.load().gki_device_synchronize())
+        self._w.exchange(self.control.rank, None)      # nobody frees a shard another rank is still reading
+        return out, counts
+
+    def alltoall_flat(self, dflat, send_start):
+        _lib.check(_lib.load().gki_device_synchronize())
+        me = self.control.rank
+        parts = self._w.exchange(me, (dflat, [int(x) for x in send_start]))
+        recv_counts = [ss[me + 1] - ss[me] for _, ss in parts]
+        recv_start = np.concatenate([[0], np.cumsum(recv_counts)]).astype(np.int64)
+        out = DeviceFlatKmers.allocate(int(recv_start[-1]))
+        for r, (src, ss) in enumerate(parts):
+            for col in ("hashes", "nodes", "ref_offsets", "allele_frequencies"):
+                self._copy(getattr(out, col), int(recv_start[r]), getattr(src, col), ss[me], recv_counts[r])
+        out.n = int(recv_start[-1])
+        _lib.check(_lib.load().gki_device_synchronize())
+        self._w.exchange(me, None)
+        return out, [int(x) for x in recv_start]
+
+    def allreduce_counts(self, counts):
+        _lib.check(_lib.load().gki_device_synchronize())
+        host = self._w.exchange(self.control.rank, counts.to_host())
+        total = np.sum(np.stack(host).astype(np.uint64), axis=0).astype(np.uint32)      # uint32 wrap like ncclSum
+        _lib.check(_lib.load().gki_memcpy_h2d(counts.ptr, _lib.hptr(total), total.nbytes))
+        return counts
+
+    def close(self):
+        pass
 
 
 class Comm:

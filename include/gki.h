@@ -317,12 +317,20 @@ int gki_probe_reads_count_nodes(gki_probe *p, const void *d_reads, const void *d
                                 int strands, int64_t max_hits, void *d_counts, int64_t n_counts, int64_t *n_kmers,
                                 int64_t *n_hits);
 
+/* Measurement aid: independent random 8-byte loads per second the device sustains from a table of table_bytes (every
+ * load that misses L2 is one 64-byte request -- the unit the probe kernels are bound by, not bytes).  Runs n_loads loads
+ * twice and reports the second launch.  bench.py reports the read-side rate as a fraction of this. */
+int gki_measure_random_loads(int64_t table_bytes, int64_t n_loads, double *loads_per_s);
+
 /* ---------------------------------------------------------------- multi-GPU exchange (RCCL over xGMI)
  * One process per GPU.  The reference gathers its per-process FlatKmers by pickling them through a
  * process pool and concatenating (command_line_interface.py:607-614, flat_kmers.py:71-90); here every
  * rank's finished columns are exchanged once, shard r landing at offset sum(counts[:r]), so that every
  * GPU holds the concatenation in rank order.  The 128-byte id comes from rank 0 and travels over the
- * caller's control plane (bench / parallel.py use torch.distributed gloo); h_counts[world] likewise. */
+ * caller's control plane (parallel.SocketControlPlane: plain TCP to rank 0); h_counts[world] likewise. */
+/* Ordering: every exchange entry point first waits for all work already submitted to the device (the columns come
+ * from finder / partition streams), runs on the communicator's own stream and returns when the exchange has completed;
+ * a caller needs no synchronisation of its own on either side. */
 #define GKI_COMM_ID_BYTES 128
 typedef struct gki_comm gki_comm;
 int gki_comm_get_unique_id(void *h_id);

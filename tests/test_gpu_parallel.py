@@ -188,3 +188,109 @@ def test_rccl_world1_partitioned_build_and_read_mapping():
         total += part.to_host()
     assert np.array_equal(total, want.to_host())
     comm.close()
+
+
+# ------------------------------------------------------------------ world > 1 in one process (parallel.LoopbackWorld)
+def _oracle_flat(g, k, cp, **kw):
+    """FlatKmers columns of oracle.find (ref_offset = position id of the end position, float32 frequencies)."""
+    exp = oracle.find(g, k, (cp.nodes, cp.offsets), True, 5, **kw)
+    pos = (g.position_id_base()[exp["start_nodes"]] + exp["start_offsets"]).astype(np.uint64)
+    return exp["kmers"].astype(np.uint64), exp["nodes"].astype(np.uint32), pos, exp["allele_frequencies"].astype(np.float32)
+
+
+def _canon(cols):
+    o = np.lexsort((cols[1], cols[0], cols[2]))
+    return [c[o] for c in cols]
+
+
+def _oracle_read_counts(index, letters, read_start, k, n_nodes):
+    counts = np.zeros(n_nodes, np.uint64)
+    for r in range(len(read_start) - 1):
+        read = bytes(letters[read_start[r]:read_start[r + 1]]).decode()
+        rc = read[::-1].translate(str.maketrans("ACGTacgt", "TGCAtgca"))
+        for strand in (read, rc):
+            for kmer in oracle.read_kmers(strand, k):
+                nodes = oracle.index_get(index, int(kmer))[0]
+                if nodes is not None:
+                    np.add.at(counts, nodes, 1)
+    return counts
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_loopback_ranks_build_the_oracle_index(world):
+    """build_index_sharded / build_index_partitioned / map_reads_partitioned with `world` ranks (threads of this
+    process, exchanges as device copies) against the ORACLE: the gathered index equals oracle.index_build of the
+    rank-ordered shard columns element by element, every bucket-range slice equals that index cut by bucket range with
+    its directory rebased, and node counts of reads equal a loop of oracle get()."""
+    from graph_kmer_index_amd.parallel import LoopbackWorld, map_reads_replicated
+    from graph_kmer_index_amd.sharding import shard_range
+    k, modulo = 31, 100003
+    g = synthetic_snp_graph(90000 + 7000 * world, 1000, k=k, seed=40 + world)
+    cp = CriticalGraphPaths.from_graph(g, k)
+    kw = dict(only_save_one_node_per_kmer=True, max_variant_nodes=5)
+
+    # every rank's shard = the oracle's records for the same critical-path range (multiset), ...
+    shards = []
+    for r in range(world):
+        a, b = shard_range(g, cp, r, world)
+        d = find_sharded(g, k, cp, r, world, **kw)
+        got = d.to_flat_kmers()
+        d.free()
+        cols = [got._hashes, got._nodes, got._ref_offsets, got._allele_frequencies]
+        want = _oracle_flat(g, k, cp, start_at_critical_path_number=a, stop_at_critical_path_number=b)
+        for x, y in zip(_canon(cols), _canon(list(want))):
+            assert np.array_equal(x, y)
+        shards.append(cols)
+    # ... and together the oracle's whole run
+    everything = [np.concatenate([s[c] for s in shards]) for c in range(4)]
+    for x, y in zip(_canon(everything), _canon(list(_oracle_flat(g, k, cp)))):
+        assert np.array_equal(x, y)
+    ref = oracle.index_build(*everything, modulo=modulo)        # stable, like the device build: element-wise comparable
+
+    rng = np.random.default_rng(world)
+    starts = rng.integers(0, len(g.seq) - 80, size=60)
+    letters = np.frombuffer(b"ACGT", np.uint8)[g.seq[(starts[:, None] + np.arange(80)[None, :]).ravel()]].copy()
+    read_start = np.arange(61, dtype=np.int64) * 80
+    want_counts = _oracle_read_counts(ref, letters, read_start, k, g.n_nodes)
+    assert want_counts.sum() > 0
+
+    def gathered(comm):
+        index, counts = build_index_sharded(g, k, cp, comm, modulo=modulo, **kw)
+        n = index.n
+        out = {c: getattr(index, c).to_host(n) for c in ("kmers", "nodes", "ref_offsets", "allele_frequencies", "frequencies")}
+        out["hashes_to_index"], out["n_kmers"], out["counts"] = index.hashes_to_index.to_host(), index.n_kmers.to_host(), counts
+        a, b = read_shard(60, comm.control.rank, comm.control.world)
+        part = map_reads_replicated(index, comm, letters[a * 80:b * 80], read_start[a:b + 1] - read_start[a], k, g.n_nodes)
+        out["read_counts"] = part.to_host()
+        index.free()
+        return out
+
+    for out in LoopbackWorld(world).run(gathered):
+        assert out["counts"] == [len(s[0]) for s in shards]
+        for name in ("kmers", "nodes", "ref_offsets", "allele_frequencies", "frequencies", "hashes_to_index", "n_kmers"):
+            assert np.array_equal(out[name], ref["_" + name]), name
+        assert np.array_equal(out["read_counts"], want_counts)
+
+    def partitioned(comm):
+        index = build_index_partitioned(g, k, cp, comm, modulo=modulo, **kw)
+        n = index.n
+        out = {c: getattr(index, c).to_host(n) for c in ("kmers", "nodes", "ref_offsets", "allele_frequencies", "frequencies")}
+        out["hashes_to_index"], out["n_kmers"] = index.hashes_to_index.to_host(), index.n_kmers.to_host()
+        out["range"] = (index.bucket_begin, index.n_buckets)
+        out["read_counts"] = map_reads_partitioned(index, comm, letters, read_start, k, g.n_nodes).to_host()
+        index.free()
+        return out
+
+    base = 0
+    for r, out in enumerate(LoopbackWorld(world).run(partitioned)):
+        lo, hi = bucket_range(modulo, world, r)
+        assert out["range"] == (lo, hi - lo)
+        n = len(out["kmers"])
+        for name in ("kmers", "nodes", "ref_offsets", "allele_frequencies", "frequencies"):
+            assert np.array_equal(out[name], ref["_" + name][base:base + n]), name
+        nk = ref["_n_kmers"][lo:hi]
+        assert np.array_equal(out["n_kmers"], nk)
+        assert np.array_equal(out["hashes_to_index"][nk > 0] + base, ref["_hashes_to_index"][lo:hi][nk > 0])
+        assert np.array_equal(out["read_counts"], want_counts)
+        base += n
+    assert base == len(everything[0])

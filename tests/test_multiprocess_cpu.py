@@ -108,3 +108,47 @@ def test_shards_partition_small_graphs_with_few_or_offset0_critical_points():
                                full["nodes"].tolist()))
             assert rows == want, (it, k, world, cuts)
     assert seen_no_crit > 0 and seen_offset0 > 0
+
+
+def _socket_worker(rank, world, port, tmpdir):
+    """Twin of _worker over parallel.SocketControlPlane (the product's control plane: plain TCP, no torch)."""
+    from graph_kmer_index_amd.parallel import SocketControlPlane
+    plane = SocketControlPlane(rank, world, "127.0.0.1", port)
+    g = synthetic_snp_graph(60000, 700, k=31, seed=21)
+    cp = CriticalGraphPaths.from_graph(g, 31)
+    a, b = shard_range(g, cp, rank, world)
+    mine = oracle.find(g, 31, (cp.nodes, cp.offsets), True, 5, start_at_critical_path_number=a,
+                       stop_at_critical_path_number=b)
+    counts = plane.allgather_int(len(mine["kmers"]))
+    ident = plane.broadcast_bytes(bytes(range(128)) if rank == 0 else None, 0)
+    modulo = 100003
+    bucket = mine["kmers"].astype(np.uint64) % np.uint64(modulo)
+    begins = np.array([modulo * p // world for p in range(world)], dtype=np.uint64)
+    send = np.bincount(np.searchsorted(begins, bucket, side="right") - 1, minlength=world)
+    matrix = plane.allgather_ints(send.tolist())
+    slowest = max(plane.allgather_float(0.5 + rank))
+    np.savez(os.path.join(tmpdir, "r%d.npz" % rank), counts=np.array(counts), ident=np.frombuffer(ident, np.uint8),
+             send=send, matrix=np.array(matrix), slowest=slowest, n=len(mine["kmers"]))
+    plane.barrier()
+    plane.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_socket_control_plane_ranks(tmp_path, world):
+    import multiprocessing
+    port = 31000 + os.getpid() % 2000 + world
+    ctx = multiprocessing.get_context("spawn")
+    procs = [ctx.Process(target=_socket_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    parts = [np.load(str(tmp_path / ("r%d.npz" % r))) for r in range(world)]
+    g = synthetic_snp_graph(60000, 700, k=31, seed=21)
+    n_full = len(oracle.find(g, 31, None, True, 5)["kmers"])
+    for p in parts:
+        assert p["counts"].tolist() == [int(q["n"]) for q in parts] and sum(p["counts"]) == n_full
+        assert p["ident"].tolist() == list(range(128))
+        assert np.array_equal(p["matrix"], np.stack([q["send"] for q in parts]))
+        assert float(p["slowest"]) == world - 0.5
