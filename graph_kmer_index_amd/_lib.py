@@ -27,12 +27,13 @@ class FindParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("k", C.c_int32), ("max_variant_nodes", C.c_int32),
                 ("one_node_per_kmer", C.c_int32), ("layout", C.c_int32), ("node_begin", C.c_int64),
                 ("off_begin", C.c_int64), ("node_end", C.c_int64), ("off_end", C.c_int64),
-                ("h_lossy_crit", C.c_void_p), ("h_node_rank", C.c_void_p), ("h_node_flags", C.c_void_p)]
+                ("h_lossy_crit", C.c_void_p), ("h_node_rank", C.c_void_p), ("h_node_flags", C.c_void_p),
+                ("h_store_nodes", C.c_void_p)]
 
     def __init__(self, k, max_variant_nodes, one_node_per_kmer, layout, node_begin, off_begin, node_end, off_end,
-                 h_lossy_crit=None, h_node_rank=None, h_node_flags=None):
+                 h_lossy_crit=None, h_node_rank=None, h_node_flags=None, h_store_nodes=None):
         super().__init__(C.sizeof(FindParams), k, max_variant_nodes, one_node_per_kmer, layout, node_begin, off_begin,
-                         node_end, off_end, h_lossy_crit, h_node_rank, h_node_flags)
+                         node_end, off_end, h_lossy_crit, h_node_rank, h_node_flags, h_store_nodes)
 
 
 class IndexView(C.Structure):

@@ -43,6 +43,7 @@ struct FindArgs {
     int32_t split, pad;      // output layout: 0 = by end node (boundary block, then interior run, per node);
                              // 1 = all interior records (by position) first, then all boundary records (by node)
     const uint8_t *nflags;   // NULL, or the GKI_NODE_* byte of every node (general graphs, include/gki.h)
+    const uint8_t *store;    // NULL, or only_store_nodes membership per node (kmer_finder.py:153); needs nflags
 };
 
 // does node n belong to the run (critical-path chunk / shard)?
@@ -103,6 +104,20 @@ __device__ __forceinline__ int32_t bnd_len_of(const DevGraph &g, const FindArgs 
     if (a.nflags) { if (a.nflags[n] & GKI_NODE_DEAD) reach = size; }  // general graphs: the search never enters the node
     else if (!g.is_ref[n] && a.M < 1) reach = size;                   // variant node, limit 0: nothing admissible
     return size < reach ? size : reach;
+}
+
+// Interior offsets [lo, hi) of node n in this run (bl = bnd_len_of).  only_store_nodes (kmer_finder.py:153) drops the
+// records of a node outside the set -- except those of the bulk path, which ignores the filter (:370-374): offsets
+// k+2 .. size-2 of a node longer than 2k+3 (:272).
+__device__ __forceinline__ void interior_range(const FindArgs &a, int64_t n, int32_t size, int32_t bl, int64_t *lo_out, int64_t *hi_out) {
+    int64_t lo = bl, hi = size;
+    if (n == a.node_begin && a.off_begin > lo) lo = a.off_begin;
+    if (n == a.node_end && a.off_end < hi) hi = a.off_end;
+    if (a.store && !a.store[n]) {
+        if (size > 2 * a.k + 3) { if (lo < a.k + 2) lo = a.k + 2; if (hi > size - 1) hi = size - 1; }
+        else hi = lo;
+    }
+    *lo_out = lo; *hi_out = hi;
 }
 
 // ------------------------------------------------------------------------------------ boundary walk
@@ -205,6 +220,19 @@ __device__ __noinline__ bool history_ok(const DevGraph &g, const uint8_t *__rest
     }
 }
 
+// only_store_nodes (kmer_finder.py:145-154): records a window with nodes path[0..n_path) yields -- its smallest node
+// if that is in the set (only_save_one_node_per_kmer), else one per node in the set.
+__device__ __forceinline__ int stored_nodes(const uint8_t *__restrict__ store, const int32_t *path, int n_path, bool one_node) {
+    if (one_node) {
+        int32_t mn = path[0];
+        for (int i = 1; i < n_path; i++) mn = path[i] < mn ? path[i] : mn;
+        return store[mn] ? 1 : 0;
+    }
+    int c = 0;
+    for (int i = 0; i < n_path; i++) c += store[path[i]] ? 1 : 0;
+    return c;
+}
+
 template <bool HAS_LOSSY, bool GEN>
 __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
                                                         uint32_t *__restrict__ bcount, uint32_t *__restrict__ total,
@@ -235,6 +263,7 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
             const int cn = HAS_LOSSY ? lossy_of(lossy, (int32_t)n) : -1;
             for (int o = o_lo > k - 1 ? o_lo : k - 1; o < o_hi; o++) {
                 if (HAS_LOSSY && cn >= 0 && o + 1 - k <= cn - 1 && cn <= o) continue;
+                if (GEN && a.store && !a.store[n]) continue;
                 count += 1;
             }
             int hi = o_hi < k - 1 ? o_hi : k - 1;
@@ -288,7 +317,11 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
                             if (!ok) to = from;
                         }
                         if (GEN && from < 0 && from < to) from = 0;      // offset -1 has no record
-                        if (from < to) count += (uint32_t)(to - from) * (a.one_node ? 1u : (uint32_t)(L + 1));
+                        if (from < to) {
+                            uint32_t per_window = a.one_node ? 1u : (uint32_t)(L + 1);
+                            if (GEN && a.store) per_window = (uint32_t)stored_nodes(a.store, path, L + 1, a.one_node != 0);
+                            count += (uint32_t)(to - from) * per_window;
+                        }
                         // the graph ends before the window of oc is complete (graph start): the search saw what there is
                         if (GEN && chk && wq.rev_begin == wq.rev_end && c + s < k - 1 - oc && vq >= a.M) *err = GKI_ERR_NOT_ONE_REF_SUCC;
                         deeper = (k - 1 - c - s > w_lo) && !(HAS_LOSSY && cq >= 0);
@@ -305,9 +338,8 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
         }
         uint32_t ic = 0;                              // interior offsets of this node in this run
         if (size > 0 && in_run(a, n)) {
-            int64_t lo = bl, hi2 = size;
-            if (n == a.node_begin && a.off_begin > lo) lo = a.off_begin;
-            if (n == a.node_end && a.off_end < hi2) hi2 = a.off_end;
+            int64_t lo, hi2;
+            interior_range(a, n, size, bl, &lo, &hi2);
             ic = hi2 > lo ? (uint32_t)(hi2 - lo) : 0u;
         }
         bcount[n] = count;
@@ -458,6 +490,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                 // windows inside the node itself (lossy-restart nodes only; rare, written by the lane alone)
                 for (int o = o_lo > k - 1 ? o_lo : k - 1; o < o_hi; o++) {
                     if (HAS_LOSSY && cn >= 0 && o + 1 - k <= cn - 1 && cn <= o) continue;
+                    if (GEN && a.store && !a.store[n]) continue;
                     put(out, idx++, gki_extract(g.seq2, wn.seq_start + o + 1 - k, k), (int32_t)n, (int32_t)n, o, pos0 + o, wn.af);
                 }
                 hi = o_hi < k - 1 ? o_hi : k - 1;
@@ -546,6 +579,11 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                     }
                 }
             }
+            int e_nls = e_nl;                        // nodes of the window that get a record (only_store_nodes)
+            if (GEN && a.store && ev) {
+                e_nls = stored_nodes(a.store, path, e_nl, !ALL);
+                if (e_nls == 0) ev = false;
+            }
             if (ALL && ev && e_nl > NLQ) {
                 // a window over more nodes than the queue carries (rows of empty or 1-bp nodes): written by the lane
                 // alone, per offset the distinct nodes ascending
@@ -555,7 +593,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                     for (int r = 0; r < e_nl; r++) {
                         int32_t best = INT_MAX;
                         for (int j2 = 0; j2 < e_nl; j2++) { const int32_t v = path[j2]; if (v > last && v < best) best = v; }
-                        put(out, idx++, h, best, (int32_t)n, o, pos0 + o, e_maf);
+                        if (!(GEN && a.store) || a.store[best]) put(out, idx++, h, best, (int32_t)n, o, pos0 + o, e_maf);
                         last = best;
                     }
                 }
@@ -574,14 +612,16 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                     q.maf[slot] = e_maf; q.mn[slot] = e_mn; q.n[slot] = (int32_t)n;
                     q.from[slot] = (uint8_t)e_from; q.cnt[slot] = (uint8_t)(e_to - e_from);
                     if (ALL) {
-                        q.nl[slot] = (uint8_t)e_nl;
+                        q.nl[slot] = (uint8_t)e_nls;
+                        const bool filt = GEN && a.store;
                         for (int a2 = 0; a2 < e_nl; a2++) {            // rank sort: the nodes of a path are distinct
                             const int32_t v = path[a2];
+                            if (filt && !a.store[v]) continue;
                             int rank = 0;
-                            for (int b2 = 0; b2 < e_nl; b2++) rank += path[b2] < v ? 1 : 0;
+                            for (int b2 = 0; b2 < e_nl; b2++) rank += (path[b2] < v && !(filt && !a.store[path[b2]])) ? 1 : 0;
                             q.nodes[slot][rank] = v;
                         }
-                        idx += (int64_t)(e_to - e_from) * e_nl;
+                        idx += (int64_t)(e_to - e_from) * e_nls;
                     } else
                     idx += e_to - e_from;
                 }
@@ -603,8 +643,8 @@ __global__ __launch_bounds__(256) void k_node_emit(DevGraph g, FindArgs a, const
         const int32_t size = g.node_size[n];
         if (size <= 0) continue;
         const bool inside = in_run(a, n);
-        int64_t lo = inside ? bnd_len_of(g, a, lossy, n, size) : 0;
-        if (n == a.node_begin && a.off_begin > lo) lo = a.off_begin;
+        int64_t lo = 0, hi = size;
+        if (inside) interior_range(a, n, size, bnd_len_of(g, a, lossy, n, size), &lo, &hi);
         const int64_t ss = g.seq_start[n];
         NodeEmit e;
         e.glo = inside ? ss + lo : (int64_t)0x7FFFFFFFFFFFFFFFll;        // outside the run: never interior
@@ -612,8 +652,6 @@ __global__ __launch_bounds__(256) void k_node_emit(DevGraph g, FindArgs a, const
         e.E = g.pos_base[n] - ss;
         e.node = (int32_t)n;
         e.af = (float)g.allele_freq[n];
-        int64_t hi = size;
-        if (n == a.node_end && a.off_end < hi) hi = a.off_end;
         e.cnt = (inside && hi > lo) ? (int32_t)(hi - lo) : 0;
         e.pad0 = 0; e.pad1 = 0;
         ne[g.node_rank[n]] = e;         // indexed by rank among non-empty nodes: what the bitmap popcount yields
@@ -767,7 +805,7 @@ struct gki_finder {
     int64_t *rec_base, *bnd_base;     // by-node layout: rec_base only; split layout: interior bases / boundary bases
     NodeEmit *ne;
     uint16_t *lossy;
-    uint8_t *nflags;                  // general graphs only (gki_find_params.h_node_flags), allocated on first use
+    uint8_t *nflags, *store;          // general graphs / only_store_nodes (gki_find_params), allocated on first use
     void *scan_tmp; int64_t scan_tmp_bytes;
     int *d_err; int64_t *d_totals; unsigned long long *d_bsum;
     int32_t *d_rank;                  // topological ranks of the run in progress (non-topological node ids only)
@@ -944,7 +982,7 @@ int gki_finder_destroy(gki_finder *f) {
     (void)hipStreamSynchronize(f->stream);
     (void)hipStreamSynchronize(f->stream2);
     void *ptrs[] = {f->bcount, f->total, f->rec_base, f->bnd_base, f->ne, f->lossy, f->scan_tmp, f->d_err, f->d_totals, f->d_bsum,
-                    f->d_rank, f->nflags};
+                    f->d_rank, f->nflags, f->store};
     for (void *p : ptrs) if (p) (void)gki_dev_free(p);
     for (int i = 0; i < 8; i++) (void)hipEventDestroy(f->ev[i]);
     (void)hipEventDestroy(f->ev_ready);
@@ -976,7 +1014,13 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
     a.n1 = p->node_end < d.n_nodes ? p->node_end + 1 : d.n_nodes;
     a.split = p->layout == GKI_LAYOUT_SPLIT ? 1 : 0; a.pad = 0;
     a.rank = nullptr; a.rank_begin = 0; a.rank_end = 0;
-    a.nflags = nullptr;
+    a.nflags = nullptr; a.store = nullptr;
+    if (p->h_store_nodes) {
+        if (!p->h_node_flags) return gki_set_error(GKI_ERR_BAD_ARG, "h_store_nodes needs h_node_flags (gki_classify_nodes)");
+        if (!f->store) HIP_TRY(gki_dev_malloc((void **)&f->store, (size_t)d.n_nodes));
+        HIP_TRY(hipMemcpyAsync(f->store, p->h_store_nodes, (size_t)d.n_nodes, hipMemcpyHostToDevice, s));
+        a.store = f->store;
+    }
     if (p->h_node_flags) {
         if (!f->nflags) HIP_TRY(gki_dev_malloc((void **)&f->nflags, (size_t)d.n_nodes));
         HIP_TRY(hipMemcpyAsync(f->nflags, p->h_node_flags, (size_t)d.n_nodes, hipMemcpyHostToDevice, s));

@@ -221,10 +221,16 @@ class DenseKmerFinder:
                 rank = g.__dict__["_topological_rank"]
                 if not (start_at is not None and start_at > 0):
                     node_begin, off_begin = int(np.argmin(rank)), 0   # "from the graph start" = from rank 0
+        store = None
+        if self._only_store_nodes is not None:                     # kmer_finder.py:153, applied by the general kernels
+            store = np.zeros(g.n_nodes, dtype=np.uint8)
+            ids = np.fromiter((int(x) for x in self._only_store_nodes), dtype=np.int64)
+            store[ids[(ids >= 0) & (ids < g.n_nodes)]] = 1
+            general = True
         p = _lib.FindParams(k, self._max_variant_nodes, int(self._only_save_one_node_per_kmer), 0,
                             node_begin, off_begin, node_end, off_end, _lib.hptr(lossy), _lib.hptr(rank),
-                            _lib.hptr(flags) if general else None)
-        p._keep = (lossy, rank, flags)
+                            _lib.hptr(flags) if general else None, _lib.hptr(store))
+        p._keep = (lossy, rank, flags, store)
         if node_begin >= g.n_nodes:
             return None
         return p
@@ -257,13 +263,6 @@ class DenseKmerFinder:
         keep = None
         if self._whitelist is not None:                                # kmer_finder.py:130-132, 362-365
             keep = self._in_whitelist(kmers)
-        if self._only_store_nodes is not None:                         # :153 (the bulk path :370-374 ignores it)
-            g, k = self._arrays, self._k
-            osn = np.fromiter((int(x) for x in self._only_store_nodes), dtype=np.int64)
-            size = g.node_size[start_nodes]
-            bulk = (nodes == start_nodes) & (start_offsets >= k + 2) & (start_offsets <= size - 2) & (size > 2 * k + 3)
-            sel = np.isin(nodes, osn) | bulk
-            keep = sel if keep is None else keep & sel
         if keep is not None:
             kmers, start_nodes, start_offsets, nodes, af = (c[keep] for c in (kmers, start_nodes, start_offsets, nodes, af))
         self._cols = dict(kmers=kmers, start_nodes=start_nodes, start_offsets=start_offsets, nodes=nodes, af=af)
@@ -273,8 +272,6 @@ class DenseKmerFinder:
         HBM (the CLI `index` path, command_line_interface.py:559-614).  Returns DeviceFlatKmers.
         split_layout: records whose window lies inside one node first, then the others (GKI_LAYOUT_SPLIT) -- the
         same multiset, written as two dense streams; False gives find()'s by-node order."""
-        if self._only_store_nodes is not None:
-            raise NotImplementedError("the only_store_nodes filter is applied by find() on the host")
         n = self._count(layout=1 if split_layout else 0)
         if out is None or out.hashes.n < n:
             out = DeviceFlatKmers.allocate(n)

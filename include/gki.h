@@ -182,6 +182,10 @@ typedef struct {
     const int32_t *h_node_rank;
     /* host uint8[n_nodes] from gki_classify_nodes, or NULL when it reported general == 0. */
     const uint8_t *h_node_flags;
+    /* host uint8[n_nodes] membership of only_store_nodes (kmer_finder.py:153) or NULL: a record is written only for a
+     * node in the set -- except the records of the bulk path (offsets k+2 .. size-2 of a node longer than 2k+3), which
+     * the reference writes regardless (:370-374).  Needs h_node_flags (the general kernels apply it). */
+    const uint8_t *h_store_nodes;
 } gki_find_params;
 /* sizeof(gki_find_params) of this build, for bindings to check at load time. */
 int64_t gki_find_params_size(void);

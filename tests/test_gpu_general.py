@@ -212,3 +212,46 @@ def test_integration_stub_runs():
     assert_same_records(got, exp)
     # the stub refuses a library with another struct layout
     assert "gki_find_params_size" in blocks[0]
+
+
+@pytest.mark.parametrize("one", [True, False])
+def test_only_store_nodes_on_device(one):
+    """kmer_finder.py:153 applied by the kernels (count and emit passes), incl. the bulk path that ignores the filter
+    (:370-374): find() and find_flat_on_device() against oracle.find(only_store_nodes=...)."""
+    from graph_kmer_index_amd.graph import synthetic_snp_graph, synthetic_indel_graph
+    rng = np.random.default_rng(61 + one)
+    cases = [synthetic_snp_graph(40000, 500, k=31, seed=5), synthetic_indel_graph(30000, 400, k=31, seed=6)]
+    for _ in range(12):
+        seqs, edges, lin, af = deep_nested_graph(rng, n_var=int(rng.integers(2, 6)), max_depth=2, min_ref=2, max_ref=90,
+                                                 max_allele=6)
+        cases.append(GraphArrays.from_dicts(seqs, edges, lin, af))
+    done = 0
+    for i, g in enumerate(cases):
+        k = 31 if i < 2 else int(rng.integers(3, 16))
+        ids = np.nonzero(g.exists)[0]
+        if i < 2:
+            store = set(int(x) for x in np.nonzero(g.is_ref == 0)[0][::2])         # what UniqueVariantKmersFinder passes
+        else:
+            store = set(int(x) for x in rng.choice(ids, size=max(1, len(ids) // 3), replace=False))
+        try:
+            cn, co = oracle.critical_paths(g, k)
+            exp, flags = oracle.find(g, k, (cn, co), one, 100, only_store_nodes=store, return_flags=True)
+        except oracle.OracleError:
+            continue
+        if flags & oracle.ORC_FLAG_UNDEFINED_BULK:
+            continue
+        f = DenseKmerFinder(g, k, critical_graph_paths=CriticalGraphPaths(cn, co), only_save_one_node_per_kmer=one,
+                            max_variant_nodes=100, only_store_nodes=store)
+        f.find()
+        assert_same_records(finder_cols(f), exp)
+        pos = g.position_id_base()[exp["start_nodes"]] + exp["start_offsets"]
+        want = sorted(zip(exp["kmers"].tolist(), exp["nodes"].tolist(), pos.tolist()))
+        for split in (True, False):
+            d = f.find_flat_on_device(split_layout=split)
+            f.synchronize()
+            fl = d.to_flat_kmers()
+            assert sorted(zip(fl._hashes.astype(np.int64).tolist(), fl._nodes.astype(np.int64).tolist(),
+                              fl._ref_offsets.astype(np.int64).tolist())) == want
+            d.free()
+        done += 1
+    assert done >= 8
