@@ -89,7 +89,13 @@ def secondary_records(lib, _lib, g, k, finder, out, n_reads, modulo=452930477, m
                    "frequencies": True, "bytes_moved_model": int(moved), "bytes_per_record_model": per_record,
                    "achieved_GBps": moved / dt / 1e9, "frac_of_hbm_peak": moved / dt / 1e9 / HBM_PEAK_GBS,
                    "timed": "wall clock around DeviceIndex.build incl. its allocations, device synchronised"}
-    log("index build: %d records in %.1f ms" % (nb, 1e3 * dt))
+    # scalar CollisionFreeKmerIndex.get (:303-315): one launch + one synchronisation per call (gki_index_get_small)
+    some = bnd.hashes.view(0, min(nb, 4096)).to_host()
+    t = time.perf_counter()
+    for x in some[:2000]:
+        idx.get_small([int(x)], 10)
+    index_build["scalar_get_calls_per_s"] = min(len(some), 2000) / (time.perf_counter() - t)
+    log("index build: %d records in %.1f ms; scalar get %.0f calls/s" % (nb, 1e3 * dt, index_build["scalar_get_calls_per_s"]))
 
     t = time.perf_counter()
     letters = make_reads(synthetic_haplotype_sequence(g), n_reads, np.random.default_rng(99))

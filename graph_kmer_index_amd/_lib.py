@@ -91,6 +91,7 @@ SYMBOLS = {
     "gki_index_lookup_count": (_I32, [C.POINTER(IndexView), _P, _I64, _I64, _P, C.POINTER(_I64)]),
     "gki_index_count_nodes": (_I32, [C.POINTER(IndexView), _P, _I64, _I64, _P, _I64]),
     "gki_index_lookup_emit": (_I32, [C.POINTER(IndexView), _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
+    "gki_index_get_small": (_I32, [C.POINTER(IndexView), _P, _I32, _I64, _P, _P, _I64]),
     "gki_probe_create": (_I32, [C.POINTER(IndexView), C.POINTER(_P)]),
     "gki_probe_destroy": (_I32, [_P]),
     "gki_probe_lookup_count": (_I32, [_P, _P, _I64, _I64, _P, C.POINTER(_I64)]),

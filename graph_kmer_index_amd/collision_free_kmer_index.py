@@ -83,6 +83,17 @@ class DeviceIndex:
             b.free()
         return out
 
+    def get_small(self, queries, max_hits=10, capacity=1024):
+        """CollisionFreeKmerIndex.get for up to 64 k-mers in one launch (gki_index_get_small): per query (number of
+        hits, int64 positions of the first min(hits, capacity, 1024) of them in bucket order)."""
+        q = np.ascontiguousarray(queries, dtype=np.uint64)
+        n_hits = np.zeros(len(q), dtype=np.int64)
+        pos = np.empty(max(len(q) * capacity, 1), dtype=np.int64)
+        view = self.view()
+        _lib.check(_lib.load().gki_index_get_small(C.byref(view), _lib.hptr(q), len(q), int(min(max_hits, 2 ** 62)),
+                                                   _lib.hptr(n_hits), _lib.hptr(pos), capacity))
+        return [(n, pos[i * capacity:i * capacity + min(n, capacity, 1024)].copy()) for i, n in enumerate(n_hits.tolist())]
+
     def probe_table(self):
         """The probe-table re-layout of this index in HBM (gki_probe_create), built on first use."""
         if self._probe is None:
@@ -437,7 +448,9 @@ class CollisionFreeKmerIndex:
     def get(self, kmer, max_hits=10):
         """collision_free_kmer_index.py:303-315, served by the batched device probe with one query; the hit
         positions index this object's own arrays, so every dtype comes back as stored."""
-        _, pos, _ = self._device_index().lookup_positions(np.array([int(kmer)], dtype=np.uint64), max_hits)
+        n, pos = self._device_index().get_small([int(kmer)], max_hits)[0]
+        if n > len(pos):                                 # a k-mer with more than 1024 records: the batched pair
+            _, pos, _ = self._device_index().lookup_positions(np.array([int(kmer)], dtype=np.uint64), max_hits)
         if len(pos) == 0:
             return None, None, None, None
         return self._nodes[pos], self._ref_offsets[pos], self._frequencies[pos], self._allele_frequencies[pos]
@@ -459,14 +472,31 @@ class CollisionFreeKmerIndex:
         return [nodes[a:b] for a, b in zip(idx[:-1], idx[1:])]
 
     def get_frequency(self, kmer, include_reverse_complement=True, k=31):
-        nodes, _, frequencies, _ = self.get(kmer, max_hits=1000000000000000)
-        f = 0 if nodes is None else int(frequencies[0])
+        """:336-352 -- the k-mer and its reverse complement in ONE launch (first hit's frequency of each)."""
+        queries = [int(kmer)]
         if include_reverse_complement:
-            rev = int(kmer_hash_to_reverse_complement_hash(kmer, k))
-            nodes, _, frequencies, _ = self.get(rev, max_hits=1000000000000000)
-            if nodes is not None:
-                f += int(frequencies[0])
+            queries.append(int(kmer_hash_to_reverse_complement_hash(kmer, k)))
+        f = 0
+        for n, pos in self._device_index().get_small(queries, 1000000000000000, capacity=1):
+            if n:                                        # the first hit's frequency (:342, :349)
+                f += int(np.asarray(self._frequencies)[pos[0]])
         return f
+
+    def get_frequencies(self, kmers, include_reverse_complement=True, k=31):
+        """get_frequency for many k-mers: int64 array, two batched probes (k-mers, reverse complements)."""
+        kmers = np.ascontiguousarray(np.asarray(kmers)).astype(np.uint64)
+
+        def first_hit_frequency(queries):
+            hs, pos, _ = self._device_index().lookup_positions(queries, max_hits=1000000000000000)
+            f = np.zeros(len(queries), dtype=np.int64)
+            has = np.diff(hs) > 0
+            f[has] = np.asarray(self._frequencies)[pos[hs[:-1][has]]]
+            return f
+        out = first_hit_frequency(kmers)
+        if include_reverse_complement:
+            from .kmer_hashing import kmer_hashes_to_reverse_complement_hash
+            out = out + first_hit_frequency(kmer_hashes_to_reverse_complement_hash(kmers, k))
+        return out
 
     def get_nodes_and_ref_offsets_from_multiple_kmers(self, kmers, max_hits=10):
         """:354-376 -- one batched device probe instead of a Python loop of get()."""
@@ -503,16 +533,7 @@ class CollisionFreeKmerIndex:
         get_frequency adds the hit of the reverse complement (k=31, :336-352).  Two batched probes of `other`."""
         kmers = np.asarray(self._kmers)
         uniq, inverse = np.unique(kmers, return_inverse=True)
-
-        def first_hit_frequency(queries):
-            hs, pos, _ = other._device_index().lookup_positions(queries, max_hits=1000000000000000)
-            f = np.zeros(len(queries), dtype=np.int64)
-            has = np.diff(hs) > 0
-            f[has] = np.asarray(other._frequencies)[pos[hs[:-1][has]]]
-            return f
-
-        from .kmer_hashing import kmer_hashes_to_reverse_complement_hash
-        freq = first_hit_frequency(uniq) + first_hit_frequency(kmer_hashes_to_reverse_complement_hash(uniq, 31))
+        freq = other.get_frequencies(uniq, True, 31)
         value = np.maximum(min_frequency, freq * multiplier)
         self._frequencies = np.asarray(self._frequencies).copy()
         self._frequencies[:] = value[inverse].astype(self._frequencies.dtype)

@@ -11,6 +11,7 @@
 // Inside a bucket records keep their input order (stable sort), which is also what the oracle's
 // stable restatement produces, so the build is comparable element by element.
 #include "gki_common.h"
+#include <mutex>
 
 namespace {
 
@@ -792,3 +793,70 @@ int gki_index_lookup_emit(const gki_index_view *ix, const void *d_queries, int64
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------ scalar get
+// CollisionFreeKmerIndex.get (collision_free_kmer_index.py:303-315) for a handful of k-mers: one launch, one wave per
+// query, queries and results in pinned host memory the kernel reads and writes directly -- no staging copies, no
+// second pass.  A query's hits (positions in the payload arrays, bucket order) land in its own `cap`-sized segment.
+namespace {
+constexpr int SMALL_Q = 64;                 // queries per call
+constexpr int SMALL_CAP = 1024;             // hits kept per query (more: the count says so and the caller goes batched)
+struct SmallStage {                         // pinned, device-mapped
+    uint64_t query[SMALL_Q];
+    int64_t n_hits[SMALL_Q];
+    int64_t pos[SMALL_Q * SMALL_CAP];
+};
+__global__ __launch_bounds__(64) void k_get_small(IndexDev ix, SmallStage *st, int64_t max_hits) {
+    const int qi = blockIdx.x, lane = threadIdx.x;
+    const uint64_t km = st->query[qi];
+    const uint64_t b = km % ix.modulo - ix.bucket_begin;                  // :304
+    int64_t total = 0;
+    if (b < ix.n_buckets) {
+        const int64_t s = ix.h2i[b], m = ix.nk[b];                        // :305-306
+        bool first = true;
+        for (int64_t j0 = 0; j0 < m; j0 += 64) {
+            const int64_t j = s + j0 + lane;
+            const bool hit = j0 + lane < m && ix.kmers[j] == km;          // :309
+            const uint64_t mask = __ballot(hit);
+            if (mask == 0) continue;
+            if (first) {                                                  // :312 frequency of the FIRST hit
+                const int64_t jf = s + j0 + (__ffsll((unsigned long long)mask) - 1);
+                if (ix.freq && (int64_t)ix.freq[jf] > max_hits) { total = 0; break; }
+                first = false;
+            }
+            if (hit) {
+                const int64_t o = total + __popcll(mask & ((1ull << lane) - 1ull));
+                if (o < SMALL_CAP) st->pos[(int64_t)qi * SMALL_CAP + o] = j;
+            }
+            total += __popcll(mask);
+        }
+    }
+    if (lane == 0) st->n_hits[qi] = total;
+}
+std::mutex g_small_mu;
+SmallStage *g_small_host = nullptr, *g_small_dev = nullptr;
+}  // namespace
+
+extern "C" int gki_index_get_small(const gki_index_view *ix, const uint64_t *h_queries, int q, int64_t max_hits,
+                                   int64_t *h_n_hits, int64_t *h_positions, int64_t capacity_per_query) {
+    if (q < 0 || q > SMALL_Q) return gki_set_error(GKI_ERR_BAD_ARG, "get_small: 0..%d queries per call", SMALL_Q);
+    if (capacity_per_query < 0) return gki_set_error(GKI_ERR_BAD_ARG, "get_small: negative capacity");
+    if (q == 0) return GKI_OK;
+    std::lock_guard<std::mutex> lock(g_small_mu);
+    if (!g_small_host) {
+        HIP_TRY(hipHostMalloc((void **)&g_small_host, sizeof(SmallStage), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void **)&g_small_dev, g_small_host, 0));
+    }
+    for (int i = 0; i < q; i++) g_small_host->query[i] = h_queries[i];
+    hipLaunchKernelGGL(k_get_small, dim3((unsigned)q), dim3(64), 0, 0, view_of(ix), g_small_dev, max_hits);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(0));
+    for (int i = 0; i < q; i++) {
+        const int64_t n = g_small_host->n_hits[i];
+        h_n_hits[i] = n;                              // may exceed what was kept: min(n, SMALL_CAP, capacity) positions are valid
+        int64_t keep = n < SMALL_CAP ? n : SMALL_CAP;
+        if (keep > capacity_per_query) keep = capacity_per_query;
+        for (int64_t j = 0; j < keep; j++) h_positions[(int64_t)i * capacity_per_query + j] = g_small_host->pos[(int64_t)i * SMALL_CAP + j];
+    }
+    return GKI_OK;
+}

@@ -69,11 +69,17 @@ class FlatKmers:
             else np.zeros(0, np.single)
         return FlatKmers(hashes, nodes, ref_offsets, af)
 
+    def _frequencies_in(self, index):
+        """get_frequency(kmer) of every hash (flat_kmers.py:92-96): batched on an index that offers it."""
+        if hasattr(index, "get_frequencies"):
+            return [int(x) for x in index.get_frequencies(np.asarray(self._hashes))]
+        return [index.get_frequency(int(kmer)) for kmer in self._hashes]
+
     def sum_of_kmer_frequencies(self, kmer_index_with_frequencies):
-        return sum([0] + [max(1, kmer_index_with_frequencies.get_frequency(int(kmer))) for kmer in self._hashes])
+        return sum([0] + [max(1, f) for f in self._frequencies_in(kmer_index_with_frequencies)])
 
     def maximum_kmer_frequency(self, kmer_index_with_frequencies):
-        return max([0] + [kmer_index_with_frequencies.get_frequency(int(kmer)) for kmer in self._hashes])
+        return max([0] + self._frequencies_in(kmer_index_with_frequencies))
 
     def get_new_without_singletons(self):
         """Keep the 2nd and later occurrences of every hash, original order (flat_kmers.py:98-125)."""

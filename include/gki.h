@@ -294,6 +294,14 @@ int gki_index_lookup_emit(const gki_index_view *ix, const void *d_queries, int64
                           const void *d_hit_start, void *d_hit_nodes, void *d_hit_ref_offsets,
                           void *d_hit_query, void *d_hit_frequencies, void *d_hit_af32, void *d_hit_position);
 
+/* CollisionFreeKmerIndex.get (:303-315) for a few k-mers from HOST memory (q <= 64): one launch, one wave per query,
+ * queries and results travel through pinned host memory the kernel addresses directly.  h_n_hits[i] = number of hits of
+ * query i (0 for a miss or when the first hit's frequency exceeds max_hits); its first min(h_n_hits[i], 1024,
+ * capacity_per_query) payload positions, in bucket order, are h_positions[i * capacity_per_query ...].  A caller that
+ * sees more hits than it got positions for uses the batched gki_index_lookup_* pair. */
+int gki_index_get_small(const gki_index_view *ix, const uint64_t *h_queries, int q, int64_t max_hits,
+                        int64_t *h_n_hits, int64_t *h_positions, int64_t capacity_per_query);
+
 /* ---------------------------------------------------------------- probe table (read-side hot loop)
  * A device-only re-layout of an index for counting: dir uint2[modulo] = {first record, count (16 bit, saturating)
  * | 16-bit fingerprint set << 16}, rows uint4[n] = {kmer, node, frequency}: one random 64-byte sector per query,

@@ -488,3 +488,49 @@ def test_device_flat_kmers_reverse_complement_and_concatenation():
     assert np.array_equal(want._hashes[n:], oracle.reverse_complement(flat._hashes, 31))
     for name in ("_hashes", "_nodes", "_ref_offsets", "_allele_frequencies"):
         assert np.array_equal(getattr(both, name), getattr(want, name)), name
+
+
+def test_scalar_getters_one_launch_and_batched_frequency_helpers():
+    """get / get_frequency through gki_index_get_small (one launch, pinned staging) and the batched
+    FlatKmers.sum_of_kmer_frequencies / maximum_kmer_frequency, against the oracle's get."""
+    import time
+    from graph_kmer_index_amd import CollisionFreeKmerIndex, FlatKmers
+    rng = np.random.default_rng(12)
+    pool = rng.integers(0, 4 ** 31, size=3000, dtype=np.int64)
+    kmers = pool[rng.integers(0, len(pool), size=20000)]
+    kmers[:1500] = pool[0]                                        # one k-mer with more than 1024 records
+    nodes = rng.integers(0, 900, size=len(kmers)).astype(np.uint32)
+    refs = rng.integers(0, 40, size=len(kmers)).astype(np.uint64)
+    af = rng.random(len(kmers)).astype(np.float32)
+    flat = FlatKmers(kmers, nodes, refs, af)
+    index = CollisionFreeKmerIndex.from_flat_kmers(flat, modulo=4001)
+    ref = oracle.index_build(kmers.astype(np.uint64), nodes, refs, af, modulo=4001)
+    queries = [int(x) for x in pool[:200]] + [int(x) for x in rng.integers(0, 4 ** 31, size=50)]
+    for mh in (10, 10 ** 15):
+        for q in queries:
+            got, want = index.get(q, max_hits=mh), oracle.index_get(ref, q, mh)
+            if want[0] is None:
+                assert got == (None, None, None, None)
+                continue
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b)
+    from graph_kmer_index_amd.kmer_hashing import kmer_hash_to_reverse_complement_hash
+
+    def oracle_freq(q):
+        f = 0
+        for x in (q, int(kmer_hash_to_reverse_complement_hash(q, 31))):
+            r = oracle.index_get(ref, x, 10 ** 15)
+            f += 0 if r[0] is None else int(r[2][0])
+        return f
+    want_f = [oracle_freq(q) for q in queries]
+    assert [index.get_frequency(q) for q in queries] == want_f
+    assert index.get_frequencies(np.array(queries, dtype=np.int64)).tolist() == want_f
+    sub = FlatKmers(np.array(queries, dtype=np.int64), np.zeros(len(queries), np.uint32))
+    assert sub.sum_of_kmer_frequencies(index) == sum(max(1, f) for f in want_f)
+    assert sub.maximum_kmer_frequency(index) == max(want_f)
+    t = time.perf_counter()
+    for q in queries * 8:
+        index.get(q)
+    rate = len(queries) * 8 / (time.perf_counter() - t)
+    print("scalar get(): %.0f calls/s" % rate)
+    assert rate > 2000
