@@ -22,6 +22,16 @@ __device__ __forceinline__ bool any_followed(const DevGraph &g, const uint8_t *_
     return false;
 }
 
+// kmer_finder.py:397-402: at the limit only the linear-ref successor is followed, and the reference asserts that there is
+// exactly one (no assertion when the node has no successors :390 or when the step is forced :397).
+__device__ __forceinline__ void check_one_ref_successor(const DevGraph &g, int32_t node, int *err) {
+    const int64_t e0 = g.edge_start[node], e1 = g.edge_start[node + 1];
+    if (e1 == e0) return;
+    int n_ref = 0;
+    for (int64_t e = e0; e < e1; e++) n_ref += g.is_ref[g.edges[e]] ? 1 : 0;
+    if (n_ref != 1) *err = GKI_ERR_NOT_ONE_REF_SUCC;
+}
+
 template <bool EMIT>
 __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, const uint8_t *__restrict__ follow,
                              int32_t n0, int32_t o0, int64_t idx, FwdOut out, uint32_t *count_out, int *err) {
@@ -43,6 +53,7 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
         forced[0] = any_followed(g, follow, n0) ? 1 : 0;
         L = 1;
         if (t == k) { cur[0] = end[0]; }       // window complete inside the start node: handled below as a completion
+        else if (!EMIT && !forced[0] && vc[0] >= M) check_one_ref_successor(g, n0, err);
     }
     // completion inside the start node
     if (have[0] == k) {
@@ -94,6 +105,7 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
         }
         cur[L] = (int32_t)g.edge_start[q]; end[L] = (int32_t)g.edge_start[q + 1];
         forced[L] = any_followed(g, follow, q) ? 1 : 0;
+        if (!EMIT && !forced[L] && vc[L] >= M) check_one_ref_successor(g, q, err);
         L++;
     }
     *count_out = count;
@@ -140,6 +152,9 @@ int gki_forward_count(gki_graph *gr, int k, int max_variant_nodes, int one_node,
     (void)gki_dev_free(cnt); (void)gki_dev_free(tmp); (void)gki_dev_free(d_err);
     if (rc != GKI_OK) return rc;
     HIP_TRY(e1); HIP_TRY(e2);
+    if (herr == GKI_ERR_NOT_ONE_REF_SUCC)
+        return gki_set_error(herr, "a path at the variant limit ends a node that does not have exactly one linear-ref "
+                             "successor: the reference asserts here (kmer_finder.py:402)");
     if (herr) return gki_set_error(herr, "a forward k-window crosses more than %d nodes", FMAX - 2);
     *n_records = total;
     return GKI_OK;

@@ -255,3 +255,32 @@ def test_only_store_nodes_on_device(one):
             d.free()
         done += 1
     assert done >= 8
+
+
+def test_early_stop_search_on_nested_graphs_incl_assertion():
+    """find_only_kmers_starting_at_position on graphs with nested variants: the reference's records in its order, and its
+    AssertionError (kmer_finder.py:402) where a path at the limit ends a node without exactly one linear-ref successor."""
+    rng = np.random.default_rng(71)
+    n_ok = n_assert = 0
+    for _ in range(60):
+        seqs, edges, lin, af = deep_nested_graph(rng, n_var=int(rng.integers(1, 4)), max_depth=int(rng.integers(1, 3)))
+        g = GraphArrays.from_dicts(seqs, edges, lin, af)
+        k = int(rng.integers(3, 9))
+        M = int(rng.choice([0, 1, 2, 4]))
+        one = bool(rng.integers(0, 2))
+        for node in rng.choice(list(seqs), size=4, replace=False):
+            node = int(node)
+            off = int(rng.integers(0, max(1, len(seqs[node]))))
+            f = DenseKmerFinder(g, k, only_save_one_node_per_kmer=one, max_variant_nodes=M)
+            try:
+                exp = oracle.find_from_position(g, k, node, off, one, M)
+            except oracle.OracleError as e:
+                assert e.code == 3
+                with pytest.raises(AssertionError):
+                    f.find_only_kmers_starting_at_position(node, off)
+                n_assert += 1
+                continue
+            f.find_only_kmers_starting_at_position(node, off)
+            assert_same_records(finder_cols(f), exp, exact_order=True)
+            n_ok += 1
+    assert n_ok > 60 and n_assert > 5
