@@ -54,13 +54,17 @@ __device__ __forceinline__ uint64_t gki_extract(const uint64_t *__restrict__ seq
 }
 
 // ---------------------------------------------------------------------------------- device graph view
-struct NodeWalk {            // everything the boundary walk needs about a node, one aligned 32-B record
+struct alignas(32) NodeWalk { // everything the boundary walk needs about a node, one aligned 32-B record
     int64_t seq_start;
-    int32_t rev_begin, rev_end;
+    uint64_t tail;           // the node's last min(size, 31) bases, 2 bits each, the first of them least significant:
+                             // the context a successor's window takes from this node, without touching the sequence
+    int32_t rev_begin;       // first predecessor in rev_edges -- or, when rev_cnt == 1, the predecessor itself
     int32_t size;
-    int32_t is_ref;
-    double af;
+    float af;                // allele frequency as float32 (flat_kmers.py:90); the float64 value is DevGraph::allele_freq
+    uint16_t rev_cnt;        // number of predecessors (0xFFFF: 65535 or more, see rev_start)
+    uint8_t is_ref, pad;
 };
+static_assert(sizeof(NodeWalk) == 32, "NodeWalk is one 32-byte record");
 
 struct DevGraph {
     int64_t n_nodes, n_bases, n_words64;     // n_words64 = ceil(n_bases / 64): one bitmap word per 64 bases
@@ -82,6 +86,21 @@ struct DevGraph {
     const int32_t *node_rank;                // [n_nodes] rank of a non-empty node in `nonempty` (unused for empty ones)
     int64_t n_nonempty;
 };
+
+// Predecessor iteration: (cur, end) index rev_edges; cur < 0 stands for "the single predecessor ~cur, not visited yet".
+__device__ __forceinline__ void preds_begin(const DevGraph &g, const NodeWalk &w, int64_t n, int32_t *cur, int32_t *end) {
+    if (w.rev_cnt == 1) { *cur = ~w.rev_begin; *end = 0; }
+    else { *cur = w.rev_begin; *end = w.rev_cnt == 0xFFFF ? (int32_t)g.rev_start[n + 1] : w.rev_begin + (int32_t)w.rev_cnt; }
+}
+__device__ __forceinline__ int32_t preds_next(const DevGraph &g, int32_t *cur) {
+    if (*cur < 0) { const int32_t q = ~*cur; *cur = 0; return q; }
+    return g.rev_edges[(*cur)++];
+}
+// the last t (<= min(size, 31)) bases of the node, first of them least significant
+__device__ __forceinline__ uint64_t node_tail(const NodeWalk &w, int t) {
+    const int t31 = w.size < 31 ? w.size : 31;
+    return (w.tail >> (2 * (t31 - t))) & ((1ull << (2 * t)) - 1ull);
+}
 
 struct gki_graph {
     DevGraph d;

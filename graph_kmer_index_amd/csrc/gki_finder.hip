@@ -106,6 +106,71 @@ __device__ __forceinline__ int32_t bnd_len_of(const DevGraph &g, const FindArgs 
     return size < reach ? size : reach;
 }
 
+// ------------------------------------------------------------------------------------ walk cache (LDS)
+// A wave walks the predecessor trees of 64 consecutive nodes, and in a graph built along a genome the predecessors of a
+// node have ids just below it.  One lane per node gathering 32-byte records from global memory costs the address unit
+// a pass per lane and instruction (measured: the count pass took as long with every record an L1 hit).  So each wave
+// first copies the records of nodes [base - WC_HALO, base + 64) and the predecessor lists of its own nodes into LDS with
+// coalesced loads, and the walk reads them there; a node or list entry outside falls back to global memory.
+constexpr int WC_HALO = 64;
+constexpr int WC_REV = 192;
+struct WalkCache {
+    uint4 rec[2 * (WC_HALO + 64)];
+    int32_t rev[WC_REV];
+};
+struct WalkView {                // wave-uniform bounds of what the cache holds
+    int64_t lo, hi;              // nodes
+    int64_t r0, r1;              // rev_edges entries
+};
+__device__ __forceinline__ WalkView stage_walk(const DevGraph &g, WalkCache &wc, int64_t base, int lane) {
+    WalkView v;
+    v.lo = base - WC_HALO < 0 ? 0 : base - WC_HALO;
+    v.hi = base + 64 > g.n_nodes ? g.n_nodes : base + 64;
+    const uint4 *src = reinterpret_cast<const uint4 *>(g.walk) + 2 * v.lo;
+    const int n16 = (int)(2 * (v.hi - v.lo));
+    for (int j = lane; j < n16; j += 64) wc.rec[j] = src[j];
+    v.r0 = g.rev_start[base];
+    const int64_t r_end = g.rev_start[v.hi];
+    v.r1 = r_end - v.r0 > WC_REV ? v.r0 + WC_REV : r_end;
+    for (int j = lane; j < (int)(v.r1 - v.r0); j += 64) wc.rev[j] = g.rev_edges[v.r0 + j];
+    __builtin_amdgcn_wave_barrier();
+    return v;
+}
+// keep a value loaded from LDS a VALUE: without this the compiler merges "LDS load or global load" into one FLAT load
+// of a selected address, which takes the global address path either way (seen in the ISA: flat_load_dwordx4, no ds_read)
+__device__ __forceinline__ void opaque(uint4 &x) { asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w)); }
+__device__ __forceinline__ void opaque(int32_t &x) { asm volatile("" : "+v"(x)); }
+
+__device__ __forceinline__ NodeWalk cached_walk(const DevGraph &g, const WalkCache &wc, const WalkView &v, int64_t q) {
+    const bool in = q >= v.lo && q < v.hi;
+    const int64_t slot = in ? q - v.lo : 0;
+    uint4 lo16 = wc.rec[2 * slot], hi16 = wc.rec[2 * slot + 1];
+    opaque(lo16); opaque(hi16);
+    if (!in) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(g.walk) + 2 * q;
+        lo16 = src[0]; hi16 = src[1];
+    }
+    NodeWalk w;
+    w.seq_start = (int64_t)(((uint64_t)lo16.y << 32) | lo16.x);
+    w.tail = ((uint64_t)lo16.w << 32) | lo16.z;
+    w.rev_begin = (int32_t)hi16.x;
+    w.size = (int32_t)hi16.y;
+    w.af = __uint_as_float(hi16.z);
+    w.rev_cnt = (uint16_t)(hi16.w & 0xFFFFu);
+    w.is_ref = (uint8_t)((hi16.w >> 16) & 0xFFu);
+    w.pad = 0;
+    return w;
+}
+__device__ __forceinline__ int32_t cached_preds_next(const DevGraph &g, const WalkCache &wc, const WalkView &v, int32_t *cur) {
+    if (*cur < 0) { const int32_t q = ~*cur; *cur = 0; return q; }
+    const int32_t i = (*cur)++;
+    const bool in = i >= v.r0 && i < v.r1;
+    int32_t q = wc.rev[in ? i - v.r0 : 0];
+    opaque(q);
+    if (!in) q = g.rev_edges[i];
+    return q;
+}
+
 // Interior offsets [lo, hi) of node n in this run (bl = bnd_len_of).  only_store_nodes (kmer_finder.py:153) drops the
 // records of a node outside the set -- except those of the bulk path, which ignores the filter (:370-374): offsets
 // k+2 .. size-2 of a node longer than 2k+3 (:272).
@@ -174,12 +239,12 @@ __device__ __noinline__ bool history_ok(const DevGraph &g, const uint8_t *__rest
     uint8_t hf[HMAX];
     {
         const NodeWalk wq = g.walk[path[L]];
-        hcur[0] = wq.rev_begin; hend[0] = wq.rev_end;
+        preds_begin(g, wq, path[L], &hcur[0], &hend[0]);
     }
     int h = 0;
     for (;;) {
         if (hcur[h] >= hend[h]) { if (h == 0) return false; h--; continue; }
-        const int32_t p = g.rev_edges[hcur[h]++];
+        const int32_t p = preds_next(g, &hcur[h]);
         const uint8_t fp = nf[p];
         if (fp & GKI_NODE_DEAD) continue;
         const int32_t child = h == 0 ? path[L] : hn[h - 1];
@@ -216,7 +281,7 @@ __device__ __noinline__ bool history_ok(const DevGraph &g, const uint8_t *__rest
         if (!(fp & GKI_NODE_NESTED)) continue;
         if (h + 1 >= HMAX) { *err = GKI_ERR_WINDOW_TOO_DEEP; return false; }
         h++;
-        hcur[h] = wp.rev_begin; hend[h] = wp.rev_end;
+        preds_begin(g, wp, p, &hcur[h], &hend[h]);
     }
 }
 
@@ -237,13 +302,20 @@ template <bool HAS_LOSSY, bool GEN>
 __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
                                                         uint32_t *__restrict__ bcount, uint32_t *__restrict__ total,
                                                         int *__restrict__ err) {
+    __shared__ WalkCache s_wc[4];
     LevelLo below[MAXN];
     LevelLo below0 = {0, 0, 0, 0, 0};  // the first suspended level stays in registers (SNP/indel graphs never go deeper)
     int32_t path[GEN ? MAXN : 1];      // general graphs: the node of every level (level 0 = the end node)
     const int k = a.k;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    WalkCache &wc = s_wc[wib];
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t n = a.n0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.n1; n += stride) {
-        const NodeWalk wn = g.walk[n];
+    for (int64_t base = a.n0 + (int64_t)blockIdx.x * blockDim.x + wib * 64; base < a.n1; base += stride) {
+        const WalkView wv = stage_walk(g, wc, base, lane);
+        const int64_t n = base + lane;
+        if (n >= a.n1) continue;
+        const NodeWalk wn = cached_walk(g, wc, wv, n);
         const int32_t size = wn.size;
         const uint8_t fn = GEN ? a.nflags[n] : (uint8_t)0;
         const bool reach_n = !(GEN && (fn & GKI_NODE_DEAD));
@@ -270,9 +342,10 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
             if (HAS_LOSSY && cn >= 0 && cn < hi) hi = cn;
             const int w_lo = chk_empty ? -1 : o_lo;       // offset -1: the k bases before the node
             if (chk_empty) hi = 0;
-            if (GEN && chk && wn.rev_begin == wn.rev_end && v0 >= a.M) *err = GKI_ERR_NOT_ONE_REF_SUCC;   // a root shorter than k
+            if (GEN && chk && wn.rev_cnt == 0 && v0 >= a.M) *err = GKI_ERR_NOT_ONE_REF_SUCC;   // a root shorter than k
             if (w_lo < hi) {
-                int32_t t_cur = wn.rev_begin, t_end = wn.rev_end;
+                int32_t t_cur, t_end;
+                preds_begin(g, wn, n, &t_cur, &t_end);
                 int t_cum = 0, t_vc = v0, t_a = nonfree0 ? v0 : 0;
                 int L = 1;
                 if (GEN) path[0] = (int32_t)n;
@@ -282,8 +355,8 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
                         if (L > 0) { const LevelLo b = L == 1 ? below0 : below[L - 1]; t_cur = b.cur; t_end = b.end; t_cum = b.cum; t_vc = b.vc; t_a = b.a; }
                         continue;
                     }
-                    const int32_t q = g.rev_edges[t_cur++];
-                    const NodeWalk wq = g.walk[q];
+                    const int32_t q = cached_preds_next(g, wc, wv, &t_cur);
+                    const NodeWalk wq = cached_walk(g, wc, wv, q);
                     const uint8_t fq = GEN ? a.nflags[q] : (uint8_t)0;
                     if (GEN) {
                         if (fq & GKI_NODE_DEAD) continue;
@@ -323,14 +396,15 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
                             count += (uint32_t)(to - from) * per_window;
                         }
                         // the graph ends before the window of oc is complete (graph start): the search saw what there is
-                        if (GEN && chk && wq.rev_begin == wq.rev_end && c + s < k - 1 - oc && vq >= a.M) *err = GKI_ERR_NOT_ONE_REF_SUCC;
+                        if (GEN && chk && wq.rev_cnt == 0 && c + s < k - 1 - oc && vq >= a.M) *err = GKI_ERR_NOT_ONE_REF_SUCC;
                         deeper = (k - 1 - c - s > w_lo) && !(HAS_LOSSY && cq >= 0);
                         new_cum = c + s;
                     }
                     if (deeper) {
                         LevelLo b; b.cur = t_cur; b.end = t_end; b.cum = (uint8_t)t_cum; b.vc = (uint8_t)t_vc; b.a = (uint8_t)t_a;
                         if (L == 1) below0 = b; else below[L - 1] = b;
-                        t_cur = wq.rev_begin; t_end = wq.rev_end; t_cum = new_cum; t_vc = vq; t_a = aq;
+                        preds_begin(g, wq, q, &t_cur, &t_end);
+                        t_cum = new_cum; t_vc = vq; t_a = aq;
                         L++;
                     }
                 }
@@ -369,6 +443,10 @@ struct EvQueue {
     uint8_t from[EVQ], cnt[EVQ];
     uint8_t nl[ALL ? EVQ : 1];                 // all-nodes mode: number of distinct window nodes of the step ...
     int32_t nodes[ALL ? EVQ : 1][NLQ];         // ... and the nodes, ascending (np.unique, kmer_finder.py:134)
+    // one-node mode, lane-per-record expansion: the queue's records numbered 0 .. T-1 in output order
+    uint16_t pre[ALL ? 1 : EVQ];               // first record number of the step at sorted position s
+    uint64_t marks[ALL ? 1 : EVQ * 32 / 64];   // bit r set: a step starts at record r (T <= EVQ * 32)
+    uint16_t wrank[ALL ? 1 : EVQ * 32 / 64];   // steps that start before word w of marks
 };
 
 #ifdef GKI_TUNING
@@ -411,21 +489,61 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, typ
             __builtin_amdgcn_wave_barrier();
         }
     }
-    // Two steps per trip, one per half-wave (a step has at most k-1 <= 30 records): lane l of a half writes record l
-    // of its step.  A lane-per-record mapping (prefix sum + binary search) was tried first; it issues 5x more
-    // instructions per record and the kernel is issue-bound, not bandwidth-bound (PMC: 9.3 GB written in 4.5 ms).
+    if (!ALL) {
+        // One lane per RECORD.  Half of the steps of a SNP graph hold a single record, so "one step per half-wave"
+        // left two thirds of the lanes idle and the address unit paid for 6.4e7 store instructions on the 3 Gbp
+        // graph (SQ_INSTS_VMEM_WR).  Here the T records of the queue are numbered in output order: an exclusive
+        // prefix of the sorted steps' sizes, a bitmap with a bit at every step's first record, and the step of record r
+        // is a popcount over that bitmap -- no search.  Trips are aligned to 16 records of the output so that a store
+        // instruction covers whole cache lines of every column wherever the steps are contiguous.
+        static_assert(EVQ * 32 / 64 == 64, "one bitmap word per lane");
+        const int c0 = lane < n_ev ? (int)q.cnt[q.key[lane] & 0xFFu] : 0;
+        const int c1 = lane + 64 < n_ev ? (int)q.cnt[q.key[lane + 64] & 0xFFu] : 0;
+        int s0 = c0, s1 = c1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t0 = __shfl_up(s0, d, 64), t1 = __shfl_up(s1, d, 64);
+            if (lane >= d) { s0 += t0; s1 += t1; }
+        }
+        const int tot0 = __shfl(s0, 63, 64);
+        const int T = tot0 + __shfl(s1, 63, 64);
+        const int ex0 = s0 - c0, ex1 = tot0 + s1 - c1;
+        q.pre[lane] = (uint16_t)ex0; q.pre[lane + 64] = (uint16_t)ex1;
+        q.marks[lane] = 0ull;
+        __builtin_amdgcn_wave_barrier();
+        unsigned int *marks32 = reinterpret_cast<unsigned int *>(q.marks);
+        if (c0) atomicOr(&marks32[ex0 >> 5], 1u << (ex0 & 31));
+        if (c1) atomicOr(&marks32[ex1 >> 5], 1u << (ex1 & 31));
+        __builtin_amdgcn_wave_barrier();
+        const int pc = __popcll(q.marks[lane]);
+        int ps = pc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(ps, d, 64); if (lane >= d) ps += t; }
+        q.wrank[lane] = (uint16_t)(ps - pc);
+        __builtin_amdgcn_wave_barrier();
+        const int shift = (int)(mn_idx & 15);
+        for (int r0 = -shift; r0 < T; r0 += 64) {
+            const int r = r0 + lane;
+            if (r >= 0 && r < T) {
+                const int w = r >> 6;
+                const int sp = (int)q.wrank[w] + __popcll(q.marks[w] & ((2ull << (r & 63)) - 1ull)) - 1;
+                const int e = (int)(q.key[sp] & 0xFFu);
+                const int j = r - (int)q.pre[sp];
+                const int o = q.from[e] + j;
+                const uint64_t h = ((q.ctx[e] >> (2 * o)) | (q.own[e] << (2 * (k - 1 - o)))) & kmask;
+                put(out, q.idx[e] + j, h, q.mn[e], q.n[e], o, q.pos0[e] + o, q.maf[e]);
+            }
+        }
+        return;
+    }
+    // All-nodes mode: two steps per trip, one per half-wave (a step has at most k-1 <= 30 offsets): lane l of a half
+    // starts at record l of its step.
     const int half = lane >> 5, l = lane & 31;
     for (int i = 0; i < n_ev; i += 2) {
         const int pos = i + half;
         if (pos < n_ev) {
             const int e = (int)(q.key[pos] & 0xFFu);
-            if (!ALL) {
-                if (l < (int)q.cnt[e]) {
-                    const int o = q.from[e] + l;
-                    const uint64_t h = ((q.ctx[e] >> (2 * o)) | (q.own[e] << (2 * (k - 1 - o)))) & kmask;
-                    put(out, q.idx[e] + l, h, q.mn[e], q.n[e], o, q.pos0[e] + o, q.maf[e]);
-                }
-            } else {                                   // one record per offset and distinct node, nodes ascending per offset
+            {                                          // one record per offset and distinct node, nodes ascending per offset
                 const int nl = (int)q.nl[e], total = (int)q.cnt[e] * nl;
                 for (int t = l; t < total; t += 32) {
                     const int o = q.from[e] + t / nl;
@@ -451,6 +569,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                                                            const int64_t *__restrict__ bnd_shift,
                                                            typename OutSel<FMT>::T out, int *__restrict__ err) {
     __shared__ EvQueue<FMT, ALL> s_q[4];
+    __shared__ WalkCache s_wc[4];
     LevelEmit below[MAXN];
     LevelEmit below0;                  // the first suspended level stays in registers
     below0.ctx = 0; below0.maf = 0.0; below0.cur = below0.end = below0.mn = 0; below0.cum = below0.vc = below0.evf = below0.evt = 0;
@@ -459,12 +578,14 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     EvQueue<FMT, ALL> &q = s_q[wib];
+    WalkCache &wc = s_wc[wib];
     const int k = a.k;
     const uint64_t kmask = (1ull << (2 * k)) - 1ull;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const int64_t n_threads = (int64_t)gridDim.x * blockDim.x;
     int n_ev = 0;
     for (int64_t base = a.n0 + (int64_t)blockIdx.x * blockDim.x + wib * 64; base < a.n1; base += n_threads) {
+        const WalkView wv = stage_walk(g, wc, base, lane);
         const int64_t n = base + lane;
         int L = 0, o_lo = 0, hi = 0;
         int64_t idx = 0, pos0 = 0;
@@ -476,7 +597,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
         double t_maf = 0.0;
         int t_a = 0;
         if (n < a.n1 && bcount[n] > 0) {
-            const NodeWalk wn = g.walk[n];
+            const NodeWalk wn = cached_walk(g, wc, wv, n);
             const uint8_t fn = GEN ? a.nflags[n] : (uint8_t)0;
             const int32_t bl = bnd_len_of(g, a, lossy, n, wn.size);
             idx = rec_base[n] + *bnd_shift;
@@ -491,13 +612,16 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                 for (int o = o_lo > k - 1 ? o_lo : k - 1; o < o_hi; o++) {
                     if (HAS_LOSSY && cn >= 0 && o + 1 - k <= cn - 1 && cn <= o) continue;
                     if (GEN && a.store && !a.store[n]) continue;
-                    put(out, idx++, gki_extract(g.seq2, wn.seq_start + o + 1 - k, k), (int32_t)n, (int32_t)n, o, pos0 + o, wn.af);
+                    put(out, idx++, gki_extract(g.seq2, wn.seq_start + o + 1 - k, k), (int32_t)n, (int32_t)n, o, pos0 + o,
+                        FMT == 1 ? g.allele_freq[n] : (double)wn.af);
                 }
                 hi = o_hi < k - 1 ? o_hi : k - 1;
                 if (HAS_LOSSY && cn >= 0 && cn < hi) hi = cn;
                 if (o_lo < hi) {
-                    t_cur = wn.rev_begin; t_end = wn.rev_end; t_cum = 0; t_vc = v0; t_evf = t_evt = 0; t_ctx = 0;
-                    t_mn = (int32_t)n; t_maf = wn.af;
+                    preds_begin(g, wn, n, &t_cur, &t_end);
+                    t_cum = 0; t_vc = v0; t_evf = t_evt = 0; t_ctx = 0;
+                    t_mn = (int32_t)n; t_maf = FMT == 1 ? g.allele_freq[n] : (double)wn.af;   // float32 rounding is monotonic:
+                    // the minimum of the rounded values is the rounded minimum (flat layout), v2 keeps float64
                     own = gki_extract(g.seq2, wn.seq_start, hi);
                     if (ALL || GEN) path[0] = (int32_t)n;
                     t_a = nonfree0 ? v0 : 0;
@@ -522,8 +646,8 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                         if (GEN) t_a = lvl_a[L];
                     }
                 } else {
-                    const int32_t qn = g.rev_edges[t_cur++];
-                    const NodeWalk wq = g.walk[qn];
+                    const int32_t qn = cached_preds_next(g, wc, wv, &t_cur);
+                    const NodeWalk wq = cached_walk(g, wc, wv, qn);
                     const uint8_t fq = GEN ? a.nflags[qn] : (uint8_t)0;
                     const int vq = t_vc + (GEN ? ((fq & GKI_NODE_REF) ? 0 : 1) : (wq.is_ref ? 0 : 1));
                     bool take;
@@ -542,7 +666,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                             const int s = wq.size, c = t_cum;
                             if (ALL || GEN) path[L] = qn;
                             const int32_t mn = qn < t_mn ? qn : t_mn;
-                            const double maf = fmin(t_maf, wq.af);               // np.min, kmer_finder.py:143
+                            const double maf = fmin(t_maf, FMT == 1 ? g.allele_freq[qn] : (double)wq.af);   // np.min, kmer_finder.py:143
                             bool deeper;
                             int new_cum, from = 0, to = 0;
                             uint64_t cx = t_ctx;
@@ -558,7 +682,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                                     if (!ok) to = from;
                                 }
                                 const int tq = s < k - 1 - c ? s : k - 1 - c;
-                                cx = t_ctx | (gki_extract(g.seq2, wq.seq_start + s - tq, tq) << (2 * (k - 1 - c - tq)));
+                                cx = t_ctx | (node_tail(wq, tq) << (2 * (k - 1 - c - tq)));
                                 deeper = (k - 1 - c - s > o_lo) && !(HAS_LOSSY && cq >= 0);
                                 new_cum = c + s;
                             }
@@ -568,7 +692,8 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                                 b.evf = (uint8_t)t_evf; b.evt = (uint8_t)t_evt; b.ctx = t_ctx; b.mn = t_mn; b.maf = t_maf;
                                 if (L == 1) below0 = b; else below[L - 1] = b;
                                 if (GEN) { lvl_a[L] = (uint8_t)t_a; t_a = aq; }
-                                t_cur = wq.rev_begin; t_end = wq.rev_end; t_cum = new_cum; t_vc = vq;
+                                preds_begin(g, wq, qn, &t_cur, &t_end);
+                                t_cum = new_cum; t_vc = vq;
                                 t_evf = from < to ? from : 0; t_evt = from < to ? to : 0;
                                 t_ctx = cx; t_mn = mn; t_maf = maf;
                                 L++;

@@ -59,7 +59,7 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
     if (have[0] == k) {
         if (EMIT) {
             out.hash[idx] = (int64_t)hs[0]; out.start_node[idx] = n0; out.start_offset[idx] = (int16_t)(o0 + k - 1);
-            out.node[idx] = n0; out.af[idx] = w0.af;
+            out.node[idx] = n0; out.af[idx] = g.allele_freq[n0];
         }
         *count_out = 1;
         return;

@@ -46,11 +46,15 @@ __global__ __launch_bounds__(256) void k_build_walk(DevGraph g, NodeWalk *__rest
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < g.n_nodes; n += stride) {
         NodeWalk w;
         w.seq_start = g.seq_start[n];
-        w.rev_begin = (int32_t)g.rev_start[n];
-        w.rev_end = (int32_t)g.rev_start[n + 1];
         w.size = g.node_size[n];
+        const int t31 = w.size < 31 ? w.size : 31;
+        w.tail = t31 > 0 ? gki_extract(g.seq2, w.seq_start + w.size - t31, t31) : 0ull;      // the 2-bit pack ran before
+        const int64_t r0 = g.rev_start[n], cnt = g.rev_start[n + 1] - r0;
+        w.rev_begin = cnt == 1 ? g.rev_edges[r0] : (int32_t)r0;
+        w.rev_cnt = (uint16_t)(cnt < 0xFFFF ? cnt : 0xFFFF);
         w.is_ref = g.is_ref[n] ? 1 : 0;
-        w.af = g.allele_freq[n];
+        w.pad = 0;
+        w.af = (float)g.allele_freq[n];
         out[n] = w;
     }
 }

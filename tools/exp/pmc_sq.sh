@@ -1,15 +1,14 @@
 #!/bin/bash
-# usage: tools/exp/pmc_sq.sh <tag> [ENV=VAL ...]  -> SQ counters of the boundary kernel for one bench run
+# usage: tools/exp/pmc_sq.sh <tag>  -> SQ counters of the finder kernels for one bench run (two rocprofv3 --pmc passes)
 tag="$1"; shift
 R="$(pwd)"; export TMPDIR=/tmp
-for e in "$@"; do export "$e"; done
 cd /tmp
 A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA"
-B="SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_LDS_BANK_CONFLICT"
+B="SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD"
 i=0
 for grp in "$A" "$B"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d "$R/gpurun_out/sq_${tag}_$i" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$R/gpurun_out/sq_${tag}_$i.json" 2> "$R/gpurun_out/sq_${tag}_$i.err" || echo "pass $i failed"
+  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d "$R/gpurun_out/sq_${tag}_$i" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --reads 0 > "$R/gpurun_out/sq_${tag}_$i.json" 2> "$R/gpurun_out/sq_${tag}_$i.err" || echo "pass $i failed"
 done
 cd "$R"
 python3 - "$tag" <<'PY'
