@@ -112,7 +112,7 @@ __device__ __forceinline__ int32_t bnd_len_of(const DevGraph &g, const FindArgs 
 // a pass per lane and instruction (measured: the count pass took as long with every record an L1 hit).  So each wave
 // first copies the records of nodes [base - WC_HALO, base + 64) and the predecessor lists of its own nodes into LDS with
 // coalesced loads, and the walk reads them there; a node or list entry outside falls back to global memory.
-constexpr int WC_HALO = 64;
+constexpr int WC_HALO = 32;
 constexpr int WC_REV = 192;
 struct WalkCache {
     uint4 rec[2 * (WC_HALO + 64)];
@@ -128,11 +128,22 @@ __device__ __forceinline__ WalkView stage_walk(const DevGraph &g, WalkCache &wc,
     v.hi = base + 64 > g.n_nodes ? g.n_nodes : base + 64;
     const uint4 *src = reinterpret_cast<const uint4 *>(g.walk) + 2 * v.lo;
     const int n16 = (int)(2 * (v.hi - v.lo));
-    for (int j = lane; j < n16; j += 64) wc.rec[j] = src[j];
     v.r0 = g.rev_start[base];
     const int64_t r_end = g.rev_start[v.hi];
     v.r1 = r_end - v.r0 > WC_REV ? v.r0 + WC_REV : r_end;
-    for (int j = lane; j < (int)(v.r1 - v.r0); j += 64) wc.rev[j] = g.rev_edges[v.r0 + j];
+    const int n_rev = (int)(v.r1 - v.r0);
+    // all loads first, then the LDS writes: one round trip to memory instead of one per 64 entries
+    constexpr int RC = 2 * (WC_HALO + 64) / 64, VC = WC_REV / 64;
+    uint4 t[RC];
+    int32_t r[VC];
+#pragma unroll
+    for (int u = 0; u < RC; u++) { const int j = u * 64 + lane; t[u] = j < n16 ? src[j] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+    for (int u = 0; u < VC; u++) { const int j = u * 64 + lane; r[u] = j < n_rev ? g.rev_edges[v.r0 + j] : 0; }
+#pragma unroll
+    for (int u = 0; u < RC; u++) wc.rec[u * 64 + lane] = t[u];
+#pragma unroll
+    for (int u = 0; u < VC; u++) wc.rev[u * 64 + lane] = r[u];
     __builtin_amdgcn_wave_barrier();
     return v;
 }
@@ -433,13 +444,23 @@ constexpr int EVQ = 128;            // step descriptors per wave queue (a walk r
 
 constexpr int NLQ = 6;              // all-nodes mode: node lists of up to NLQ nodes travel through the queue
 
+template <int FMT> struct MafOf { typedef float T; };        // float32 rounding is monotonic: min, then round == round, then min
+template <> struct MafOf<1> { typedef double T; };           // get_flat_kmers(v="2") keeps float64 (kmer_finder.py:58)
+
 template <int FMT, bool ALL>
 struct EvQueue {
-    uint64_t ctx[EVQ], own[EVQ];
-    int64_t idx[EVQ], pos0[EVQ];
-    double maf[EVQ];
-    int32_t mn[EVQ], n[EVQ];
-    uint32_t key[EVQ];           // (idx - min idx) << 8 | slot, sorted: the steps in output order
+    // per node of the group in progress (lane l walks node base + l)
+    uint64_t own[64];            // the node's first k-1 bases
+    int64_t pos0[64];            // position id of (node, 0)
+    int32_t n[64];
+    // per queued step
+    uint64_t ctx[EVQ];
+    int64_t idx[EVQ];
+    typename MafOf<FMT>::T maf[EVQ];
+    int32_t mn[EVQ];
+    uint8_t order[EVQ];          // slot of the step at position p of the output order
+    uint8_t ln[EVQ], seq[EVQ];   // the lane (node) that queued the step, and its number among that lane's queued steps
+    uint8_t lbase[64];           // output position of a lane's first queued step
     uint8_t from[EVQ], cnt[EVQ];
     uint8_t nl[ALL ? EVQ : 1];                 // all-nodes mode: number of distinct window nodes of the step ...
     int32_t nodes[ALL ? EVQ : 1][NLQ];         // ... and the nodes, ascending (np.unique, kmer_finder.py:134)
@@ -459,36 +480,29 @@ __device__ int g_dbg_skip_expand = 0;     // tools/exp builds only (make tuning)
 // Expansion writes the queued steps in OUTPUT order.  Steps arrive in walk order, i.e. interleaved across the 64
 // nodes of the wave; written that way every cache line of the wave's output block is touched several microseconds
 // apart, and at ~5 TB/s of writes a 4-MB L2 turns over in ~6 us, so lines left half-written were flushed twice
-// (PMC: 11.4 GB written for 7.4 GB of records).  Sorting the <= 128 steps by their first record slot (bitonic sort
-// of packed keys in LDS) makes consecutive lanes write consecutive records.
+// (PMC: 11.4 GB written for 7.4 GB of records).  Output order is (node, order of queueing): record slots grow with
+// the node id and, inside a node, with every step queued.  The queue never holds steps of two node groups (it is
+// flushed when a group is done), so the position of a step is "steps queued by lower lanes" + its number within its
+// lane: one wave scan and a scatter -- the first version sorted packed keys with a 28-stage bitonic network.
 template <int FMT, bool ALL>
-__device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, typename OutSel<FMT>::T out, int k, uint64_t kmask,
-                                             int lane) {
+__device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int my_cnt, typename OutSel<FMT>::T out, int k,
+                                             uint64_t kmask, int lane) {
     if (GKI_DBG_SKIP_EXPAND_IS(1)) return;
     static_assert(EVQ == 128, "two steps per lane");
-    // smallest first-record slot of the queue
-    int64_t mn_idx = INT64_MAX;
+    {
+        int ps = my_cnt;
 #pragma unroll
-    for (int b = 0; b < 2; b++) { const int e = b * 64 + lane; if (e < n_ev && q.idx[e] < mn_idx) mn_idx = q.idx[e]; }
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(ps, d, 64); if (lane >= d) ps += t; }
+        q.lbase[lane] = (uint8_t)(ps - my_cnt);
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { const int64_t o = __shfl_xor(mn_idx, d, 64); mn_idx = o < mn_idx ? o : mn_idx; }
-#pragma unroll
-    for (int b = 0; b < 2; b++) {
-        const int e = b * 64 + lane;
-        q.key[e] = e < n_ev ? (((uint32_t)(q.idx[e] - mn_idx) << 8) | (uint32_t)e) : 0xFFFFFFFFu;
-    }
-    // bitonic sort of 128 keys, one compare-exchange per lane and step (a wave executes in lockstep; LDS ops of one
-    // wave are ordered)
-    for (int size = 2; size <= (GKI_DBG_SKIP_EXPAND_IS(2) ? 0 : EVQ); size <<= 1) {
-        for (int str = size >> 1; str > 0; str >>= 1) {
-            const int lo = ((lane / str) * (str << 1)) + (lane % str);
-            const int hi = lo + str;
-            const bool up = (lo & size) == 0;
-            const uint32_t a = q.key[lo], c = q.key[hi];
-            if ((c < a) == up) { q.key[lo] = c; q.key[hi] = a; }
-            __builtin_amdgcn_wave_barrier();
+        for (int b = 0; b < 2; b++) {
+            const int e = b * 64 + lane;
+            if (e < n_ev) q.order[(int)q.lbase[q.ln[e]] + (int)q.seq[e]] = (uint8_t)e;
         }
+        __builtin_amdgcn_wave_barrier();
     }
+    const int64_t mn_idx = q.idx[q.order[0]];        // smallest record slot of the queue
     if (!ALL) {
         // One lane per RECORD.  Half of the steps of a SNP graph hold a single record, so "one step per half-wave"
         // left two thirds of the lanes idle and the address unit paid for 6.4e7 store instructions on the 3 Gbp
@@ -497,8 +511,8 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, typ
         // is a popcount over that bitmap -- no search.  Trips are aligned to 16 records of the output so that a store
         // instruction covers whole cache lines of every column wherever the steps are contiguous.
         static_assert(EVQ * 32 / 64 == 64, "one bitmap word per lane");
-        const int c0 = lane < n_ev ? (int)q.cnt[q.key[lane] & 0xFFu] : 0;
-        const int c1 = lane + 64 < n_ev ? (int)q.cnt[q.key[lane + 64] & 0xFFu] : 0;
+        const int c0 = lane < n_ev ? (int)q.cnt[q.order[lane]] : 0;
+        const int c1 = lane + 64 < n_ev ? (int)q.cnt[q.order[lane + 64]] : 0;
         int s0 = c0, s1 = c1;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -527,11 +541,11 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, typ
             if (r >= 0 && r < T) {
                 const int w = r >> 6;
                 const int sp = (int)q.wrank[w] + __popcll(q.marks[w] & ((2ull << (r & 63)) - 1ull)) - 1;
-                const int e = (int)(q.key[sp] & 0xFFu);
+                const int e = (int)q.order[sp];
                 const int j = r - (int)q.pre[sp];
-                const int o = q.from[e] + j;
-                const uint64_t h = ((q.ctx[e] >> (2 * o)) | (q.own[e] << (2 * (k - 1 - o)))) & kmask;
-                put(out, q.idx[e] + j, h, q.mn[e], q.n[e], o, q.pos0[e] + o, q.maf[e]);
+                const int o = q.from[e] + j, ln = q.ln[e];
+                const uint64_t h = ((q.ctx[e] >> (2 * o)) | (q.own[ln] << (2 * (k - 1 - o)))) & kmask;
+                put(out, q.idx[e] + j, h, q.mn[e], q.n[ln], o, q.pos0[ln] + o, (double)q.maf[e]);
             }
         }
         return;
@@ -542,13 +556,13 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, typ
     for (int i = 0; i < n_ev; i += 2) {
         const int pos = i + half;
         if (pos < n_ev) {
-            const int e = (int)(q.key[pos] & 0xFFu);
+            const int e = (int)q.order[pos];
             {                                          // one record per offset and distinct node, nodes ascending per offset
-                const int nl = (int)q.nl[e], total = (int)q.cnt[e] * nl;
+                const int nl = (int)q.nl[e], total = (int)q.cnt[e] * nl, ln = q.ln[e];
                 for (int t = l; t < total; t += 32) {
                     const int o = q.from[e] + t / nl;
-                    const uint64_t h = ((q.ctx[e] >> (2 * o)) | (q.own[e] << (2 * (k - 1 - o)))) & kmask;
-                    put(out, q.idx[e] + t, h, q.nodes[e][t % nl], q.n[e], o, q.pos0[e] + o, q.maf[e]);
+                    const uint64_t h = ((q.ctx[e] >> (2 * o)) | (q.own[ln] << (2 * (k - 1 - o)))) & kmask;
+                    put(out, q.idx[e] + t, h, q.nodes[e][t % nl], q.n[ln], o, q.pos0[ln] + o, (double)q.maf[e]);
                 }
             }
         }
@@ -583,7 +597,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
     const uint64_t kmask = (1ull << (2 * k)) - 1ull;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const int64_t n_threads = (int64_t)gridDim.x * blockDim.x;
-    int n_ev = 0;
+    int n_ev = 0, my_cnt = 0;              // steps in the queue; of them, queued by this lane
     for (int64_t base = a.n0 + (int64_t)blockIdx.x * blockDim.x + wib * 64; base < a.n1; base += n_threads) {
         const WalkView wv = stage_walk(g, wc, base, lane);
         const int64_t n = base + lane;
@@ -623,6 +637,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                     t_mn = (int32_t)n; t_maf = FMT == 1 ? g.allele_freq[n] : (double)wn.af;   // float32 rounding is monotonic:
                     // the minimum of the rounded values is the rounded minimum (flat layout), v2 keeps float64
                     own = gki_extract(g.seq2, wn.seq_start, hi);
+                    q.own[lane] = own; q.pos0[lane] = pos0; q.n[lane] = (int32_t)n;
                     if (ALL || GEN) path[0] = (int32_t)n;
                     t_a = nonfree0 ? v0 : 0;
                     L = 1;
@@ -728,13 +743,14 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
             if (pending) {
                 const int n_new = __popcll(pending);
                 if (n_ev + n_new > EVQ) {                    // wave-uniform: make room first
-                    expand_queue<FMT, ALL>(q, n_ev, out, k, kmask, lane);
-                    n_ev = 0;
+                    expand_queue<FMT, ALL>(q, n_ev, my_cnt, out, k, kmask, lane);
+                    n_ev = 0; my_cnt = 0;
                 }
                 if (ev) {
                     const int slot = n_ev + __popcll(pending & lt_mask);
-                    q.ctx[slot] = e_ctx; q.own[slot] = own; q.idx[slot] = idx; q.pos0[slot] = pos0;
-                    q.maf[slot] = e_maf; q.mn[slot] = e_mn; q.n[slot] = (int32_t)n;
+                    q.ln[slot] = (uint8_t)lane; q.seq[slot] = (uint8_t)my_cnt++;
+                    q.ctx[slot] = e_ctx; q.idx[slot] = idx;
+                    q.maf[slot] = (typename MafOf<FMT>::T)e_maf; q.mn[slot] = e_mn;
                     q.from[slot] = (uint8_t)e_from; q.cnt[slot] = (uint8_t)(e_to - e_from);
                     if (ALL) {
                         q.nl[slot] = (uint8_t)e_nls;
@@ -753,8 +769,11 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                 n_ev += n_new;
             }
         }
+        if (n_ev > 0) {                                      // the queue never mixes node groups (see expand_queue)
+            expand_queue<FMT, ALL>(q, n_ev, my_cnt, out, k, kmask, lane);
+            n_ev = 0; my_cnt = 0;
+        }
     }
-    if (n_ev > 0) expand_queue<FMT, ALL>(q, n_ev, out, k, kmask, lane);
 }
 
 // ------------------------------------------------------------------------------------ per-node constants
