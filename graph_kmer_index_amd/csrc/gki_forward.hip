@@ -35,7 +35,7 @@ __device__ __forceinline__ void check_one_ref_successor(const DevGraph &g, int32
 template <bool EMIT>
 __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, const uint8_t *__restrict__ follow,
                              int32_t n0, int32_t o0, int64_t idx, FwdOut out, uint32_t *count_out, int *err) {
-    int32_t nd[FMAX], cur[FMAX], end[FMAX];
+    int32_t nd[FMAX], cur[FMAX], end[FMAX], last[FMAX];
     uint8_t have[FMAX], vc[FMAX], forced[FMAX];
     uint64_t hs[FMAX];
     uint32_t count = 0;
@@ -51,6 +51,7 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
         have[0] = (uint8_t)t;
         cur[0] = (int32_t)g.edge_start[n0]; end[0] = (int32_t)g.edge_start[n0 + 1];
         forced[0] = any_followed(g, follow, n0) ? 1 : 0;
+        last[0] = INT_MIN;
         L = 1;
         if (t == k) { cur[0] = end[0]; }       // window complete inside the start node: handled below as a completion
         else if (!EMIT && !forced[0] && vc[0] >= M) check_one_ref_successor(g, n0, err);
@@ -67,11 +68,23 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
     while (L > 0) {
         const int j = L - 1;
         if (cur[j] >= end[j]) { L--; continue; }
-        const int32_t e = cur[j]++;
-        const int32_t q = g.edges[e];
+        int32_t q;
+        if (forced[j]) {
+            // :386-388 forced traversal: only the successors in the follow set, and -- the reference iterates a Python
+            // set of small ints there -- in ascending id order whatever the successor list says.  cur[j] counts the
+            // forced successors already taken; last[j] is the latest of them.
+            q = INT_MAX;
+            for (int32_t e = (int32_t)g.edge_start[nd[j]]; e < end[j]; e++) {
+                const int32_t c = g.edges[e];
+                if (follow[c] && c > last[j] && c < q) q = c;
+            }
+            if (q == INT_MAX) { cur[j] = end[j]; continue; }
+            last[j] = q;
+        } else {
+            q = g.edges[cur[j]++];
+        }
         const NodeWalk wq = g.walk[q];
         if (forced[j]) {
-            if (!follow[q]) continue;                                   // :386-388 forced traversal
         } else if (vc[j] >= M && !wq.is_ref) {
             continue;                                                   // :397-403 only the linear-ref successor
         }
@@ -105,6 +118,7 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
         }
         cur[L] = (int32_t)g.edge_start[q]; end[L] = (int32_t)g.edge_start[q + 1];
         forced[L] = any_followed(g, follow, q) ? 1 : 0;
+        last[L] = INT_MIN;
         if (!EMIT && !forced[L] && vc[L] >= M) check_one_ref_successor(g, q, err);
         L++;
     }

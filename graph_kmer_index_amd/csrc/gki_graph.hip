@@ -332,7 +332,7 @@ int gki_classify_nodes(int64_t n_nodes, const int32_t *node_size, const int64_t 
         const int64_t n = ids_topological ? i : order[(size_t)i];
         uint8_t f = out[n];
         const int64_t r0 = rev_start[n], r1 = rev_start[n + 1];
-        if (is_root[(size_t)n] && r1 == r0) {
+        if (is_root[(size_t)n]) {             // a search starts here with no history (chromosome start, critical point)
             clean[(size_t)n] = INF;
             out[n] = f | GKI_NODE_T;
             if (f & (GKI_NODE_CHECK | GKI_NODE_HFS | GKI_NODE_FORCED)) gen = true;

@@ -45,7 +45,7 @@ def check_supported_graph(g, k):
             raise NotImplementedError("chromosome start node %d is shorter than k" % s)
 
 
-def classify_nodes(g, k, max_variant_nodes, only_follow_nodes=None):
+def classify_nodes(g, k, max_variant_nodes, only_follow_nodes=None, critical_nodes=None):
     """(uint8[n_nodes] GKI_NODE_* flags, general) -- gki_classify_nodes (include/gki.h): which nodes the order-free
     form of the variant limit (kmer_finder.py:383-417) can stop at when it looks for a history.  `general` False
     means "at most max_variant_nodes variant nodes in the window" is the whole rule for this graph and the kernels run
@@ -55,12 +55,16 @@ def classify_nodes(g, k, max_variant_nodes, only_follow_nodes=None):
         follow = np.zeros(g.n_nodes, dtype=np.uint8)
         ids = np.fromiter((int(x) for x in only_follow_nodes), dtype=np.int64)
         follow[ids[(ids >= 0) & (ids < g.n_nodes)]] = 1
-    key = (int(k), min(int(max_variant_nodes), 64), None if follow is None else follow.tobytes())
+    crit = np.zeros(0, dtype=np.int32) if critical_nodes is None else np.ascontiguousarray(critical_nodes, dtype=np.int32)
+    key = (int(k), min(int(max_variant_nodes), 64), None if follow is None else follow.tobytes(), crit.tobytes())
     cache = g.__dict__.setdefault("_node_classes", {})
     if key not in cache:
         if len(cache) > 8:
             cache.clear()
-        roots = np.ascontiguousarray(list(g.chromosome_start_nodes.values()) + [g.first_node], dtype=np.int32)
+        # search roots: chromosome starts and every critical node (each critical point starts a search with no history,
+        # kmer_finder.py:190-232)
+        roots = np.ascontiguousarray(np.concatenate([np.asarray(list(g.chromosome_start_nodes.values()) + [g.first_node],
+                                                                dtype=np.int32), crit]))
         flags = np.zeros(g.n_nodes, dtype=np.uint8)
         general = C.c_int32(0)
         _lib.check(_lib.load().gki_classify_nodes(
@@ -165,12 +169,12 @@ class DenseKmerFinder:
     def _make_params(self):
         g, k = self._arrays, self._k
         check_supported_graph(g, k)
-        flags, general = classify_nodes(g, k, self._max_variant_nodes, self._only_follow_nodes)
         if self._critical_graph_paths is None:
             logging.info("Making critical graph paths since it's not specified.")
             self._critical_graph_paths = CriticalGraphPaths.from_graph(g, k)
         cp = self._critical_graph_paths
         crit_nodes = np.asarray(cp.nodes).astype(np.int64)
+        flags, general = classify_nodes(g, k, self._max_variant_nodes, self._only_follow_nodes, crit_nodes)
         crit_offsets = np.asarray(cp.offsets).astype(np.int64)
         start_at, stop_at = self._start_at_critical_path_number, self._stop_at_critical_path_number
         lossy = lossy_table(g, k, crit_nodes, crit_offsets, start_at, stop_at)

@@ -153,7 +153,8 @@ int gki_critical_paths(int64_t n_nodes, const int32_t *h_node_size,
 #define GKI_NODE_DEAD 128    /* exact: the search never enters the node (no alive edge from an entered node, or no history
                                 within the limit): no records, never stepped on */
 /* Host, one pass in topological order, O(nodes + edges) plus a backward enumeration for every non-free NESTED node.
- * h_follow: uint8[n_nodes] membership of only_follow_nodes or NULL; h_roots: chromosome start nodes (search roots).
+ * h_follow: uint8[n_nodes] membership of only_follow_nodes or NULL; h_roots: the nodes a search starts from with no
+ * history -- chromosome starts and every critical node (kmer_finder.py:190-232: each critical point starts its own search).
  * h_out_flags uint8[n_nodes].  *general = 1 if any node is NESTED / CHECK / HFS / FORCED or cut off, i.e.
  * gki_finder_count needs the flags; 0 = the graph is in the class where "at most max_variant_nodes variant nodes in
  * the window" is the whole rule and h_node_flags may stay NULL.  GKI_ERR_BAD_ARG if the graph has a cycle. */

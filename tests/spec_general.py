@@ -118,15 +118,16 @@ def history_ok(g, flags, k, M, path):
     return rec(q, [], [])
 
 
-def classify(g, k, M, follow=None):
-    """Per-node flag byte, in topological order.  DEAD is exact: the node is never entered by the search."""
+def classify(g, k, M, follow=None, critical_nodes=()):
+    """Per-node flag byte, in topological order.  DEAD is exact: the node is never entered by the search.  Every
+    critical node starts a search of its own with no history (kmer_finder.py:190-232), like a chromosome start."""
     N = g.n_nodes
     F = set(int(x) for x in follow) if follow is not None else set()
     size = g.node_size
     succ = lambda n: g.edges[g.edge_start[n]:g.edge_start[n + 1]].tolist()
     pred = lambda n: g.rev_edges[g.rev_start[n]:g.rev_start[n + 1]].tolist()
     flags = [0] * N
-    roots = set(int(x) for x in g.chromosome_start_nodes.values()) | {g.first_node}
+    roots = set(int(x) for x in g.chromosome_start_nodes.values()) | {g.first_node} | set(int(x) for x in critical_nodes)
     for n in range(N):
         if g.is_ref[n]:
             flags[n] |= REF
@@ -141,7 +142,7 @@ def classify(g, k, M, follow=None):
     INF = 1 << 40
     clean = [0] * N             # all-linear-ref bases of the best history before the node's entry
     for n in topological_order(g):
-        if n in roots and not pred(n):
+        if n in roots:
             clean[n] = INF
             flags[n] |= T
             continue
@@ -166,9 +167,9 @@ def classify(g, k, M, follow=None):
 def spec_rows_general(g, k, max_variant_nodes=4, one_node=False, critical=None, follow=None):
     """Counter of (hash, start_node, start_offset, node, allele_freq); raises SpecError where the reference asserts."""
     M = max_variant_nodes
-    flags = classify(g, k, M, follow)
-    size = g.node_size
     crit = critical or {}
+    flags = classify(g, k, M, follow, crit.keys())
+    size = g.node_size
     rows = Counter()
 
     def preds(n):

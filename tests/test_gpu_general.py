@@ -111,6 +111,29 @@ def test_chunked_runs_and_store_filter_on_nested_graphs():
     assert ok > 40
 
 
+def test_every_critical_point_starts_a_search_of_its_own():
+    """A forced allele plus a tight limit can cut the graph in two for the search that comes from upstream; the next
+    critical point still starts its own search (kmer_finder.py:190-232), so a chunk that begins there has records and
+    the linear-successor assertion only fires in the chunk that reaches the offending node (found by the soak)."""
+    rng = np.random.default_rng(53)
+    seen = {"ok": 0, "assert": 0, "skip": 0}
+    for _ in range(120):
+        seqs, edges, lin, af = nested_bubble_graph(rng, n_var=int(rng.integers(4, 12)), min_ref=1, max_ref=24, p_nest=0.7)
+        g = GraphArrays.from_dicts(seqs, edges, lin, af)
+        k = int(rng.integers(6, 20))
+        try:
+            n_crit = len(oracle.critical_paths(g, k)[0])
+        except oracle.OracleError:
+            continue
+        variant = np.nonzero(g.is_ref == 0)[0]
+        follow = set(int(x) for x in rng.choice(variant, size=max(1, len(variant) // 4), replace=False))
+        a = int(rng.integers(0, n_crit + 1))
+        b = int(rng.integers(a, n_crit + 2))
+        for chunk in (None, (a, b)):
+            seen[run_case(g, k, int(rng.choice([1, 2, 3])), bool(rng.integers(0, 2)), follow=follow, chunk=chunk)] += 1
+    assert seen["ok"] > 60 and seen["assert"] > 10, seen
+
+
 def test_flat_layouts_on_nested_graphs():
     """find_flat_on_device (both layouts) = find() on general graphs too."""
     rng = np.random.default_rng(52)

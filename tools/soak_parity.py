@@ -9,7 +9,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np
 from graph_kmer_index_amd import DenseKmerFinder, CriticalGraphPaths, GraphArrays
 from graph_kmer_index_amd.graph import synthetic_indel_graph
-from graphgen import random_bubble_graph, overlapping_bubble_graph
+from graphgen import random_bubble_graph, overlapping_bubble_graph, nested_bubble_graph, deep_nested_graph
 from gpu_util import assert_same_records, finder_cols
 from oracle import oracle
 
@@ -25,7 +25,15 @@ def progress(msg):
 
 
 def make_graph(rng, k):
-    mode = rng.choice(["bubble", "overlap", "chain", "indel"])
+    mode = rng.choice(["bubble", "overlap", "chain", "indel", "nested", "deep"])
+    if mode == "nested":               # a variant inside an alternative allele: nodes with no linear-ref predecessor
+        seqs, edges, lin, af = nested_bubble_graph(rng, n_var=int(rng.integers(2, 12)), min_ref=1, max_ref=int(rng.integers(2, 2 * k + 3)),
+                                                   p_nest=float(rng.choice([0.3, 0.7])))
+        return mode, GraphArrays.from_dicts(seqs, edges, lin, af)
+    if mode == "deep":
+        seqs, edges, lin, af = deep_nested_graph(rng, n_var=int(rng.integers(1, 8)), max_depth=int(rng.integers(1, 4)), min_ref=1,
+                                                 max_ref=int(rng.integers(2, 2 * k + 3)), max_allele=int(rng.integers(1, 8)))
+        return mode, GraphArrays.from_dicts(seqs, edges, lin, af)
     if mode == "bubble":
         seqs, edges, lin, af = random_bubble_graph(rng, n_var=int(rng.integers(2, 40)), min_ref=1, max_ref=int(rng.integers(2, 3 * k + 3)),
                                                    p_indel=float(rng.choice([0.0, 0.3, 0.7])), with_af=True)
@@ -205,7 +213,7 @@ def main():
     if args.what != "find":
         return {"forward": soak_forward, "index": soak_index, "reads": soak_reads}[args.what](args)
     t_end = time.time() + args.seconds
-    it = checked = refused = 0
+    it = checked = refused = asserted = 0
     why = {}
     while time.time() < t_end:
         seed = args.seed * 1_000_003 + it
@@ -229,15 +237,32 @@ def main():
             a = int(rng.integers(0, len(crit[0])))
             b = int(rng.integers(a, len(crit[0]) + 1))
             kw = dict(start_at_critical_path_number=a, stop_at_critical_path_number=b)
+        if rng.random() < 0.15:                                   # kmer_finder.py:386-388 in find()
+            variant = np.nonzero(g.is_ref == 0)[0]
+            if len(variant):
+                kw = dict(kw, only_follow_nodes=set(int(x) for x in rng.choice(variant, size=max(1, len(variant) // 4), replace=False)))
         try:
             full, flags = oracle.find(g, k, crit, one, M, return_flags=True, **kw)
-        except oracle.OracleError:
-            continue                                              # the reference hits its recursion limit here
+        except oracle.OracleError as e:
+            if e.code != 3:
+                continue                                          # the reference hits its recursion limit here
+            # the reference's `assert len(next_nodes) == 1` (kmer_finder.py:402): the library must raise too
+            f = DenseKmerFinder(g, k, critical_graph_paths=CriticalGraphPaths(crit[0], crit[1]), only_save_one_node_per_kmer=one,
+                                max_variant_nodes=M, **kw)
+            try:
+                f.find()
+            except AssertionError:
+                asserted += 1
+                f.close()
+                continue
+            except ValueError:
+                continue                                          # (also undefined in the reference)
+            print("library did not raise where the reference asserts:", desc, mode, kw); sys.exit(1)
         wl = None
         if len(full["kmers"]) and rng.random() < 0.25:
             wl = set(int(x) for x in full["kmers"][rng.random(len(full["kmers"])) < 0.5])
             full = oracle.find(g, k, crit, one, M, whitelist=wl, **kw)
-        elif rng.random() < 0.15:
+        elif rng.random() < 0.15 and "only_follow_nodes" not in kw:
             osn = set(int(x) for x in np.nonzero(rng.random(g.n_nodes) < 0.4)[0])
             kw = dict(kw, only_store_nodes=osn)                   # kmer_finder.py:153 (the bulk path ignores it, :370-374)
             full = oracle.find(g, k, crit, one, M, **kw)
@@ -259,7 +284,7 @@ def main():
             assert_same_records(finder_cols(f), full)
         except AssertionError as e:
             print("MISMATCH:", desc, mode, kw, "whitelist" if wl else "", e); sys.exit(1)
-        if rng.random() < 0.35 and wl is None and "only_store_nodes" not in kw:
+        if rng.random() < 0.35 and wl is None:
             # the FlatKmers emit path (other kernels' format, split and by-node layouts) holds the same records
             pos = g.position_id_base()[full["start_nodes"]] + full["start_offsets"]
             want = (full["kmers"].astype(np.uint64), full["nodes"].astype(np.uint32), pos.astype(np.uint64),
@@ -273,7 +298,7 @@ def main():
                 if len(got[0]) != len(want[0]) or not all(np.array_equal(a_[og], b_[ow]) for a_, b_ in zip(got, want)):
                     print("MISMATCH flat layout split=%s:" % split, desc, mode, kw); sys.exit(1)
                 d.free()
-        if not kw and wl is None and rng.random() < 0.25:
+        if not kw and wl is None and rng.random() < 0.25:        # (whole runs without node sets only)
             # the multi-GPU shards (sharding.critical_path_cuts) partition the full run
             from graph_kmer_index_amd.sharding import critical_path_cuts
             world = int(rng.integers(2, 7))
@@ -296,7 +321,8 @@ def main():
                     print("MISMATCH shards do not partition the run:", desc, mode, "world", world, cuts, e); sys.exit(1)
         f.close()
         checked += 1
-    print("soak ok: %d graphs compared, %d refused (undefined in the reference / unsupported), %d drawn" % (checked, refused, it))
+    print("soak ok: %d graphs compared, %d raised the reference's linear-successor assertion like the oracle, %d refused "
+          "(undefined in the reference / unsupported), %d drawn" % (checked, asserted, refused, it))
     for reason, count in sorted(why.items(), key=lambda kv: -kv[1]):
         print("   refused %5d x %s" % (count, reason))
 
