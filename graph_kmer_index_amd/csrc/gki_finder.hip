@@ -102,7 +102,7 @@ __device__ __forceinline__ int32_t bnd_len_of(const DevGraph &g, const FindArgs 
     int32_t reach = a.k - 1;                                          // offsets < k-1 look into predecessors
     if (a.has_lossy && lossy[n] != 0xFFFF) reach = lossy[n] + a.k - 1;      // E1 windows end up to c+k-2
     if (a.nflags) { if (a.nflags[n] & GKI_NODE_DEAD) reach = size; }  // general graphs: the search never enters the node
-    else if (!g.is_ref[n] && a.M < 1) reach = size;                   // variant node, limit 0: nothing admissible
+    else if (a.M < 1 && !g.is_ref[n]) reach = size;                   // variant node, limit 0: nothing admissible
     return size < reach ? size : reach;
 }
 
@@ -1206,7 +1206,9 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
     if (a.split)
         GKI_TRY(gki_scan_u32_to_i64(f->bcount + a.n0, n_run, f->bnd_base + a.n0, f->scan_tmp, f->scan_tmp_bytes, s));
     if (n_run > 0) {
-        hipLaunchKernelGGL(k_node_emit, dim3(stream_grid(n_run, 256)), dim3(256), 0, s, d, a, f->lossy, f->bcount,
+        // one node per thread, no grid-stride loop: a thread's loads and its 48-byte store form one dependent chain, so the
+        // kernel lives on the number of chains in flight
+        hipLaunchKernelGGL(k_node_emit, dim3((unsigned)ceil_div(n_run, 256)), dim3(256), 0, s, d, a, f->lossy, f->bcount,
                            f->rec_base, f->ne);
         HIP_TRY(hipGetLastError());
     }

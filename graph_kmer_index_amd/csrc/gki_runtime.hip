@@ -277,13 +277,31 @@ __device__ __forceinline__ TAcc block_exclusive(TAcc v, TAcc *total, TAcc *lds /
     return wave_off + inc - v;
 }
 
+// A thread's SI = 8 consecutive items: two 16-byte loads when they are 4-byte items of a full, aligned tile (the
+// element-wise form costs the address unit eight passes over the same lines).
+template <typename TIn, typename TAcc>
+__device__ __forceinline__ void load_items(const TIn *__restrict__ in, int64_t base, int64_t n, TAcc v[SI]) {
+    static_assert(SI == 8, "two uint4 per thread");
+    if (sizeof(TIn) == 4 && base + SI <= n && (reinterpret_cast<uintptr_t>(in + base) & 15) == 0) {
+        const uint4 a = reinterpret_cast<const uint4 *>(in + base)[0], b = reinterpret_cast<const uint4 *>(in + base)[1];
+        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int i = 0; i < SI; i++) { TIn t; __builtin_memcpy(&t, &w[i], 4); v[i] = (TAcc)t; }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < SI; i++) v[i] = (base + i < n) ? (TAcc)in[base + i] : (TAcc)0;
+}
+
 template <typename TIn, typename TAcc>
 __global__ __launch_bounds__(SB) void k_block_sums(const TIn *__restrict__ in, int64_t n, TAcc *__restrict__ sums) {
     __shared__ TAcc lds[SB / 64 + 1];
     int64_t base = (int64_t)blockIdx.x * STILE + (int64_t)threadIdx.x * SI;
+    TAcc v[SI];
+    load_items<TIn, TAcc>(in, base, n, v);
     TAcc s = 0;
 #pragma unroll
-    for (int i = 0; i < SI; i++) if (base + i < n) s += (TAcc)in[base + i];
+    for (int i = 0; i < SI; i++) s += v[i];
     TAcc tot;
     block_exclusive<TAcc>(s, &tot, lds);
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
@@ -296,12 +314,25 @@ __global__ __launch_bounds__(SB) void k_block_scan(const TIn *__restrict__ in, i
     __shared__ TAcc lds[SB / 64 + 1];
     int64_t base = (int64_t)blockIdx.x * STILE + (int64_t)threadIdx.x * SI;
     TAcc v[SI];
+    load_items<TIn, TAcc>(in, base, n, v);
     TAcc s = 0;
 #pragma unroll
-    for (int i = 0; i < SI; i++) { v[i] = (base + i < n) ? (TAcc)in[base + i] : (TAcc)0; s += v[i]; }
+    for (int i = 0; i < SI; i++) s += v[i];
     TAcc tot;
     TAcc ex = block_exclusive<TAcc>(s, &tot, lds);
     ex += block_off ? block_off[blockIdx.x] : (TAcc)0;
+    if (sizeof(TOut) == 8 && base + SI < n && (reinterpret_cast<uintptr_t>(out + base) & 15) == 0) {
+        // a full tile that does not hold the last item: four 16-byte stores
+        ulonglong2 *o2 = reinterpret_cast<ulonglong2 *>(out + base);
+#pragma unroll
+        for (int i = 0; i < SI; i += 2) {
+            ulonglong2 p;
+            p.x = (unsigned long long)(TOut)ex; ex += v[i];
+            p.y = (unsigned long long)(TOut)ex; ex += v[i + 1];
+            o2[i / 2] = p;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < SI; i++) {
         if (base + i < n) out[base + i] = (TOut)ex;
