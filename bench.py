@@ -36,14 +36,14 @@ BYTES_PER_RECORD = 25            # 1 B of node sequence read + 2
 def pmc_traffic(n_ref_bases, n_sites, k):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (collected with
     tools/collect_pmc.sh on the same workload; counters cannot be read from inside this process)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_3gbp.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_3gbp.json")
     try:
         with open(path) as fh:
             d = json.load(fh)
         w = d["workload"]
         if (w["n_ref_bases"], w["n_snp_bubbles"], w["k"]) != (n_ref_bases, n_sites, k):
             return None, None
-        return d["dominant_kernel_traffic_bytes_per_launch"], "profiles/r01_pmc_3gbp.json"
+        return d["dominant_kernel_traffic_bytes_per_launch"], "profiles/r02_pmc_3gbp.json"
     except (OSError, KeyError, ValueError):
         return None, None
 
