@@ -200,6 +200,8 @@ def main():
                     "deletions and insertions (north star's SNP/indel mix; empty nodes in the graph)")
     ap.add_argument("--all-nodes", action="store_true", help="diagnostic: only_save_one_node_per_kmer=False")
     ap.add_argument("--pretend-shard", default=None, help="diagnostic: R/W -> run only rank R's shard of W on this one GPU")
+    ap.add_argument("--general", action="store_true", help="diagnostic: run the general-graph kernel variants (node flags of "
+                    "gki_classify_nodes) on this graph, which does not need them: what the flags cost")
     ap.add_argument("--verify", action="store_true", help="size-independent checks on the full output (slow)")
     ap.add_argument("--reads", type=float, default=4e6, help="reads of the read_mapping record (0: skip the secondary records)")
     args = ap.parse_args()
@@ -253,6 +255,8 @@ def main():
                              start_at_critical_path_number=a if shard_w > 1 else None,
                              stop_at_critical_path_number=b if shard_w > 1 else None)
 
+    finder._force_general_kernels = args.general
+
     def barrier():
         _lib.check(lib.gki_device_synchronize())
         plane.barrier()
@@ -281,7 +285,7 @@ def main():
     if args.verify:
         checks = verify(out, g, k, n_interior)
     secondary = None
-    if (world == 1 and args.reads > 0 and not (args.linear or args.indels or args.all_nodes or args.pretend_shard)
+    if (world == 1 and args.reads > 0 and not (args.linear or args.indels or args.all_nodes or args.pretend_shard or args.general)
             and out.n - n_interior > 0):
         secondary = secondary_records(lib, _lib, g, k, finder, out, int(args.reads))
 

@@ -117,12 +117,14 @@ constexpr int WC_REV = 192;
 struct WalkCache {
     uint4 rec[2 * (WC_HALO + 64)];
     int32_t rev[WC_REV];
+    uint8_t flg[WC_HALO + 64];       // general graphs: the GKI_NODE_* byte of the staged nodes
 };
 struct WalkView {                // wave-uniform bounds of what the cache holds
     int64_t lo, hi;              // nodes
     int64_t r0, r1;              // rev_edges entries
 };
-__device__ __forceinline__ WalkView stage_walk(const DevGraph &g, WalkCache &wc, int64_t base, int lane) {
+__device__ __forceinline__ WalkView stage_walk(const DevGraph &g, WalkCache &wc, int64_t base, int lane,
+                                               const uint8_t *__restrict__ nflags = nullptr) {
     WalkView v;
     v.lo = base - WC_HALO < 0 ? 0 : base - WC_HALO;
     v.hi = base + 64 > g.n_nodes ? g.n_nodes : base + 64;
@@ -140,10 +142,19 @@ __device__ __forceinline__ WalkView stage_walk(const DevGraph &g, WalkCache &wc,
     for (int u = 0; u < RC; u++) { const int j = u * 64 + lane; t[u] = j < n16 ? src[j] : make_uint4(0, 0, 0, 0); }
 #pragma unroll
     for (int u = 0; u < VC; u++) { const int j = u * 64 + lane; r[u] = j < n_rev ? g.rev_edges[v.r0 + j] : 0; }
+    uint8_t fl[2] = {0, 0};
+    if (nflags) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) { const int j = u * 64 + lane; if (j < (int)(v.hi - v.lo)) fl[u] = nflags[v.lo + j]; }
+    }
 #pragma unroll
     for (int u = 0; u < RC; u++) wc.rec[u * 64 + lane] = t[u];
 #pragma unroll
     for (int u = 0; u < VC; u++) wc.rev[u * 64 + lane] = r[u];
+    if (nflags) {
+        wc.flg[lane] = fl[0];
+        if (lane < WC_HALO) wc.flg[64 + lane] = fl[1];
+    }
     __builtin_amdgcn_wave_barrier();
     return v;
 }
@@ -171,6 +182,13 @@ __device__ __forceinline__ NodeWalk cached_walk(const DevGraph &g, const WalkCac
     w.is_ref = (uint8_t)((hi16.w >> 16) & 0xFFu);
     w.pad = 0;
     return w;
+}
+__device__ __forceinline__ uint8_t cached_flag(const uint8_t *__restrict__ nflags, const WalkCache &wc, const WalkView &v, int64_t q) {
+    const bool in = q >= v.lo && q < v.hi;
+    int32_t f = wc.flg[in ? q - v.lo : 0];
+    opaque(f);
+    if (!in) f = nflags[q];
+    return (uint8_t)f;
 }
 __device__ __forceinline__ int32_t cached_preds_next(const DevGraph &g, const WalkCache &wc, const WalkView &v, int32_t *cur) {
     if (*cur < 0) { const int32_t q = ~*cur; *cur = 0; return q; }
@@ -323,12 +341,12 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
     WalkCache &wc = s_wc[wib];
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t base = a.n0 + (int64_t)blockIdx.x * blockDim.x + wib * 64; base < a.n1; base += stride) {
-        const WalkView wv = stage_walk(g, wc, base, lane);
+        const WalkView wv = stage_walk(g, wc, base, lane, GEN ? a.nflags : nullptr);
         const int64_t n = base + lane;
         if (n >= a.n1) continue;
         const NodeWalk wn = cached_walk(g, wc, wv, n);
         const int32_t size = wn.size;
-        const uint8_t fn = GEN ? a.nflags[n] : (uint8_t)0;
+        const uint8_t fn = GEN ? cached_flag(a.nflags, wc, wv, n) : (uint8_t)0;
         const bool reach_n = !(GEN && (fn & GKI_NODE_DEAD));
         const int32_t bl = bnd_len_of(g, a, lossy, n, size);
         uint32_t count = 0;
@@ -368,7 +386,7 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
                     }
                     const int32_t q = cached_preds_next(g, wc, wv, &t_cur);
                     const NodeWalk wq = cached_walk(g, wc, wv, q);
-                    const uint8_t fq = GEN ? a.nflags[q] : (uint8_t)0;
+                    const uint8_t fq = GEN ? cached_flag(a.nflags, wc, wv, q) : (uint8_t)0;
                     if (GEN) {
                         if (fq & GKI_NODE_DEAD) continue;
                         if ((fq & GKI_NODE_HFS) && !(a.nflags[path[L - 1]] & GKI_NODE_FORCED)) continue;
@@ -464,10 +482,10 @@ struct EvQueue {
     uint8_t from[EVQ], cnt[EVQ];
     uint8_t nl[ALL ? EVQ : 1];                 // all-nodes mode: number of distinct window nodes of the step ...
     int32_t nodes[ALL ? EVQ : 1][NLQ];         // ... and the nodes, ascending (np.unique, kmer_finder.py:134)
-    // one-node mode, lane-per-record expansion: the queue's records numbered 0 .. T-1 in output order
-    uint16_t pre[ALL ? 1 : EVQ];               // first record number of the step at sorted position s
-    uint64_t marks[ALL ? 1 : EVQ * 32 / 64];   // bit r set: a step starts at record r (T <= EVQ * 32)
-    uint16_t wrank[ALL ? 1 : EVQ * 32 / 64];   // steps that start before word w of marks
+    // lane-per-window expansion: the queue's windows (one per step and offset) numbered 0 .. T-1 in output order
+    uint16_t pre[EVQ];               // first window number of the step at sorted position s
+    uint64_t marks[EVQ * 32 / 64];   // bit r set: a step starts at window r (T <= EVQ * 32)
+    uint16_t wrank[EVQ * 32 / 64];   // steps that start before word w of marks
 };
 
 #ifdef GKI_TUNING
@@ -503,67 +521,56 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
         __builtin_amdgcn_wave_barrier();
     }
     const int64_t mn_idx = q.idx[q.order[0]];        // smallest record slot of the queue
-    if (!ALL) {
-        // One lane per RECORD.  Half of the steps of a SNP graph hold a single record, so "one step per half-wave"
-        // left two thirds of the lanes idle and the address unit paid for 6.4e7 store instructions on the 3 Gbp
-        // graph (SQ_INSTS_VMEM_WR).  Here the T records of the queue are numbered in output order: an exclusive
-        // prefix of the sorted steps' sizes, a bitmap with a bit at every step's first record, and the step of record r
-        // is a popcount over that bitmap -- no search.  Trips are aligned to 16 records of the output so that a store
-        // instruction covers whole cache lines of every column wherever the steps are contiguous.
-        static_assert(EVQ * 32 / 64 == 64, "one bitmap word per lane");
-        const int c0 = lane < n_ev ? (int)q.cnt[q.order[lane]] : 0;
-        const int c1 = lane + 64 < n_ev ? (int)q.cnt[q.order[lane + 64]] : 0;
-        int s0 = c0, s1 = c1;
+    // One lane per WINDOW (= per record in one-node mode).  Half of the steps of a SNP graph hold a single window, so
+    // "one step per half-wave" left two thirds of the lanes idle and the address unit paid for 6.4e7 store
+    // instructions on the 3 Gbp graph (SQ_INSTS_VMEM_WR).  Here the T windows of the queue are numbered in output
+    // order: an exclusive prefix of the sorted steps' sizes, a bitmap with a bit at every step's first window, and the
+    // step of window r is a popcount over that bitmap -- no search.  Trips are aligned to 16 records of the output so
+    // that a store instruction covers whole cache lines of every column wherever the steps are contiguous.  In
+    // all-nodes mode a window has one record per distinct node: the lane writes them in turn (neighbouring lanes then
+    // write `nl` records apart and the following turns fill the gaps while the lines are still in L2).
+    static_assert(EVQ * 32 / 64 == 64, "one bitmap word per lane");
+    const int c0 = lane < n_ev ? (int)q.cnt[q.order[lane]] : 0;
+    const int c1 = lane + 64 < n_ev ? (int)q.cnt[q.order[lane + 64]] : 0;
+    int s0 = c0, s1 = c1;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t0 = __shfl_up(s0, d, 64), t1 = __shfl_up(s1, d, 64);
-            if (lane >= d) { s0 += t0; s1 += t1; }
-        }
-        const int tot0 = __shfl(s0, 63, 64);
-        const int T = tot0 + __shfl(s1, 63, 64);
-        const int ex0 = s0 - c0, ex1 = tot0 + s1 - c1;
-        q.pre[lane] = (uint16_t)ex0; q.pre[lane + 64] = (uint16_t)ex1;
-        q.marks[lane] = 0ull;
-        __builtin_amdgcn_wave_barrier();
-        unsigned int *marks32 = reinterpret_cast<unsigned int *>(q.marks);
-        if (c0) atomicOr(&marks32[ex0 >> 5], 1u << (ex0 & 31));
-        if (c1) atomicOr(&marks32[ex1 >> 5], 1u << (ex1 & 31));
-        __builtin_amdgcn_wave_barrier();
-        const int pc = __popcll(q.marks[lane]);
-        int ps = pc;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(ps, d, 64); if (lane >= d) ps += t; }
-        q.wrank[lane] = (uint16_t)(ps - pc);
-        __builtin_amdgcn_wave_barrier();
-        const int shift = (int)(mn_idx & 15);
-        for (int r0 = -shift; r0 < T; r0 += 64) {
-            const int r = r0 + lane;
-            if (r >= 0 && r < T) {
-                const int w = r >> 6;
-                const int sp = (int)q.wrank[w] + __popcll(q.marks[w] & ((2ull << (r & 63)) - 1ull)) - 1;
-                const int e = (int)q.order[sp];
-                const int j = r - (int)q.pre[sp];
-                const int o = q.from[e] + j, ln = q.ln[e];
-                const uint64_t h = ((q.ctx[e] >> (2 * o)) | (q.own[ln] << (2 * (k - 1 - o)))) & kmask;
-                put(out, q.idx[e] + j, h, q.mn[e], q.n[ln], o, q.pos0[ln] + o, (double)q.maf[e]);
-            }
-        }
-        return;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t0 = __shfl_up(s0, d, 64), t1 = __shfl_up(s1, d, 64);
+        if (lane >= d) { s0 += t0; s1 += t1; }
     }
-    // All-nodes mode: two steps per trip, one per half-wave (a step has at most k-1 <= 30 offsets): lane l of a half
-    // starts at record l of its step.
-    const int half = lane >> 5, l = lane & 31;
-    for (int i = 0; i < n_ev; i += 2) {
-        const int pos = i + half;
-        if (pos < n_ev) {
-            const int e = (int)q.order[pos];
-            {                                          // one record per offset and distinct node, nodes ascending per offset
-                const int nl = (int)q.nl[e], total = (int)q.cnt[e] * nl, ln = q.ln[e];
-                for (int t = l; t < total; t += 32) {
-                    const int o = q.from[e] + t / nl;
-                    const uint64_t h = ((q.ctx[e] >> (2 * o)) | (q.own[ln] << (2 * (k - 1 - o)))) & kmask;
-                    put(out, q.idx[e] + t, h, q.nodes[e][t % nl], q.n[ln], o, q.pos0[ln] + o, (double)q.maf[e]);
-                }
+    const int tot0 = __shfl(s0, 63, 64);
+    const int T = tot0 + __shfl(s1, 63, 64);
+    const int ex0 = s0 - c0, ex1 = tot0 + s1 - c1;
+    q.pre[lane] = (uint16_t)ex0; q.pre[lane + 64] = (uint16_t)ex1;
+    q.marks[lane] = 0ull;
+    __builtin_amdgcn_wave_barrier();
+    unsigned int *marks32 = reinterpret_cast<unsigned int *>(q.marks);
+    if (c0) atomicOr(&marks32[ex0 >> 5], 1u << (ex0 & 31));
+    if (c1) atomicOr(&marks32[ex1 >> 5], 1u << (ex1 & 31));
+    __builtin_amdgcn_wave_barrier();
+    const int pc = __popcll(q.marks[lane]);
+    int ps = pc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(ps, d, 64); if (lane >= d) ps += t; }
+    q.wrank[lane] = (uint16_t)(ps - pc);
+    __builtin_amdgcn_wave_barrier();
+    const int shift = ALL ? 0 : (int)(mn_idx & 15);
+    for (int r0 = -shift; r0 < T; r0 += 64) {
+        const int r = r0 + lane;
+        if (r >= 0 && r < T) {
+            const int w = r >> 6;
+            const int sp = (int)q.wrank[w] + __popcll(q.marks[w] & ((2ull << (r & 63)) - 1ull)) - 1;
+            const int e = (int)q.order[sp];
+            const int j = r - (int)q.pre[sp];
+            const int o = q.from[e] + j, ln = q.ln[e];
+            const uint64_t h = ((q.ctx[e] >> (2 * o)) | (q.own[ln] << (2 * (k - 1 - o)))) & kmask;
+            if (!ALL) {
+                put(out, q.idx[e] + j, h, q.mn[e], q.n[ln], o, q.pos0[ln] + o, (double)q.maf[e]);
+            } else {                                   // one record per distinct node of the window, nodes ascending
+                const int nl = (int)q.nl[e];
+                const int64_t first = q.idx[e] + (int64_t)j * nl;
+                for (int t = 0; t < nl; t++)
+                    put(out, first + t, h, q.nodes[e][t], q.n[ln], o, q.pos0[ln] + o, (double)q.maf[e]);
             }
         }
     }
@@ -599,7 +606,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
     const int64_t n_threads = (int64_t)gridDim.x * blockDim.x;
     int n_ev = 0, my_cnt = 0;              // steps in the queue; of them, queued by this lane
     for (int64_t base = a.n0 + (int64_t)blockIdx.x * blockDim.x + wib * 64; base < a.n1; base += n_threads) {
-        const WalkView wv = stage_walk(g, wc, base, lane);
+        const WalkView wv = stage_walk(g, wc, base, lane, GEN ? a.nflags : nullptr);
         const int64_t n = base + lane;
         int L = 0, o_lo = 0, hi = 0;
         int64_t idx = 0, pos0 = 0;
@@ -612,7 +619,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
         int t_a = 0;
         if (n < a.n1 && bcount[n] > 0) {
             const NodeWalk wn = cached_walk(g, wc, wv, n);
-            const uint8_t fn = GEN ? a.nflags[n] : (uint8_t)0;
+            const uint8_t fn = GEN ? cached_flag(a.nflags, wc, wv, n) : (uint8_t)0;
             const int32_t bl = bnd_len_of(g, a, lossy, n, wn.size);
             idx = rec_base[n] + *bnd_shift;
             pos0 = g.pos_base[n];
@@ -663,7 +670,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                 } else {
                     const int32_t qn = cached_preds_next(g, wc, wv, &t_cur);
                     const NodeWalk wq = cached_walk(g, wc, wv, qn);
-                    const uint8_t fq = GEN ? a.nflags[qn] : (uint8_t)0;
+                    const uint8_t fq = GEN ? cached_flag(a.nflags, wc, wv, qn) : (uint8_t)0;
                     const int vq = t_vc + (GEN ? ((fq & GKI_NODE_REF) ? 0 : 1) : (wq.is_ref ? 0 : 1));
                     bool take;
                     int aq = 0;

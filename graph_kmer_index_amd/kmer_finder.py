@@ -225,6 +225,7 @@ class DenseKmerFinder:
                 rank = g.__dict__["_topological_rank"]
                 if not (start_at is not None and start_at > 0):
                     node_begin, off_begin = int(np.argmin(rank)), 0   # "from the graph start" = from rank 0
+        general = general or getattr(self, "_force_general_kernels", False)    # bench.py --general: price of the flags
         store = None
         if self._only_store_nodes is not None:                     # kmer_finder.py:153, applied by the general kernels
             store = np.zeros(g.n_nodes, dtype=np.uint8)
