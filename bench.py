@@ -198,6 +198,9 @@ def main():
     ap.add_argument("--linear", action="store_true", help="diagnostic: linear chain graph without variants (BASELINE configs[1] shape)")
     ap.add_argument("--indels", type=float, default=0.0, help="diagnostic: this fraction of the sites each become 1-bp "
                     "deletions and insertions (north star's SNP/indel mix; empty nodes in the graph)")
+    ap.add_argument("--nested", type=float, default=0.0, help="diagnostic: this fraction of the sites get an alternative allele "
+                    "that contains a SNP itself (nodes with no linear-ref predecessor: the general kernels); "
+                    "max_variant_nodes is raised to 8 so that the reference's linear-successor assertion stays quiet")
     ap.add_argument("--all-nodes", action="store_true", help="diagnostic: only_save_one_node_per_kmer=False")
     ap.add_argument("--pretend-shard", default=None, help="diagnostic: R/W -> run only rank R's shard of W on this one GPU")
     ap.add_argument("--general", action="store_true", help="diagnostic: run the general-graph kernel variants (node flags of "
@@ -220,7 +223,7 @@ def main():
     plane = SocketControlPlane(rank, world)           # barrier + max / sum of two scalars; a no-op at world 1
 
     from graph_kmer_index_amd import _lib, DenseKmerFinder, CriticalGraphPaths, DeviceGraph
-    from graph_kmer_index_amd.graph import synthetic_snp_graph, synthetic_linear_graph, synthetic_indel_graph
+    from graph_kmer_index_amd.graph import synthetic_snp_graph, synthetic_linear_graph, synthetic_indel_graph, synthetic_nested_graph
     from graph_kmer_index_amd.sharding import shard_range
     lib = _lib.load()
     _lib.require_device()
@@ -233,6 +236,9 @@ def main():
         g = synthetic_linear_graph(G, 25000, seed=1234)
     elif args.indels > 0:
         g = synthetic_indel_graph(G, S, k=k, seed=1234, p_del=args.indels, p_ins=args.indels)
+    elif args.nested > 0:
+        g = synthetic_nested_graph(G, S, k=k, seed=1234, p_nest=args.nested)
+        args.max_variant_nodes = max(args.max_variant_nodes, 8)
     else:
         g = synthetic_snp_graph(G, S, k=k, seed=1234)
     t_gen = time.perf_counter() - t0
@@ -285,7 +291,7 @@ def main():
     if args.verify:
         checks = verify(out, g, k, n_interior)
     secondary = None
-    if (world == 1 and args.reads > 0 and not (args.linear or args.indels or args.all_nodes or args.pretend_shard or args.general)
+    if (world == 1 and args.reads > 0 and not (args.linear or args.indels or args.nested or args.all_nodes or args.pretend_shard or args.general)
             and out.n - n_interior > 0):
         secondary = secondary_records(lib, _lib, g, k, finder, out, int(args.reads))
 
@@ -294,7 +300,7 @@ def main():
         value = n_total * args.steps / elapsed
         avg_int_ms = float(np.mean(interior_ms))
         achieved = BYTES_PER_RECORD * n_interior / (avg_int_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(G, S, k) if world == 1 and not args.linear and not args.indels else (None, None)
+        traffic, traffic_src = pmc_traffic(G, S, k) if world == 1 and not (args.linear or args.indels or args.nested) else (None, None)
         res = {
             "metric": "k-mers hashed+indexed per second (k=31, 3 Gbp graph)", "value": value, "unit": "k-mers/s",
             "timed_region": "enumerate + hash + FlatKmers rows in HBM (gki_finder_count + gki_finder_emit_flat); the index "

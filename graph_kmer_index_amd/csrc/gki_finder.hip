@@ -42,7 +42,7 @@ struct FindArgs {
     int32_t rank_begin, rank_end;
     int32_t split, pad;      // output layout: 0 = by end node (boundary block, then interior run, per node);
                              // 1 = all interior records (by position) first, then all boundary records (by node)
-    const uint8_t *nflags;   // NULL, or the GKI_NODE_* byte of every node (general graphs, include/gki.h)
+    const uint16_t *nflags;  // NULL, or per node: GKI_NODE_* byte | history bound << 8 (general graphs, include/gki.h)
     const uint8_t *store;    // NULL, or only_store_nodes membership per node (kmer_finder.py:153); needs nflags
 };
 
@@ -117,14 +117,14 @@ constexpr int WC_REV = 192;
 struct WalkCache {
     uint4 rec[2 * (WC_HALO + 64)];
     int32_t rev[WC_REV];
-    uint8_t flg[WC_HALO + 64];       // general graphs: the GKI_NODE_* byte of the staged nodes
+    uint16_t flg[WC_HALO + 64];      // general graphs: the flag word of the staged nodes
 };
 struct WalkView {                // wave-uniform bounds of what the cache holds
     int64_t lo, hi;              // nodes
     int64_t r0, r1;              // rev_edges entries
 };
 __device__ __forceinline__ WalkView stage_walk(const DevGraph &g, WalkCache &wc, int64_t base, int lane,
-                                               const uint8_t *__restrict__ nflags = nullptr) {
+                                               const uint16_t *__restrict__ nflags = nullptr) {
     WalkView v;
     v.lo = base - WC_HALO < 0 ? 0 : base - WC_HALO;
     v.hi = base + 64 > g.n_nodes ? g.n_nodes : base + 64;
@@ -142,7 +142,7 @@ __device__ __forceinline__ WalkView stage_walk(const DevGraph &g, WalkCache &wc,
     for (int u = 0; u < RC; u++) { const int j = u * 64 + lane; t[u] = j < n16 ? src[j] : make_uint4(0, 0, 0, 0); }
 #pragma unroll
     for (int u = 0; u < VC; u++) { const int j = u * 64 + lane; r[u] = j < n_rev ? g.rev_edges[v.r0 + j] : 0; }
-    uint8_t fl[2] = {0, 0};
+    uint16_t fl[2] = {0, 0};
     if (nflags) {
 #pragma unroll
         for (int u = 0; u < 2; u++) { const int j = u * 64 + lane; if (j < (int)(v.hi - v.lo)) fl[u] = nflags[v.lo + j]; }
@@ -183,12 +183,12 @@ __device__ __forceinline__ NodeWalk cached_walk(const DevGraph &g, const WalkCac
     w.pad = 0;
     return w;
 }
-__device__ __forceinline__ uint8_t cached_flag(const uint8_t *__restrict__ nflags, const WalkCache &wc, const WalkView &v, int64_t q) {
+__device__ __forceinline__ uint16_t cached_flag(const uint16_t *__restrict__ nflags, const WalkCache &wc, const WalkView &v, int64_t q) {
     const bool in = q >= v.lo && q < v.hi;
     int32_t f = wc.flg[in ? q - v.lo : 0];
     opaque(f);
     if (!in) f = nflags[q];
-    return (uint8_t)f;
+    return (uint16_t)f;
 }
 __device__ __forceinline__ int32_t cached_preds_next(const DevGraph &g, const WalkCache &wc, const WalkView &v, int32_t *cur) {
     if (*cur < 0) { const int32_t q = ~*cur; *cur = 0; return q; }
@@ -241,8 +241,8 @@ struct LevelLo {                 // what a suspended level needs to resume
 // gki_classify_nodes settled on the host (GKI_NODE_DEAD is exact).
 constexpr int HMAX = 40;         // nodes of one enumerated history (k-1 one-base nodes + slack)
 
-__device__ __noinline__ bool history_ok(const DevGraph &g, const uint8_t *__restrict__ nf, int k, int M,
-                                        const int32_t *path, int L, int *err) {
+__device__ __noinline__ bool history_ok(const DevGraph &g, const WalkCache &wc, const WalkView &wv,
+                                        const uint16_t *__restrict__ nf, int k, int M, const int32_t *path, int L, int *err) {
     // open constraints of the window's nodes path[0..L] (end node .. q): the step into a non-free node y still sees
     // the history nodes within t bases of q's entry and tolerates fewer than m variant nodes among them
     int8_t ct[MAXN];
@@ -252,14 +252,14 @@ __device__ __noinline__ bool history_ok(const DevGraph &g, const uint8_t *__rest
         int between = 0, c = 0;                  // bases / variant nodes of path[i+1..L]
         for (int i = L; i >= 0; i--) {
             const int32_t y = path[i];
-            const uint8_t fy = nf[y];
+            const uint16_t fy = cached_flag(nf, wc, wv, y);
             if (!(fy & (GKI_NODE_REF | GKI_NODE_FORCED))) {
                 const int m = M - c;
                 if (m <= 0) return false;
                 const int t = k - between;
                 if (t > 0) { ct[nc] = (int8_t)t; cm[nc] = (int16_t)(m > 30000 ? 30000 : m); nc++; }
             }
-            const int sy = g.walk[y].size;
+            const int sy = cached_walk(g, wc, wv, y).size;
             between = between + sy > k ? k : between + sy;
             c += (fy & GKI_NODE_REF) ? 0 : 1;
         }
@@ -267,18 +267,18 @@ __device__ __noinline__ bool history_ok(const DevGraph &g, const uint8_t *__rest
     int32_t hn[HMAX], hcur[HMAX], hend[HMAX], hd[HMAX], hsz[HMAX];     // history nodes, nearest first; hd = bases nearer than the node
     uint8_t hf[HMAX];
     {
-        const NodeWalk wq = g.walk[path[L]];
+        const NodeWalk wq = cached_walk(g, wc, wv, path[L]);
         preds_begin(g, wq, path[L], &hcur[0], &hend[0]);
     }
     int h = 0;
     for (;;) {
         if (hcur[h] >= hend[h]) { if (h == 0) return false; h--; continue; }
-        const int32_t p = preds_next(g, &hcur[h]);
-        const uint8_t fp = nf[p];
+        const int32_t p = cached_preds_next(g, wc, wv, &hcur[h]);
+        const uint8_t fp = (uint8_t)cached_flag(nf, wc, wv, p);
         if (fp & GKI_NODE_DEAD) continue;
         const int32_t child = h == 0 ? path[L] : hn[h - 1];
         if ((fp & GKI_NODE_HFS) && !(nf[child] & GKI_NODE_FORCED)) continue;      // edge removed by a forced sibling
-        const NodeWalk wp = g.walk[p];
+        const NodeWalk wp = cached_walk(g, wc, wv, p);
         hn[h] = p; hf[h] = fp;
         hd[h] = h == 0 ? 0 : hd[h - 1] + hsz[h - 1];
         hsz[h] = wp.size > (1 << 20) ? (1 << 20) : wp.size;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
         if (n >= a.n1) continue;
         const NodeWalk wn = cached_walk(g, wc, wv, n);
         const int32_t size = wn.size;
-        const uint8_t fn = GEN ? cached_flag(a.nflags, wc, wv, n) : (uint8_t)0;
+        const uint16_t fn = GEN ? cached_flag(a.nflags, wc, wv, n) : (uint16_t)0;
         const bool reach_n = !(GEN && (fn & GKI_NODE_DEAD));
         const int32_t bl = bnd_len_of(g, a, lossy, n, size);
         uint32_t count = 0;
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
                     }
                     const int32_t q = cached_preds_next(g, wc, wv, &t_cur);
                     const NodeWalk wq = cached_walk(g, wc, wv, q);
-                    const uint8_t fq = GEN ? cached_flag(a.nflags, wc, wv, q) : (uint8_t)0;
+                    const uint16_t fq = GEN ? cached_flag(a.nflags, wc, wv, q) : (uint16_t)0;
                     if (GEN) {
                         if (fq & GKI_NODE_DEAD) continue;
                         if ((fq & GKI_NODE_HFS) && !(a.nflags[path[L - 1]] & GKI_NODE_FORCED)) continue;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
                         if (GEN && from < to) {
                             bool ok = true;                          // a history before the window's first node?
                             if (!(fq & (GKI_NODE_T | GKI_NODE_SIMPLE)))
-                                ok = (fq & GKI_NODE_NESTED) ? history_ok(g, a.nflags, k, a.M, path, L, err) : false;
+                                ok = (fq & GKI_NODE_NESTED) ? (vq + (int)(fq >> 8) < a.M || history_ok(g, wc, wv, a.nflags, k, a.M, path, L, err)) : false;
                             if (ok && chk && from <= oc && oc < to && vq >= a.M) *err = GKI_ERR_NOT_ONE_REF_SUCC;
                             if (!ok) to = from;
                         }
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
         int t_a = 0;
         if (n < a.n1 && bcount[n] > 0) {
             const NodeWalk wn = cached_walk(g, wc, wv, n);
-            const uint8_t fn = GEN ? cached_flag(a.nflags, wc, wv, n) : (uint8_t)0;
+            const uint16_t fn = GEN ? cached_flag(a.nflags, wc, wv, n) : (uint16_t)0;
             const int32_t bl = bnd_len_of(g, a, lossy, n, wn.size);
             idx = rec_base[n] + *bnd_shift;
             pos0 = g.pos_base[n];
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                 } else {
                     const int32_t qn = cached_preds_next(g, wc, wv, &t_cur);
                     const NodeWalk wq = cached_walk(g, wc, wv, qn);
-                    const uint8_t fq = GEN ? cached_flag(a.nflags, wc, wv, qn) : (uint8_t)0;
+                    const uint16_t fq = GEN ? cached_flag(a.nflags, wc, wv, qn) : (uint16_t)0;
                     const int vq = t_vc + (GEN ? ((fq & GKI_NODE_REF) ? 0 : 1) : (wq.is_ref ? 0 : 1));
                     bool take;
                     int aq = 0;
@@ -700,7 +700,9 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                                 const int cq = HAS_LOSSY ? lossy_of(lossy, qn) : -1;
                                 if (HAS_LOSSY && cq >= 0) { const int min_ok = k - 1 - c - s + cq; if (from < min_ok) from = min_ok; }
                                 if (GEN && from < to && !(fq & (GKI_NODE_T | GKI_NODE_SIMPLE))) {      // a history before q?
-                                    const bool ok = (fq & GKI_NODE_NESTED) ? history_ok(g, a.nflags, k, a.M, path, L, err) : false;
+                                    // (fq >> 8: no history holds more variant nodes in the k bases before q -- if even
+                                    // that many fit under the limit, any history that enters q will do, and q is entered)
+                                    const bool ok = (fq & GKI_NODE_NESTED) ? (vq + (int)(fq >> 8) < a.M || history_ok(g, wc, wv, a.nflags, k, a.M, path, L, err)) : false;
                                     if (!ok) to = from;
                                 }
                                 const int tq = s < k - 1 - c ? s : k - 1 - c;
@@ -956,7 +958,7 @@ struct gki_finder {
     int64_t *rec_base, *bnd_base;     // by-node layout: rec_base only; split layout: interior bases / boundary bases
     NodeEmit *ne;
     uint16_t *lossy;
-    uint8_t *nflags, *store;          // general graphs / only_store_nodes (gki_find_params), allocated on first use
+    uint16_t *nflags; uint8_t *store; // general graphs / only_store_nodes (gki_find_params), allocated on first use
     void *scan_tmp; int64_t scan_tmp_bytes;
     int *d_err; int64_t *d_totals; unsigned long long *d_bsum;
     int32_t *d_rank;                  // topological ranks of the run in progress (non-topological node ids only)
@@ -1173,8 +1175,8 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
         a.store = f->store;
     }
     if (p->h_node_flags) {
-        if (!f->nflags) HIP_TRY(gki_dev_malloc((void **)&f->nflags, (size_t)d.n_nodes));
-        HIP_TRY(hipMemcpyAsync(f->nflags, p->h_node_flags, (size_t)d.n_nodes, hipMemcpyHostToDevice, s));
+        if (!f->nflags) HIP_TRY(gki_dev_malloc((void **)&f->nflags, (size_t)d.n_nodes * 2));
+        HIP_TRY(hipMemcpyAsync(f->nflags, p->h_node_flags, (size_t)d.n_nodes * 2, hipMemcpyHostToDevice, s));
         a.nflags = f->nflags;
         if (!a.has_lossy) HIP_TRY(hipMemsetAsync(f->lossy, 0xFF, (size_t)d.n_nodes * 2, s));   // the general kernels always read it
     }

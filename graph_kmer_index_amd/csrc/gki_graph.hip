@@ -294,9 +294,11 @@ bool host_node_has_history(const int32_t *node_size, const int64_t *rev_start, c
 
 int gki_classify_nodes(int64_t n_nodes, const int32_t *node_size, const int64_t *edge_start, const int32_t *edges,
                        const int64_t *rev_start, const int32_t *rev_edges, const uint8_t *is_ref, const uint8_t *follow,
-                       const int32_t *roots, int n_roots, int k, int max_variant_nodes, uint8_t *out, int32_t *general) {
+                       const int32_t *roots, int n_roots, int k, int max_variant_nodes, uint16_t *out16, int32_t *general) {
     *general = 0;
     if (n_nodes <= 0) return GKI_OK;
+    std::vector<uint8_t> flag_bytes((size_t)n_nodes, 0), bound((size_t)n_nodes, 0);
+    uint8_t *out = flag_bytes.data();
     bool ids_topological = true;
     for (int64_t n = 0; n < n_nodes && ids_topological; n++)
         for (int64_t e = edge_start[n]; e < edge_start[n + 1]; e++)
@@ -332,6 +334,17 @@ int gki_classify_nodes(int64_t n_nodes, const int32_t *node_size, const int64_t 
         const int64_t n = ids_topological ? i : order[(size_t)i];
         uint8_t f = out[n];
         const int64_t r0 = rev_start[n], r1 = rev_start[n + 1];
+        // upper bound on the variant nodes of the k bases before n, over every backward path (saturating)
+        {
+            int ub = 0;
+            for (int64_t r = rev_start[n]; r < rev_start[n + 1]; r++) {
+                const int32_t p = rev_edges[r];
+                if (out[p] & GKI_NODE_DEAD) continue;
+                int u = ((out[p] & GKI_NODE_REF) ? 0 : 1) + (node_size[p] >= k ? 0 : (int)bound[(size_t)p]);
+                if (u > ub) ub = u;
+            }
+            bound[(size_t)n] = (uint8_t)(ub > 255 ? 255 : ub);
+        }
         if (is_root[(size_t)n]) {             // a search starts here with no history (chromosome start, critical point)
             clean[(size_t)n] = INF;
             out[n] = f | GKI_NODE_T;
@@ -378,6 +391,7 @@ int gki_classify_nodes(int64_t n_nodes, const int32_t *node_size, const int64_t 
         if (f & (GKI_NODE_NESTED | GKI_NODE_CHECK | GKI_NODE_HFS | GKI_NODE_FORCED)) gen = true;
     }
     if (too_deep) return gki_set_error(GKI_ERR_WINDOW_TOO_DEEP, "classify: a history crosses more than 4096 nodes");
+    for (int64_t n = 0; n < n_nodes; n++) out16[n] = (uint16_t)(out[n] | ((uint16_t)bound[(size_t)n] << 8));
     *general = gen ? 1 : 0;
     return GKI_OK;
 }

@@ -461,6 +461,87 @@ def synthetic_indel_graph(n_ref_bases, n_sites, k=31, seed=1234, p_del=0.1, p_in
                        first_node=0, chromosome_start_nodes=[0], node_to_ref_offset=ntro)
 
 
+def synthetic_nested_graph(n_ref_bases, n_sites, k=31, seed=1234, p_nest=0.2, max_node_len=32767, max_sites_per_window=2):
+    """BASELINE config 3 with variants INSIDE alternative alleles: like `synthetic_snp_graph`, but a fraction `p_nest`
+    of the sites are an insertion-like allele that itself contains a SNP: the alternative allele is the chain
+    Z1 (1-4 bases) -> {za | zb} (one base each) -> Z2 (1-4 bases), all four nodes non-linear-ref, so za, zb and Z2 have
+    no linear-ref predecessor and Z1, za, zb do not have exactly one linear-ref successor (what
+    `gki_classify_nodes` calls NESTED / CHECK).  Node ids are topological: segment chunks, ref allele, then the alt
+    allele's node(s), next segment ...; successor order [ref allele, alt entry].  At most `max_sites_per_window`
+    sites per k bases, so that a window holds at most 3 * max_sites_per_window variant nodes."""
+    sites = synthetic_snp_sites(n_ref_bases, n_sites, k, seed, max_sites_per_window=max_sites_per_window)
+    S = len(sites)
+    rng = np.random.default_rng([seed, 17])
+    nested = rng.random(S) < p_nest
+    seg_lo = np.concatenate([[0], sites + 1])
+    seg_hi = np.concatenate([sites, [n_ref_bases]])
+    seg_len = seg_hi - seg_lo
+    assert np.all(seg_len >= 1)
+    n_chunks = np.maximum(1, -(-seg_len // max_node_len))
+    if np.any(n_chunks > 1):
+        assert np.all(seg_len[n_chunks > 1] // n_chunks[n_chunks > 1] > k + 1)
+    site_nodes = np.where(nested, 5, 2).astype(np.int64)           # ref allele + (alt | Z1, za, zb, Z2)
+    total_seg_nodes = int(n_chunks.sum())
+    n_nodes = total_seg_nodes + int(site_nodes.sum())
+    node_size = np.ones(n_nodes, dtype=np.int32)
+    is_ref = np.ones(n_nodes, dtype=np.uint8)
+    af = np.ones(n_nodes, dtype=np.float64)
+    seg_first = np.zeros(S + 1, dtype=np.int64)
+    seg_first[1:] = np.cumsum(n_chunks[:-1] + site_nodes)
+    chunk_seg = np.repeat(np.arange(S + 1), n_chunks)
+    chunk_idx = np.arange(total_seg_nodes) - np.repeat(np.cumsum(n_chunks) - n_chunks, n_chunks)
+    base = seg_len[chunk_seg] // n_chunks[chunk_seg]
+    rem = seg_len[chunk_seg] - base * n_chunks[chunk_seg]
+    chunk_node = seg_first[chunk_seg] + chunk_idx
+    node_size[chunk_node] = base + (chunk_idx < rem)
+    ref_allele = seg_first[:-1] + n_chunks[:-1]
+    alt_in = ref_allele + 1
+    z1 = alt_in[nested]
+    za, zb, z2 = z1 + 1, z1 + 2, z1 + 3
+    node_size[z1] = rng.integers(1, 5, size=len(z1))
+    node_size[z2] = rng.integers(1, 5, size=len(z1))
+    for arr in (alt_in, za, zb, z2):
+        is_ref[arr] = 0
+    f = rng.uniform(0.01, 0.99, size=S)
+    af[ref_allele] = f
+    af[alt_in] = 1.0 - f
+    af[za] = af[zb] = af[z2] = 1.0 - f[nested]
+    # sequence in node order, drawn as one stream (the reference is what the linear nodes spell); a SNP's alt base
+    # differs from the ref allele's base right before it, zb's base from za's
+    seq_start = np.zeros(n_nodes + 1, dtype=np.int64)
+    np.cumsum(node_size, out=seq_start[1:])
+    seq = random_codes(int(seq_start[-1]), seed)
+    snp_alt = alt_in[~nested]
+    seq[seq_start[snp_alt]] = (seq[seq_start[snp_alt] - 1] + 1 + rng.integers(0, 3, size=len(snp_alt), dtype=np.uint8)) % 4
+    seq[seq_start[zb]] = (seq[seq_start[za]] + 1 + rng.integers(0, 3, size=len(zb), dtype=np.uint8)) % 4
+    lin = np.nonzero(is_ref)[0]
+    # edges
+    out_deg = np.ones(n_nodes, dtype=np.int64)
+    last_chunk = seg_first + n_chunks - 1
+    out_deg[last_chunk[:-1]] = 2
+    out_deg[last_chunk[-1]] = 0
+    out_deg[z1] = 2
+    edge_start = np.zeros(n_nodes + 1, dtype=np.int64)
+    np.cumsum(out_deg, out=edge_start[1:])
+    edges = np.zeros(int(edge_start[-1]), dtype=np.int32)
+    inner = np.ones(total_seg_nodes, dtype=bool)
+    inner[np.cumsum(n_chunks) - 1] = False
+    edges[edge_start[chunk_node[inner]]] = chunk_node[inner] + 1
+    edges[edge_start[last_chunk[:-1]]] = ref_allele
+    edges[edge_start[last_chunk[:-1]] + 1] = alt_in
+    edges[edge_start[ref_allele]] = seg_first[1:]
+    edges[edge_start[snp_alt]] = seg_first[1:][~nested]
+    edges[edge_start[z1]] = za
+    edges[edge_start[z1] + 1] = zb
+    edges[edge_start[za]] = z2
+    edges[edge_start[zb]] = z2
+    edges[edge_start[z2]] = seg_first[1:][nested]
+    ntro = np.zeros(n_nodes + 1, dtype=np.int64)
+    ntro[lin] = np.concatenate([[0], np.cumsum(node_size[lin])[:-1]])
+    return GraphArrays(node_size, seq, edge_start, edges, is_ref, af,
+                       first_node=0, chromosome_start_nodes=[0], node_to_ref_offset=ntro)
+
+
 def synthetic_haplotype_sequence(graph, seed=99):
     """Base codes along one random path of a `synthetic_snp_graph`: at every SNP bubble the ref or the alt allele
     with probability 1/2 (read simulation for the lookup benchmarks)."""

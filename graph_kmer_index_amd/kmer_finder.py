@@ -46,7 +46,7 @@ def check_supported_graph(g, k):
 
 
 def classify_nodes(g, k, max_variant_nodes, only_follow_nodes=None, critical_nodes=None):
-    """(uint8[n_nodes] GKI_NODE_* flags, general) -- gki_classify_nodes (include/gki.h): which nodes the order-free
+    """(uint16[n_nodes] GKI_NODE_* flags | history bound << 8, general) -- gki_classify_nodes (include/gki.h): which nodes the order-free
     form of the variant limit (kmer_finder.py:383-417) can stop at when it looks for a history.  `general` False
     means "at most max_variant_nodes variant nodes in the window" is the whole rule for this graph and the kernels run
     without the flags.  Host pass in topological order; kept on the graph object per (k, limit, follow set)."""
@@ -65,7 +65,7 @@ def classify_nodes(g, k, max_variant_nodes, only_follow_nodes=None, critical_nod
         # kmer_finder.py:190-232)
         roots = np.ascontiguousarray(np.concatenate([np.asarray(list(g.chromosome_start_nodes.values()) + [g.first_node],
                                                                 dtype=np.int32), crit]))
-        flags = np.zeros(g.n_nodes, dtype=np.uint8)
+        flags = np.zeros(g.n_nodes, dtype=np.uint16)
         general = C.c_int32(0)
         _lib.check(_lib.load().gki_classify_nodes(
             g.n_nodes, _lib.hptr(g.node_size), _lib.hptr(g.edge_start), _lib.hptr(g.edges), _lib.hptr(g.rev_start),

@@ -137,7 +137,9 @@ int gki_critical_paths(int64_t n_nodes, const int32_t *h_node_size,
  * streams, which is what the writes like best; meant for consumers that sort anyway (the index build). */
 #define GKI_LAYOUT_BY_NODE 0
 #define GKI_LAYOUT_SPLIT 1
-/* Per-node flag byte of gki_find_params.h_node_flags, computed by gki_classify_nodes (host).  The search of
+/* Per-node flag word (uint16: GKI_NODE_* byte | history bound << 8) of gki_find_params.h_node_flags, computed by
+ * gki_classify_nodes (host).  History bound: an upper bound (saturating at 255) on the distinct non-linear-ref nodes any
+ * backward path holds in the k bases before the node -- when window + bound stay under the limit, any history will do.  The search of
  * kmer_finder.py:383-417 reaches a window iff SOME history satisfied the variant limit at every step into a node whose
  * entry is not free (free: linear-ref(-dummy) node, or a forced `only_follow_nodes` successor :386-388).  Walking
  * backwards, a history need not be enumerated past a node with GKI_NODE_T: a linear-ref node reachable through >= k
@@ -155,13 +157,13 @@ int gki_critical_paths(int64_t n_nodes, const int32_t *h_node_size,
 /* Host, one pass in topological order, O(nodes + edges) plus a backward enumeration for every non-free NESTED node.
  * h_follow: uint8[n_nodes] membership of only_follow_nodes or NULL; h_roots: the nodes a search starts from with no
  * history -- chromosome starts and every critical node (kmer_finder.py:190-232: each critical point starts its own search).
- * h_out_flags uint8[n_nodes].  *general = 1 if any node is NESTED / CHECK / HFS / FORCED or cut off, i.e.
+ * h_out_flags uint16[n_nodes].  *general = 1 if any node is NESTED / CHECK / HFS / FORCED or cut off, i.e.
  * gki_finder_count needs the flags; 0 = the graph is in the class where "at most max_variant_nodes variant nodes in
  * the window" is the whole rule and h_node_flags may stay NULL.  GKI_ERR_BAD_ARG if the graph has a cycle. */
 int gki_classify_nodes(int64_t n_nodes, const int32_t *h_node_size, const int64_t *h_edge_start, const int32_t *h_edges,
                        const int64_t *h_rev_start, const int32_t *h_rev_edges, const uint8_t *h_is_ref,
                        const uint8_t *h_follow, const int32_t *h_roots, int n_roots, int k, int max_variant_nodes,
-                       uint8_t *h_out_flags, int32_t *general);
+                       uint16_t *h_out_flags, int32_t *general);
 
 typedef struct {
     uint32_t struct_size;         /* sizeof(gki_find_params): a binding built against another layout is refused */
@@ -181,8 +183,8 @@ typedef struct {
      * whose rank lies between the ranks of node_begin and node_end (node_end == n_nodes: to the end); costs a pass
      * over all nodes instead of over the run's. */
     const int32_t *h_node_rank;
-    /* host uint8[n_nodes] from gki_classify_nodes, or NULL when it reported general == 0. */
-    const uint8_t *h_node_flags;
+    /* host uint16[n_nodes] from gki_classify_nodes, or NULL when it reported general == 0. */
+    const uint16_t *h_node_flags;
     /* host uint8[n_nodes] membership of only_store_nodes (kmer_finder.py:153) or NULL: a record is written only for a
      * node in the set -- except the records of the bulk path (offsets k+2 .. size-2 of a node longer than 2k+3), which
      * the reference writes regardless (:370-374).  Needs h_node_flags (the general kernels apply it). */

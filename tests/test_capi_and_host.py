@@ -168,6 +168,7 @@ def test_supported_graph_checks():
     check_supported_graph(g, 4)
     flags, general = classify_nodes(g, 4, 4)
     assert general and flags[3] & 16 and flags[2] & 8 and all(flags[n] & 4 for n in (0, 1, 4))
+    assert flags.dtype == np.uint16 and (flags[4] >> 8) == 2            # up to two variant nodes (2, 3) right before node 4
     check_supported_graph(synthetic_snp_graph(20000, 300, k=31, seed=3), 31)
     assert not classify_nodes(synthetic_snp_graph(20000, 300, k=31, seed=3), 31, 4)[1]
     two = GraphArrays.from_dicts({0: "ACGTACGT", 1: "AC", 2: "GGGG"}, {1: [2]}, [0, 1, 2])

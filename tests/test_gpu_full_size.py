@@ -12,7 +12,8 @@ import numpy as np
 import pytest
 
 from graph_kmer_index_amd import CriticalGraphPaths, DenseKmerFinder
-from graph_kmer_index_amd.graph import synthetic_indel_graph, synthetic_linear_graph, synthetic_snp_graph
+from graph_kmer_index_amd.graph import (synthetic_indel_graph, synthetic_linear_graph, synthetic_nested_graph,
+                                        synthetic_snp_graph)
 from graph_kmer_index_amd.sharding import critical_path_cuts
 from gpu_util import assert_same_records, finder_cols
 from oracle import oracle
@@ -37,15 +38,23 @@ def test_config1_linear_10mbp_equals_oracle_record_by_record():
     assert_same_records(got, exp, exact_order=True)
 
 
-@pytest.mark.parametrize("kind", ["snp", "snp_indel"])
+@pytest.mark.parametrize("kind", ["snp", "snp_indel", "nested"])
 def test_config2_full_size_properties(kind):
     # "snp_indel": 10 % of the sites 1-bp deletions (empty alt node), 10 % insertions (empty ref-dummy node)
+    # "nested": 20 % of the sites an alternative allele that contains a SNP itself (four non-linear nodes, three of them
+    #   without a linear-ref predecessor): the GENERAL kernels with gki_classify_nodes' flags, at full size
+    M = 5
     if kind == "snp":
         g = synthetic_snp_graph(3_000_000_000, 5_000_000, k=K, seed=1234)
-    else:
+    elif kind == "snp_indel":
         g = synthetic_indel_graph(3_000_000_000, 5_000_000, k=K, seed=1234, p_del=0.1, p_ins=0.1)
+    else:
+        g = synthetic_nested_graph(3_000_000_000, 5_000_000, k=K, seed=1234, p_nest=0.2)
+        M = 8                # <= 2 sites per k bases, <= 3 variant nodes each: the reference's assertion never fires
+        from graph_kmer_index_amd.kmer_finder import classify_nodes
+        assert classify_nodes(g, K, M)[1]
     cp = CriticalGraphPaths.from_graph(g, K)
-    kw = dict(critical_graph_paths=cp, only_save_one_node_per_kmer=True, max_variant_nodes=5)
+    kw = dict(critical_graph_paths=cp, only_save_one_node_per_kmer=True, max_variant_nodes=M)
 
     # the whole graph, split layout
     full = DenseKmerFinder(g, K, **kw)
@@ -107,7 +116,7 @@ def test_config2_full_size_properties(kind):
         a = int(a)
         f = DenseKmerFinder(g, K, start_at_critical_path_number=a, stop_at_critical_path_number=a + 1500, **kw)
         f.find()
-        exp = oracle.find(g, K, crit, True, 5, start_at_critical_path_number=a, stop_at_critical_path_number=a + 1500)
+        exp = oracle.find(g, K, crit, True, M, start_at_critical_path_number=a, stop_at_critical_path_number=a + 1500)
         assert len(exp["kmers"]) > 500_000
         assert_same_records(finder_cols(f), exp)
         f.close()
