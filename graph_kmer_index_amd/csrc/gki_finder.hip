@@ -410,7 +410,12 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
                         int from = k - 1 - c - s; if (from < w_lo) from = w_lo;
                         int to = k - 1 - c; if (to > hi) to = hi;
                         const int cq = HAS_LOSSY ? lossy_of(lossy, q) : -1;
-                        if (HAS_LOSSY && cq >= 0) { const int min_ok = k - 1 - c - s + cq; if (from < min_ok) from = min_ok; }
+                        if (HAS_LOSSY && cq >= 0) {
+                            const int min_ok = k - 1 - c - s + cq; if (from < min_ok) from = min_ok;
+                            // the search restarted at (q, cq) with no history: at an end position whose window would
+                            // reach before that point it holds the shorter window, which still decides :402
+                            if (GEN && chk && oc >= w_lo && oc < min_ok && vq >= a.M) *err = GKI_ERR_NOT_ONE_REF_SUCC;
+                        }
                         if (GEN && from < to) {
                             bool ok = true;                          // a history before the window's first node?
                             if (!(fq & (GKI_NODE_T | GKI_NODE_SIMPLE)))

@@ -90,9 +90,11 @@ def overlapping_bubble_graph(rng, n_var=4, min_ref=2, max_ref=8):
     return seqs, edges, linear, None
 
 
-def nested_bubble_graph(rng, n_var=4, min_ref=2, max_ref=10, p_nest=0.6):
+def nested_bubble_graph(rng, n_var=4, min_ref=2, max_ref=10, p_nest=0.6, p_chain=0.0):
     """Bubbles whose alt allele may itself contain a bubble (a variant inside an insertion):
-    R -> {ref allele | Z1 -> {za | zb} -> Z2} -> R'.  Nodes inside the alt allele have no linear-ref predecessor."""
+    R -> {ref allele | Z1 -> {za | zb} -> Z2} -> R'.  Nodes inside the alt allele have no linear-ref predecessor.
+    p_chain: probability that a ref segment is split into a single-edge chain of two nodes (critical points with a
+    lossy restart right behind a nested bubble)."""
     seqs, edges, linear = {}, {}, []
     nid = 0
 
@@ -123,6 +125,9 @@ def nested_bubble_graph(rng, n_var=4, min_ref=2, max_ref=10, p_nest=0.6):
         edges[ref_a] = [head]
         edges[alt_out] = [head]
         tail = head
+        if p_chain and rng.random() < p_chain:
+            tail = add(_rand_seq(rng, int(rng.integers(min_ref, max_ref + 1))), True)
+            edges[head] = [tail]
     return seqs, edges, linear, None
 
 

@@ -214,7 +214,11 @@ def spec_rows_general(g, k, max_variant_nodes=4, one_node=False, critical=None, 
             bases_rev = bases_rev + [int(g.seq[g.seq_start[node] + off])]
             need -= 1
             if need > 0 and c is not None and 0 < c < k - 1 and off == c:
-                return                       # E1: a window never spans (N, c-1), (N, c)
+                # E1: a window never spans (N, c-1), (N, c) -- the search restarted at (N, c) with no history, so what it
+                # holds at the end position is this shorter window (it still decides the assertion of :402)
+                if on_partial is not None:
+                    on_partial(path)
+                return
             off -= 1
         if need == 0:
             on_complete(path, bases_rev)

@@ -307,3 +307,17 @@ def test_early_stop_search_on_nested_graphs_incl_assertion():
             assert_same_records(finder_cols(f), exp, exact_order=True)
             n_ok += 1
     assert n_ok > 60 and n_assert > 5
+
+
+def test_assertion_after_a_lossy_restart():
+    """A single-edge chain right behind a nested bubble gives a critical point (N, c) with 0 < c < k-1: the search
+    restarts there without history (SURVEY.md 8a' E1), so at the nodes that follow it holds a window shorter than k --
+    and the assertion of kmer_finder.py:402 is decided on that shorter window (found by the soak)."""
+    rng = np.random.default_rng(54)
+    seen = {"ok": 0, "assert": 0, "skip": 0}
+    for _ in range(150):
+        seqs, edges, lin, af = nested_bubble_graph(rng, n_var=int(rng.integers(2, 7)), min_ref=1, max_ref=int(rng.integers(2, 14)),
+                                                   p_nest=0.6, p_chain=0.5)
+        g = GraphArrays.from_dicts(seqs, edges, lin, af)
+        seen[run_case(g, int(rng.integers(3, 24)), int(rng.choice([1, 2, 3, 4])), bool(rng.integers(0, 2)))] += 1
+    assert seen["ok"] > 30 and seen["assert"] > 30, seen

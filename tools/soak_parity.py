@@ -28,7 +28,7 @@ def make_graph(rng, k):
     mode = rng.choice(["bubble", "overlap", "chain", "indel", "nested", "deep"])
     if mode == "nested":               # a variant inside an alternative allele: nodes with no linear-ref predecessor
         seqs, edges, lin, af = nested_bubble_graph(rng, n_var=int(rng.integers(2, 12)), min_ref=1, max_ref=int(rng.integers(2, 2 * k + 3)),
-                                                   p_nest=float(rng.choice([0.3, 0.7])))
+                                                   p_nest=float(rng.choice([0.3, 0.7])), p_chain=float(rng.choice([0.0, 0.4])))
         return mode, GraphArrays.from_dicts(seqs, edges, lin, af)
     if mode == "deep":
         seqs, edges, lin, af = deep_nested_graph(rng, n_var=int(rng.integers(1, 8)), max_depth=int(rng.integers(1, 4)), min_ref=1,
