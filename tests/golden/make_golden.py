@@ -171,6 +171,14 @@ def nested_cases():
         cand = [n for n in seqs if not g.is_linear_ref_node_or_linear_ref_dummy_node(n)]
         follow = [int(x) for x in rng.choice(cand, size=max(1, len(cand) // 3), replace=False)]
         add("follow_%d" % i, seqs, edges, lin, 3 + i % 5, [1, 2, 100][i % 3], bool(i % 2), follow)
+    # single-edge chains behind nested bubbles: critical points with a lossy restart (SURVEY.md 8a' E1) next to nodes
+    # that carry the assertion
+    for i in range(16):
+        seqs, edges, lin, _ = nested_bubble_graph(rng, n_var=int(rng.integers(2, 6)), min_ref=1, max_ref=12, p_nest=0.6, p_chain=0.5)
+        try:
+            add("nested_chain_%d" % i, seqs, edges, lin, 4 + i % 10, [1, 2, 3, 4][i % 4], bool(i % 2))
+        except OverflowError:
+            pass                                      # reference crash E2 (critical offset -1)
     return cases
 
 

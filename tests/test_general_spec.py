@@ -44,7 +44,7 @@ def spec(g, k, M, one, critd, follow=None):
 def test_oracle_and_spec_match_reference_on_nested_fixtures():
     with open(os.path.join(GOLD, "finder_nested.json")) as fh:
         cases = json.load(fh)
-    assert len(cases) >= 40 and {c["M"] for c in cases} == {0, 1, 2, 3, 4, 100} and {c["k"] for c in cases} == {3, 4, 5, 6, 7}
+    assert len(cases) >= 40 and {c["M"] for c in cases} == {0, 1, 2, 3, 4, 100} and {c["k"] for c in cases} >= {3, 4, 5, 6, 7}
     for case in cases:
         g = GraphArrays.from_dicts({int(a): b for a, b in case["seqs"].items()},
                                    {int(a): b for a, b in case["edges"].items()}, case["linear"])

@@ -115,7 +115,7 @@ def test_indel_generator_graphs_match_reference():
         assert np.array_equal(o["allele_frequencies"], fl._allele_frequencies)
 
 
-@pytest.mark.parametrize("mode,n,seed", [("nested", 80, 5), ("deep", 80, 6), ("follow", 60, 7)])
+@pytest.mark.parametrize("mode,n,seed", [("nested", 80, 5), ("deep", 80, 6), ("follow", 60, 7), ("nested_chain", 120, 8)])
 def test_nested_graphs_oracle_and_general_spec_match_reference(mode, n, seed):
     """Graphs with nodes that have no linear-ref predecessor, and find() with only_follow_nodes (kmer_finder.py:386-388):
     the reference itself, the oracle (exact order) and the order-free general rule the kernels implement
@@ -128,7 +128,12 @@ def test_nested_graphs_oracle_and_general_spec_match_reference(mode, n, seed):
         k = int(rng.integers(3, 8))
         M = int(rng.choice([0, 1, 2, 3, 4, 100]))
         one = bool(rng.integers(0, 2))
-        if mode == "deep":
+        if mode == "nested_chain":           # single-edge chains behind nested bubbles: lossy restarts (E1) next to them
+            k = int(rng.integers(3, 16))
+            M = int(rng.choice([1, 2, 3, 4]))
+            seqs, edges, lin, af = nested_bubble_graph(rng, n_var=int(rng.integers(2, 6)), min_ref=1, max_ref=12, p_nest=0.6,
+                                                       p_chain=0.5)
+        elif mode == "deep":
             seqs, edges, lin, af = deep_nested_graph(rng, n_var=int(rng.integers(1, 4)), max_depth=int(rng.integers(1, 4)))
         elif mode == "nested" or it % 2:
             seqs, edges, lin, af = nested_bubble_graph(rng, n_var=int(rng.integers(2, 5)), p_nest=0.7)
