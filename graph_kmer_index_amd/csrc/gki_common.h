@@ -104,6 +104,7 @@ __device__ __forceinline__ uint64_t node_tail(const NodeWalk &w, int t) {
 
 struct gki_graph {
     DevGraph d;
+    int64_t *h_seq_start;                    // host copy of d.seq_start [n_nodes+1] (chunk bounds without a device read)
     hipStream_t stream;
     int device;
     void *owned[24];

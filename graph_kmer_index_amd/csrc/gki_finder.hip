@@ -1251,9 +1251,9 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
     int64_t p0 = 0, p1 = d.n_bases;
     if (!a.rank && (a.node_begin > 0 || a.node_end < d.n_nodes)) {
         int64_t nb = a.node_begin < d.n_nodes ? a.node_begin : d.n_nodes;
-        HIP_TRY(hipMemcpy(&p0, d.seq_start + nb, 8, hipMemcpyDeviceToHost));
+        p0 = f->g->h_seq_start[nb];
         if (a.node_end < d.n_nodes) {
-            HIP_TRY(hipMemcpy(&p1, d.seq_start + a.node_end, 8, hipMemcpyDeviceToHost));
+            p1 = f->g->h_seq_start[a.node_end];
             p1 += a.off_end;                        // (node_end, off_end) is exclusive
             if (p1 > d.n_bases) p1 = d.n_bases;
         }

@@ -2,6 +2,7 @@
 // node-start bitmap + rank that turns "which node owns base p" into a popcount.
 #include "gki_common.h"
 #include <vector>
+#include <stdlib.h>
 #include <limits.h>
 
 namespace {
@@ -115,6 +116,9 @@ int graph_create_common(gki_graph **out, int64_t n_nodes, const int32_t *h_node_
     if (seq_start[n_nodes] != n_bases) { delete g; return gki_set_error(GKI_ERR_BAD_ARG, "sum(node_size) != n_bases"); }
     d.n_nonempty = (int64_t)nonempty.size();
 
+    g->h_seq_start = (int64_t *)malloc((size_t)(n_nodes + 1) * 8);
+    if (!g->h_seq_start) { delete g; return gki_set_error(GKI_ERR_HIP, "graph_create: out of host memory"); }
+    memcpy(g->h_seq_start, seq_start.data(), (size_t)(n_nodes + 1) * 8);
     GKI_TRY(upload(g, h_node_size, n_nodes, &d.node_size));
     GKI_TRY(upload(g, seq_start.data(), n_nodes + 1, &d.seq_start));
     GKI_TRY(upload(g, h_edge_start, n_nodes + 1, &d.edge_start));
@@ -208,6 +212,7 @@ int gki_graph_destroy(gki_graph *g) {
     (void)hipEventDestroy(g->ev_prep0);
     (void)hipEventDestroy(g->ev_prep1);
     (void)hipStreamDestroy(g->stream);
+    free(g->h_seq_start);
     delete g;
     return GKI_OK;
 }
