@@ -271,7 +271,10 @@ __device__ __noinline__ bool history_ok(const DevGraph &g, const WalkCache &wc, 
         preds_begin(g, wq, path[L], &hcur[0], &hend[0]);
     }
     int h = 0;
-    for (;;) {
+    for (int budget = 1 << 16;; budget--) {
+        // every lane's enumeration ends: a graph with more than 65 536 history steps behind one window is refused
+        // (GKI_ERR_WINDOW_TOO_DEEP) rather than walked for minutes
+        if (budget == 0) { *err = GKI_ERR_WINDOW_TOO_DEEP; return false; }
         if (hcur[h] >= hend[h]) { if (h == 0) return false; h--; continue; }
         const int32_t p = cached_preds_next(g, wc, wv, &hcur[h]);
         const uint8_t fp = (uint8_t)cached_flag(nf, wc, wv, p);

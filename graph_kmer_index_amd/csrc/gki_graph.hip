@@ -252,7 +252,8 @@ bool host_node_has_history(const int32_t *node_size, const int64_t *rev_start, c
     std::vector<uint8_t> hf;
     hcur.push_back(rev_start[n]); hend.push_back(rev_start[n + 1]);
     size_t h = 0;                                      // nodes of the current history = h (slot h is being filled)
-    for (;;) {
+    for (int64_t budget = (int64_t)1 << 24;; budget--) {
+        if (budget == 0) { *too_deep = 1; return false; }        // refuse rather than enumerate for minutes
         if (hcur[h] >= hend[h]) {
             if (h == 0) return false;
             hcur.pop_back(); hend.pop_back(); hn.pop_back(); hd.pop_back(); hsz.pop_back(); hf.pop_back();
@@ -395,7 +396,8 @@ int gki_classify_nodes(int64_t n_nodes, const int32_t *node_size, const int64_t 
         }
         if (f & (GKI_NODE_NESTED | GKI_NODE_CHECK | GKI_NODE_HFS | GKI_NODE_FORCED)) gen = true;
     }
-    if (too_deep) return gki_set_error(GKI_ERR_WINDOW_TOO_DEEP, "classify: a history crosses more than 4096 nodes");
+    if (too_deep) return gki_set_error(GKI_ERR_WINDOW_TOO_DEEP, "classify: the histories behind one node cross more than 4096 "
+                                       "nodes or take more than 2^24 steps to enumerate");
     for (int64_t n = 0; n < n_nodes; n++) out16[n] = (uint16_t)(out[n] | ((uint16_t)bound[(size_t)n] << 8));
     *general = gen ? 1 : 0;
     return GKI_OK;

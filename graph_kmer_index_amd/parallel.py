@@ -83,10 +83,24 @@ class SocketControlPlane(_GatherControlPlane):
         self._peers, self._sock, self._server = [], None, None
         if self.world == 1:
             return
+        # Rank 0 takes the first free port of port .. port+15 and greets every connection with a magic word; the others
+        # try those ports in turn until one answers with it (another service may own a port of the range).
+        magic = b"GKI1" + struct.pack("<q", self.world)
+        ports = range(port, port + 16)
         if self.rank == 0:
-            self._server = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            self._server.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            self._server.bind((addr, port))
+            last = None
+            for cand in ports:
+                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                try:
+                    srv.bind((addr, cand))
+                    self._server = srv
+                    break
+                except OSError as e:
+                    last = e
+                    srv.close()
+            if self._server is None:
+                raise last
             self._server.listen(self.world)
             self._server.settimeout(timeout)
             peers = {}
@@ -94,19 +108,28 @@ class SocketControlPlane(_GatherControlPlane):
                 conn, _ = self._server.accept()
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 conn.settimeout(timeout)
+                conn.sendall(magic)
                 peers[struct.unpack("<q", _recv_exact(conn, 8))[0]] = conn
             self._peers = [peers[r] for r in range(1, self.world)]
         else:
             import time
             deadline = time.time() + timeout
-            while True:
-                try:
-                    self._sock = socket.create_connection((addr, port), timeout=timeout)
-                    break
-                except OSError:
+            while self._sock is None:
+                for cand in ports:
+                    try:
+                        sock = socket.create_connection((addr, cand), timeout=2.0)
+                        sock.settimeout(2.0)
+                        if _recv_exact(sock, len(magic)) == magic:
+                            self._sock = sock
+                            break
+                        sock.close()
+                    except (OSError, ConnectionError):
+                        pass
+                if self._sock is None:
                     if time.time() > deadline:
-                        raise
+                        raise TimeoutError("control plane: rank 0 did not answer on %s:%d..%d" % (addr, port, port + 15))
                     time.sleep(0.05)
+            self._sock.settimeout(timeout)
             self._sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             self._sock.sendall(struct.pack("<q", self.rank))
 

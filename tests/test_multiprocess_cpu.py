@@ -136,7 +136,12 @@ def _socket_worker(rank, world, port, tmpdir):
 @pytest.mark.parametrize("world", [2, 3])
 def test_socket_control_plane_ranks(tmp_path, world):
     import multiprocessing
-    port = 31000 + os.getpid() % 2000 + world
+    import socket
+    port = 31000 + os.getpid() % 2000 + 20 * world
+    # the first port of the range belongs to somebody else: rank 0 moves on, the others find it by its greeting
+    squatter = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    squatter.bind(("127.0.0.1", port))
+    squatter.listen(8)
     ctx = multiprocessing.get_context("spawn")
     procs = [ctx.Process(target=_socket_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
     for p in procs:
@@ -144,6 +149,7 @@ def test_socket_control_plane_ranks(tmp_path, world):
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
+    squatter.close()
     parts = [np.load(str(tmp_path / ("r%d.npz" % r))) for r in range(world)]
     g = synthetic_snp_graph(60000, 700, k=31, seed=21)
     n_full = len(oracle.find(g, 31, None, True, 5)["kmers"])
