@@ -294,3 +294,37 @@ def test_loopback_ranks_build_the_oracle_index(world):
         assert np.array_equal(out["read_counts"], want_counts)
         base += n
     assert base == len(everything[0])
+
+
+def test_bench_line_has_the_contract_fields(tmp_path):
+    """bench.py end to end at a small size: one JSON line with the driver's fields, the roofline and CPU-baseline objects
+    and the two secondary records; a second run as two ranks (on this one GPU) over the socket control plane."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    small = ["--bases", "2e7", "--sites", "3e4", "--steps", "2", "--warmup", "1", "--cpu-sample-bases", "2e6", "--cpu-cores", "2"]
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--reads", "2e4"] + small, capture_output=True,
+                         text=True, timeout=600, check=True).stdout.strip().splitlines()
+    assert len(out) == 1
+    d = json.loads(out[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "timed_region", "index_build",
+                "read_mapping"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["vs_baseline"] is None
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["bound"] == "hbm"
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 2 and d["cpu_baseline"]["value"] > 0
+    assert d["index_build"]["records"] > 0 and d["read_mapping"]["kmers"] == 2 * 20000 * 120
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline"] + small,
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    lines = [o[0].strip() for o in outs]
+    assert lines[1] == "" and lines[0].count("\\n") == 0                 # rank 0 alone prints the line
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["config"]["records_per_step"] == d["config"]["records_per_step"]
