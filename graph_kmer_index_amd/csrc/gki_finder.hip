@@ -1205,14 +1205,18 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
 
     HIP_TRY(hipEventRecord(f->ev[0], s));
     if (n_run > 0) {
+        // one group of 256 nodes per workgroup, no grid-stride loop: with 2048 workgroups of 29 groups each (7 fit a CU,
+        // an eighth waits) the pass took 0.70 ms, with one group each 0.59 (GKI_CNT_BLOCKS sweeps it in tuning builds)
+        const int64_t want = ceil_div(n_run, 256), cap = GKI_KNOB("GKI_CNT_BLOCKS", 1 << 30);
+        const int count_grid = (int)(want < cap ? want : cap);
         if (a.nflags)
-            hipLaunchKernelGGL((k_count_boundary<true, true>), dim3(stream_grid(n_run, 256)), dim3(256), 0, s, d, a, f->lossy,
+            hipLaunchKernelGGL((k_count_boundary<true, true>), dim3(count_grid), dim3(256), 0, s, d, a, f->lossy,
                                f->bcount, f->total, f->d_err);
         else if (a.has_lossy)
-            hipLaunchKernelGGL((k_count_boundary<true, false>), dim3(stream_grid(n_run, 256)), dim3(256), 0, s, d, a, f->lossy,
+            hipLaunchKernelGGL((k_count_boundary<true, false>), dim3(count_grid), dim3(256), 0, s, d, a, f->lossy,
                                f->bcount, f->total, f->d_err);
         else
-            hipLaunchKernelGGL((k_count_boundary<false, false>), dim3(stream_grid(n_run, 256)), dim3(256), 0, s, d, a, f->lossy,
+            hipLaunchKernelGGL((k_count_boundary<false, false>), dim3(count_grid), dim3(256), 0, s, d, a, f->lossy,
                                f->bcount, f->total, f->d_err);
         HIP_TRY(hipGetLastError());
     }
