@@ -969,6 +969,7 @@ struct gki_finder {
     uint16_t *nflags; uint8_t *store; // general graphs / only_store_nodes (gki_find_params), allocated on first use
     void *scan_tmp; int64_t scan_tmp_bytes;
     int *d_err; int64_t *d_totals; unsigned long long *d_bsum;
+    int64_t *h_totals;                // pinned: {total, error, boundary records, 0, boundary sum} read back by every count
     int32_t *d_rank;                  // topological ranks of the run in progress (non-topological node ids only)
     FindArgs args;
     int64_t n_records, n_boundary_records, n_interior_records;
@@ -1132,6 +1133,7 @@ int gki_finder_create(gki_graph *g, gki_finder **out) {
     HIP_TRY(gki_dev_malloc((void **)&f->d_totals, 4 * 8));
     HIP_TRY(hipMemset(f->d_totals, 0, 4 * 8));
     HIP_TRY(gki_dev_malloc((void **)&f->d_bsum, 8));
+    HIP_TRY(hipHostMalloc((void **)&f->h_totals, 5 * 8, hipHostMallocDefault));
     f->scan_tmp_bytes = gki_scan_tmp_bytes(n);
     HIP_TRY(gki_dev_malloc(&f->scan_tmp, (size_t)f->scan_tmp_bytes));
     *out = f;
@@ -1145,6 +1147,7 @@ int gki_finder_destroy(gki_finder *f) {
     void *ptrs[] = {f->bcount, f->total, f->rec_base, f->bnd_base, f->ne, f->lossy, f->scan_tmp, f->d_err, f->d_totals, f->d_bsum,
                     f->d_rank, f->nflags, f->store};
     for (void *p : ptrs) if (p) (void)gki_dev_free(p);
+    if (f->h_totals) (void)hipHostFree(f->h_totals);
     for (int i = 0; i < 8; i++) (void)hipEventDestroy(f->ev[i]);
     (void)hipEventDestroy(f->ev_ready);
     (void)hipEventDestroy(f->ev_join);
@@ -1240,11 +1243,11 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
     hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, s, f->rec_base, f->bnd_base, a.n1, a.split, f->d_err, f->d_totals);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(f->ev[7], s));
-    int64_t tot[4];
-    unsigned long long bsum = 0;
+    int64_t *tot = f->h_totals;                       // pinned host memory: the two small copies are true async DMAs
     HIP_TRY(hipMemcpyAsync(tot, f->d_totals, 32, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&bsum, f->d_bsum, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(tot + 4, f->d_bsum, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    unsigned long long bsum = (unsigned long long)tot[4];
     if (tot[1] == GKI_ERR_NOT_ONE_REF_SUCC)
         return gki_set_error(GKI_ERR_NOT_ONE_REF_SUCC, "a window at the variant limit ends a node that does not have exactly one "
                              "linear-ref successor: the reference asserts here (kmer_finder.py:402); raise max_variant_nodes");
