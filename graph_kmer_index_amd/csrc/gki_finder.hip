@@ -497,7 +497,8 @@ struct EvQueue {
 };
 
 #ifdef GKI_TUNING
-__device__ int g_dbg_skip_expand = 0;     // tools/exp builds only (make tuning): 1 = phase A alone, 2 = no sort
+__device__ int g_dbg_skip_expand = 0;     // tools/exp builds only (make tuning): 1 = phase A alone, 2 = no sort,
+                                          // 3 = phase A alone and no node lists built (all-nodes mode; nothing reads them)
 #define GKI_DBG_SKIP_EXPAND_IS(v) (g_dbg_skip_expand == (v))
 #else
 #define GKI_DBG_SKIP_EXPAND_IS(v) false
@@ -513,7 +514,7 @@ __device__ int g_dbg_skip_expand = 0;     // tools/exp builds only (make tuning)
 template <int FMT, bool ALL>
 __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int my_cnt, typename OutSel<FMT>::T out, int k,
                                              uint64_t kmask, int lane) {
-    if (GKI_DBG_SKIP_EXPAND_IS(1)) return;
+    if (GKI_DBG_SKIP_EXPAND_IS(1) || GKI_DBG_SKIP_EXPAND_IS(3)) return;
     static_assert(EVQ == 128, "two steps per lane");
     {
         int ps = my_cnt;
@@ -772,6 +773,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                     if (ALL) {
                         q.nl[slot] = (uint8_t)e_nls;
                         const bool filt = GEN && a.store;
+                        if (!GKI_DBG_SKIP_EXPAND_IS(3))
                         for (int a2 = 0; a2 < e_nl; a2++) {            // rank sort: the nodes of a path are distinct
                             const int32_t v = path[a2];
                             if (filt && !a.store[v]) continue;

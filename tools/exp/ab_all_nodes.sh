@@ -6,7 +6,7 @@ R="$(pwd)"; L="$R/graph_kmer_index_amd/libgki_hip.so"
 cp "$L" /tmp/gki_new.so
 run() {  # $1 = tag
   timeout -k 10 200 python3 "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --reads 0 --all-nodes 2>/dev/null \
-   | python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); k=d['config']['kernels_ms_rank0_last_step'] if 'kernels_ms_rank0_last_step' in d.get('config',{}) else d.get('kernels_ms_rank0_last_step'); print('$1', round(d['ms_per_step'],2), {a: round(b,2) for a,b in k.items()})"
+   | python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); k=d['kernels_ms_rank0_last_step']; print('$1', round(d['ms_per_step'],2), {a: round(b,2) for a,b in k.items()})"
 }
 for i in 1 2 3; do
   cp "$R/tools/exp/_ab/libgki_base.so" "$L"; run base
