@@ -526,6 +526,24 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
         for (int b = 0; b < 2; b++) {
             const int e = b * 64 + lane;
             if (e < n_ev) q.order[(int)q.lbase[q.ln[e]] + (int)q.seq[e]] = (uint8_t)e;
+            if (ALL && e < n_ev) {
+                // the step's nodes ascending (records of a window are written per distinct node, ascending): a fixed
+                // 12-comparator network on registers, every lane the same instructions; slots >= nl count as +inf
+                static_assert(NLQ == 6, "sorting network for six");
+                const int nl = (int)q.nl[e];
+                int32_t v[NLQ];
+#pragma unroll
+                for (int t = 0; t < NLQ; t++) v[t] = t < nl ? q.nodes[e][t] : INT_MAX;
+#define GKI_CSWAP(i, j) { const int32_t lo_ = v[i] < v[j] ? v[i] : v[j], hi_ = v[i] < v[j] ? v[j] : v[i]; v[i] = lo_; v[j] = hi_; }
+                GKI_CSWAP(0, 5) GKI_CSWAP(1, 3) GKI_CSWAP(2, 4)
+                GKI_CSWAP(1, 2) GKI_CSWAP(3, 4)
+                GKI_CSWAP(0, 3) GKI_CSWAP(2, 5)
+                GKI_CSWAP(0, 1) GKI_CSWAP(2, 3) GKI_CSWAP(4, 5)
+                GKI_CSWAP(1, 2) GKI_CSWAP(3, 4)
+#undef GKI_CSWAP
+#pragma unroll
+                for (int t = 0; t < NLQ; t++) q.nodes[e][t] = v[t];
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -773,13 +791,15 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                     if (ALL) {
                         q.nl[slot] = (uint8_t)e_nls;
                         const bool filt = GEN && a.store;
-                        if (!GKI_DBG_SKIP_EXPAND_IS(3))
-                        for (int a2 = 0; a2 < e_nl; a2++) {            // rank sort: the nodes of a path are distinct
-                            const int32_t v = path[a2];
-                            if (filt && !a.store[v]) continue;
-                            int rank = 0;
-                            for (int b2 = 0; b2 < e_nl; b2++) rank += (path[b2] < v && !(filt && !a.store[path[b2]])) ? 1 : 0;
-                            q.nodes[slot][rank] = v;
+                        if (!GKI_DBG_SKIP_EXPAND_IS(3)) {
+                            // in path order; expand_queue sorts them, one lane per step (a sort here is a divergent double
+                            // loop over scratch that the whole wave executes: 2/3 of this mode's extra walk time)
+                            int j2 = 0;
+                            for (int a2 = 0; a2 < e_nl; a2++) {
+                                const int32_t v = path[a2];
+                                if (filt && !a.store[v]) continue;
+                                q.nodes[slot][j2++] = v;
+                            }
                         }
                         idx += (int64_t)(e_to - e_from) * e_nls;
                     } else
