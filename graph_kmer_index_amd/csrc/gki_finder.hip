@@ -499,6 +499,7 @@ struct EvQueue {
 #ifdef GKI_TUNING
 __device__ int g_dbg_skip_expand = 0;     // tools/exp builds only (make tuning): 1 = phase A alone, 2 = no sort,
                                           // 3 = phase A alone and no node lists built (all-nodes mode; nothing reads them)
+                                          // 4 = phase A alone and windows over more than NLQ nodes dropped (output incomplete)
 #define GKI_DBG_SKIP_EXPAND_IS(v) (g_dbg_skip_expand == (v))
 #else
 #define GKI_DBG_SKIP_EXPAND_IS(v) false
@@ -514,7 +515,7 @@ __device__ int g_dbg_skip_expand = 0;     // tools/exp builds only (make tuning)
 template <int FMT, bool ALL>
 __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int my_cnt, typename OutSel<FMT>::T out, int k,
                                              uint64_t kmask, int lane) {
-    if (GKI_DBG_SKIP_EXPAND_IS(1) || GKI_DBG_SKIP_EXPAND_IS(3)) return;
+    if (GKI_DBG_SKIP_EXPAND_IS(1) || GKI_DBG_SKIP_EXPAND_IS(3) || GKI_DBG_SKIP_EXPAND_IS(4)) return;
     static_assert(EVQ == 128, "two steps per lane");
     {
         int ps = my_cnt;
@@ -760,20 +761,51 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                 e_nls = stored_nodes(a.store, path, e_nl, !ALL);
                 if (e_nls == 0) ev = false;
             }
-            if (ALL && ev && e_nl > NLQ) {
-                // a window over more nodes than the queue carries (rows of empty or 1-bp nodes): written by the lane
-                // alone, per offset the distinct nodes ascending
-                for (int o = e_from; o < e_to; o++) {
-                    const uint64_t h = ((e_ctx >> (2 * o)) | (own << (2 * (k - 1 - o)))) & kmask;
-                    int32_t last = INT_MIN;
-                    for (int r = 0; r < e_nl; r++) {
-                        int32_t best = INT_MAX;
-                        for (int j2 = 0; j2 < e_nl; j2++) { const int32_t v = path[j2]; if (v > last && v < best) best = v; }
-                        if (!(GEN && a.store) || a.store[best]) put(out, idx++, h, best, (int32_t)n, o, pos0 + o, e_maf);
-                        last = best;
+            if (ALL && ev && e_nl > NLQ && GKI_DBG_SKIP_EXPAND_IS(4)) ev = false;
+            if (ALL) {
+                // A window over more nodes than a queued step carries (rows of empty or 1-bp nodes, SNPs a few bases
+                // apart): written by the WAVE, one such step at a time.  Written by its lane alone -- per record a
+                // selection over the scratch-resident path -- a single step held its wave for thousands of dependent
+                // scratch loads; on the 3 Gbp SNP graph those stragglers were 3.4 of the kernel's 12 ms.
+                uint64_t ovf = __ballot(ev && e_nl > NLQ);
+                if (ovf) {
+                    int32_t *stage = reinterpret_cast<int32_t *>(q.marks);     // 128 words, idle outside expand_queue
+                    static_assert(MAXN <= 64 && sizeof(q.marks) >= 128 * sizeof(int32_t), "staging for one node list");
+                    const bool filt = GEN && a.store;
+                    while (ovf) {
+                        const int owner = __ffsll((unsigned long long)ovf) - 1;
+                        ovf &= ovf - 1;
+                        if (lane == owner) {                                    // its nodes that get a record, path order
+                            int j2 = 0;
+                            for (int a2 = 0; a2 < e_nl; a2++) {
+                                const int32_t v = path[a2];
+                                if (filt && !a.store[v]) continue;
+                                stage[j2++] = v;
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        const int nls = __shfl(e_nls, owner, 64), from = __shfl(e_from, owner, 64);
+                        const int n_rec = (__shfl(e_to, owner, 64) - from) * nls;
+                        const uint64_t cx = __shfl((unsigned long long)e_ctx, owner, 64), ow = __shfl((unsigned long long)own, owner, 64);
+                        const int64_t ix = __shfl((long long)idx, owner, 64), p0 = __shfl((long long)pos0, owner, 64);
+                        const double maf = __shfl(e_maf, owner, 64);
+                        const int32_t nn = (int32_t)(base + owner);
+                        if (lane < nls) {                                       // ascending: the nodes of a path are distinct
+                            const int32_t v = stage[lane];
+                            int rank = 0;
+                            for (int b2 = 0; b2 < nls; b2++) rank += stage[b2] < v ? 1 : 0;
+                            stage[64 + rank] = v;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        for (int rec = lane; rec < n_rec; rec += 64) {          // per offset the distinct nodes ascending
+                            const int w = rec / nls, o = from + w;
+                            const uint64_t h = ((cx >> (2 * o)) | (ow << (2 * (k - 1 - o)))) & kmask;
+                            put(out, ix + rec, h, stage[64 + rec - w * nls], nn, o, p0 + o, maf);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane == owner) { idx += n_rec; ev = false; }
                     }
                 }
-                ev = false;
             }
             const uint64_t pending = __ballot(ev);
             if (pending) {

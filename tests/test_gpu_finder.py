@@ -321,6 +321,46 @@ def test_whitelist_on_device_as_set_index_and_flat_columns():
     assert len(finder_cols(f)["kmers"]) == 0
 
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,M,seed", [(16, 100, 41), (24, 3, 42), (31, 100, 43), (31, 5, 44)])
+def test_windows_over_more_nodes_than_the_step_queue_carries(k, M, seed):
+    # bubbles 1-3 bp apart: with only_save_one_node_per_kmer=False most windows span far more than the 6 nodes a queued
+    # step carries (NLQ in csrc/gki_finder.hip), so their records come from the kernel's many-node path -- in the v2
+    # layout (find), both flat layouts on the device, and under the only_store_nodes filter
+    rng = np.random.default_rng(seed)
+    seqs, edges, lin, af = random_bubble_graph(rng, n_var=12, min_ref=1, max_ref=3, p_indel=0.4, with_af=True,
+                                               first_ref=k + 3, last_ref=k + 5)
+    g = GraphArrays.from_dicts(seqs, edges, lin, af)
+    exp = oracle.find(g, k, None, False, M)
+    per_window = len(exp["kmers"]) / max(1, len(set(zip(exp["kmers"].tolist(), exp["start_nodes"].tolist(),
+                                                           exp["start_offsets"].tolist()))))
+    assert per_window > 6.5                      # the case is what it claims to be
+    f = DenseKmerFinder(g, k, only_save_one_node_per_kmer=False, max_variant_nodes=M)
+    f.find()
+    v2 = finder_cols(f)
+    assert_same_records(v2, exp)
+    pos = g.position_id_base()[v2["start_nodes"]] + v2["start_offsets"]
+    want = (v2["kmers"].astype(np.uint64), v2["nodes"].astype(np.uint32), pos.astype(np.uint64),
+            v2["allele_frequencies"].astype(np.float32))
+    for split in (False, True):
+        d = f.find_flat_on_device(split_layout=split)
+        f.synchronize()
+        flat = d.to_flat_kmers()
+        got = (flat._hashes, flat._nodes, flat._ref_offsets, flat._allele_frequencies)
+        if split:
+            og = np.lexsort((got[3], got[1], got[0], got[2]))
+            ow = np.lexsort((want[3], want[1], want[0], want[2]))
+            for a_, b_ in zip(got, want):
+                assert np.array_equal(a_[og], b_[ow])
+        else:
+            for a_, b_ in zip(got, want):
+                assert np.array_equal(a_, b_)
+    keep = set(int(x) for x in range(g.n_nodes) if x % 3 != 1)
+    f = DenseKmerFinder(g, k, only_save_one_node_per_kmer=False, max_variant_nodes=M, only_store_nodes=keep)
+    f.find()
+    assert_same_records(finder_cols(f), oracle.find(g, k, None, False, M, only_store_nodes=keep))
+
 @pytest.mark.parametrize("case", [c for c in TOY if "from_position" in c["kw"]], ids=lambda c: c["name"])
 def test_kmers_from_position_reference_cases(case):
     # tests/test_kmer_finder.py:118-129, 300-382 of the reference (early-stop searches), exact order

@@ -15,6 +15,9 @@ for i in 1 2 3; do
   run "one-node walk alone" 1
   run "all-nodes walk alone" 1 --all-nodes
   run "all-nodes walk, no node lists" 3 --all-nodes
+  run "all-nodes walk, no >NLQ windows" 4 --all-nodes
+  run "all-nodes whole kernel" 0 --all-nodes
+  run "one-node whole kernel" 0
 done
 export GKI_DBG_SKIP_EXPAND=3
 cd /tmp
