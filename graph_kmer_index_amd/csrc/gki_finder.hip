@@ -163,6 +163,27 @@ __device__ __forceinline__ WalkView stage_walk(const DevGraph &g, WalkCache &wc,
 __device__ __forceinline__ void opaque(uint4 &x) { asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w)); }
 __device__ __forceinline__ void opaque(int32_t &x) { asm volatile("" : "+v"(x)); }
 
+// Lossy-restart offsets (uint16 per node, 0xFFFF = none) of the staged nodes, next to the walk cache: the walk asks for
+// lossy[q] at every predecessor step, and from global memory that was a dependent load per step (+0.15 ms count,
+// +0.38 ms emit on the 3 Gbp graph for a run with no such point at all; staged: +0.09 / +0.07 ms).  Same window as
+// stage_walk.  Not used by the general variants: measured no gain there (count unchanged, emit +0.08 ms), DESIGN.md 4.2.
+__device__ __forceinline__ void stage_lossy(uint16_t *lsy, const uint16_t *__restrict__ lossy, const DevGraph &g, int64_t base, int lane) {
+    const int64_t lo = base - WC_HALO < 0 ? 0 : base - WC_HALO, hi = base + 64 > g.n_nodes ? g.n_nodes : base + 64;
+    const int nn = (int)(hi - lo);
+    const uint16_t x0 = lane < nn ? lossy[lo + lane] : (uint16_t)0xFFFF;
+    const uint16_t x1 = (lane < WC_HALO && 64 + lane < nn) ? lossy[lo + 64 + lane] : (uint16_t)0xFFFF;
+    lsy[lane] = x0;
+    if (lane < WC_HALO) lsy[64 + lane] = x1;
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ int cached_lossy(const uint16_t *__restrict__ lossy, const uint16_t *lsy, const WalkView &v, int64_t q) {
+    const bool in = q >= v.lo && q < v.hi;
+    int32_t c = lsy[in ? q - v.lo : 0];
+    opaque(c);
+    if (!in) c = lossy[q];
+    return c == 0xFFFF ? -1 : c;
+}
+
 __device__ __forceinline__ NodeWalk cached_walk(const DevGraph &g, const WalkCache &wc, const WalkView &v, int64_t q) {
     const bool in = q >= v.lo && q < v.hi;
     const int64_t slot = in ? q - v.lo : 0;
@@ -335,6 +356,8 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
                                                         uint32_t *__restrict__ bcount, uint32_t *__restrict__ total,
                                                         int *__restrict__ err) {
     __shared__ WalkCache s_wc[4];
+    constexpr bool LSY = HAS_LOSSY && !GEN;      // staged lossy offsets: see stage_lossy (no gain in the general variants)
+    __shared__ uint16_t s_lsy[LSY ? 4 : 1][WC_HALO + 64];
     LevelLo below[MAXN];
     LevelLo below0 = {0, 0, 0, 0, 0};  // the first suspended level stays in registers (SNP/indel graphs never go deeper)
     int32_t path[GEN ? MAXN : 1];      // general graphs: the node of every level (level 0 = the end node)
@@ -344,6 +367,8 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
     WalkCache &wc = s_wc[wib];
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t base = a.n0 + (int64_t)blockIdx.x * blockDim.x + wib * 64; base < a.n1; base += stride) {
+        uint16_t *lsy = s_lsy[LSY ? wib : 0];
+        if (LSY) stage_lossy(lsy, lossy, g, base, lane);
         const WalkView wv = stage_walk(g, wc, base, lane, GEN ? a.nflags : nullptr);
         const int64_t n = base + lane;
         if (n >= a.n1) continue;
@@ -412,7 +437,7 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
                     } else {
                         int from = k - 1 - c - s; if (from < w_lo) from = w_lo;
                         int to = k - 1 - c; if (to > hi) to = hi;
-                        const int cq = HAS_LOSSY ? lossy_of(lossy, q) : -1;
+                        const int cq = LSY ? cached_lossy(lossy, lsy, wv, q) : (HAS_LOSSY ? lossy_of(lossy, q) : -1);
                         if (HAS_LOSSY && cq >= 0) {
                             const int min_ok = k - 1 - c - s + cq; if (from < min_ok) from = min_ok;
                             // the search restarted at (q, cq) with no history: at an end position whose window would
@@ -619,6 +644,8 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                                                            typename OutSel<FMT>::T out, int *__restrict__ err) {
     __shared__ EvQueue<FMT, ALL> s_q[4];
     __shared__ WalkCache s_wc[4];
+    constexpr bool LSY = HAS_LOSSY && !GEN;      // staged lossy offsets: see stage_lossy (no gain in the general variants)
+    __shared__ uint16_t s_lsy[LSY ? 4 : 1][WC_HALO + 64];
     LevelEmit below[MAXN];
     LevelEmit below0;                  // the first suspended level stays in registers
     below0.ctx = 0; below0.maf = 0.0; below0.cur = below0.end = below0.mn = 0; below0.cum = below0.vc = below0.evf = below0.evt = 0;
@@ -634,6 +661,8 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
     const int64_t n_threads = (int64_t)gridDim.x * blockDim.x;
     int n_ev = 0, my_cnt = 0;              // steps in the queue; of them, queued by this lane
     for (int64_t base = a.n0 + (int64_t)blockIdx.x * blockDim.x + wib * 64; base < a.n1; base += n_threads) {
+        uint16_t *lsy = s_lsy[LSY ? wib : 0];
+        if (LSY) stage_lossy(lsy, lossy, g, base, lane);
         const WalkView wv = stage_walk(g, wc, base, lane, GEN ? a.nflags : nullptr);
         const int64_t n = base + lane;
         int L = 0, o_lo = 0, hi = 0;
@@ -725,7 +754,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                             } else {
                                 from = k - 1 - c - s; if (from < o_lo) from = o_lo;
                                 to = k - 1 - c; if (to > hi) to = hi;
-                                const int cq = HAS_LOSSY ? lossy_of(lossy, qn) : -1;
+                                const int cq = LSY ? cached_lossy(lossy, lsy, wv, qn) : (HAS_LOSSY ? lossy_of(lossy, qn) : -1);
                                 if (HAS_LOSSY && cq >= 0) { const int min_ok = k - 1 - c - s + cq; if (from < min_ok) from = min_ok; }
                                 if (GEN && from < to && !(fq & (GKI_NODE_T | GKI_NODE_SIMPLE))) {      // a history before q?
                                     // (fq >> 8: no history holds more variant nodes in the k bases before q -- if even
@@ -1227,6 +1256,9 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
     a.k = p->k; a.M = p->max_variant_nodes > 250 ? 250 : p->max_variant_nodes;
     a.one_node = p->one_node_per_kmer ? 1 : 0;
     a.has_lossy = p->h_lossy_crit ? 1 : 0;
+    // tuning builds: run the lossy-restart kernel variants on a graph without such points (what does the variant cost?)
+    const bool force_lossy = !a.has_lossy && GKI_KNOB("GKI_FORCE_LOSSY", 0) != 0;
+    if (force_lossy) { HIP_TRY(hipMemsetAsync(f->lossy, 0xFF, (size_t)d.n_nodes * 2, s)); a.has_lossy = 1; }
     a.node_begin = p->node_begin; a.off_begin = p->off_begin; a.node_end = p->node_end; a.off_end = p->off_end;
     a.n0 = p->node_begin < d.n_nodes ? p->node_begin : d.n_nodes;
     a.n1 = p->node_end < d.n_nodes ? p->node_end + 1 : d.n_nodes;
@@ -1256,7 +1288,7 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
     }
     f->args = a;
     const int64_t n_run = a.n1 - a.n0;
-    if (a.has_lossy) HIP_TRY(hipMemcpyAsync(f->lossy, p->h_lossy_crit, (size_t)d.n_nodes * 2, hipMemcpyHostToDevice, s));
+    if (a.has_lossy && !force_lossy) HIP_TRY(hipMemcpyAsync(f->lossy, p->h_lossy_crit, (size_t)d.n_nodes * 2, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(f->d_err, 0, 4, s));
     HIP_TRY(hipMemsetAsync(f->d_bsum, 0, 8, s));
 
@@ -1266,14 +1298,15 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
         // an eighth waits) the pass took 0.70 ms, with one group each 0.59 (GKI_CNT_BLOCKS sweeps it in tuning builds)
         const int64_t want = ceil_div(n_run, 256), cap = GKI_KNOB("GKI_CNT_BLOCKS", 1 << 30);
         const int count_grid = (int)(want < cap ? want : cap);
+        const int cnt_pad = GKI_KNOB("GKI_CNT_LDS_PAD", 0);   // tuning builds: unused dynamic LDS, to lower the occupancy
         if (a.nflags)
-            hipLaunchKernelGGL((k_count_boundary<true, true>), dim3(count_grid), dim3(256), 0, s, d, a, f->lossy,
+            hipLaunchKernelGGL((k_count_boundary<true, true>), dim3(count_grid), dim3(256), cnt_pad, s, d, a, f->lossy,
                                f->bcount, f->total, f->d_err);
         else if (a.has_lossy)
-            hipLaunchKernelGGL((k_count_boundary<true, false>), dim3(count_grid), dim3(256), 0, s, d, a, f->lossy,
+            hipLaunchKernelGGL((k_count_boundary<true, false>), dim3(count_grid), dim3(256), cnt_pad, s, d, a, f->lossy,
                                f->bcount, f->total, f->d_err);
         else
-            hipLaunchKernelGGL((k_count_boundary<false, false>), dim3(count_grid), dim3(256), 0, s, d, a, f->lossy,
+            hipLaunchKernelGGL((k_count_boundary<false, false>), dim3(count_grid), dim3(256), cnt_pad, s, d, a, f->lossy,
                                f->bcount, f->total, f->d_err);
         HIP_TRY(hipGetLastError());
     }
