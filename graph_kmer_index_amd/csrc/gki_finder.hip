@@ -262,8 +262,14 @@ struct LevelLo {                 // what a suspended level needs to resume
 // gki_classify_nodes settled on the host (GKI_NODE_DEAD is exact).
 constexpr int HMAX = 40;         // nodes of one enumerated history (k-1 one-base nodes + slack)
 
-__device__ __noinline__ bool history_ok(const DevGraph &g, const WalkCache &wc, const WalkView &wv,
+// The graph arrays the enumeration reads, BY VALUE: with `const DevGraph &` the kernel's DevGraph escaped to memory for
+// this out-of-line call and every load through its pointers in the kernel itself became a FLAT load (address space
+// lost) -- which waits on the LDS counter as well as on the memory counter, in kernels full of LDS traffic.
+struct WalkSrc { const NodeWalk *walk; const int32_t *rev_edges; const int64_t *rev_start; };
+__device__ __noinline__ bool history_ok(const WalkSrc gs, const WalkCache &wc, const WalkView &wv,
                                         const uint16_t *__restrict__ nf, int k, int M, const int32_t *path, int L, int *err) {
+    DevGraph g = {};                       // only these three members are read below (helpers are inlined)
+    g.walk = gs.walk; g.rev_edges = gs.rev_edges; g.rev_start = gs.rev_start;
     // open constraints of the window's nodes path[0..L] (end node .. q): the step into a non-free node y still sees
     // the history nodes within t bases of q's entry and tolerates fewer than m variant nodes among them
     int8_t ct[MAXN];
@@ -351,8 +357,12 @@ __device__ __forceinline__ int stored_nodes(const uint8_t *__restrict__ store, c
     return c;
 }
 
+// The walk is a chain of dependent LDS / memory reads: its speed is the number of resident waves.  The general variant
+// needs 100 VGPRs unconstrained (4 waves per SIMD; the others 53-55 = 8) -- held to 64 it spills ~30 values around the
+// history_ok call and is still faster at every step: 1.27 / 1.11 / 0.99 / 0.95 / 0.94 ms at 4 / 5 / 6 / 7 / 8 waves on the
+// 3 Gbp SNP graph, 2.19 / 1.88 / 1.70 / 1.66 / 1.64 ms with 20 % nested sites (tools/exp/ab_libs.sh, same box).
 template <bool HAS_LOSSY, bool GEN>
-__global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
+__global__ __launch_bounds__(256, GEN ? 8 : 1) void k_count_boundary(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
                                                         uint32_t *__restrict__ bcount, uint32_t *__restrict__ total,
                                                         int *__restrict__ err) {
     __shared__ WalkCache s_wc[4];
@@ -447,7 +457,7 @@ __global__ __launch_bounds__(256) void k_count_boundary(DevGraph g, FindArgs a, 
                         if (GEN && from < to) {
                             bool ok = true;                          // a history before the window's first node?
                             if (!(fq & (GKI_NODE_T | GKI_NODE_SIMPLE)))
-                                ok = (fq & GKI_NODE_NESTED) ? (vq + (int)(fq >> 8) < a.M || history_ok(g, wc, wv, a.nflags, k, a.M, path, L, err)) : false;
+                                ok = (fq & GKI_NODE_NESTED) ? (vq + (int)(fq >> 8) < a.M || history_ok(WalkSrc{g.walk, g.rev_edges, g.rev_start}, wc, wv, a.nflags, k, a.M, path, L, err)) : false;
                             if (ok && chk && from <= oc && oc < to && vq >= a.M) *err = GKI_ERR_NOT_ONE_REF_SUCC;
                             if (!ok) to = from;
                         }
@@ -759,7 +769,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                                 if (GEN && from < to && !(fq & (GKI_NODE_T | GKI_NODE_SIMPLE))) {      // a history before q?
                                     // (fq >> 8: no history holds more variant nodes in the k bases before q -- if even
                                     // that many fit under the limit, any history that enters q will do, and q is entered)
-                                    const bool ok = (fq & GKI_NODE_NESTED) ? (vq + (int)(fq >> 8) < a.M || history_ok(g, wc, wv, a.nflags, k, a.M, path, L, err)) : false;
+                                    const bool ok = (fq & GKI_NODE_NESTED) ? (vq + (int)(fq >> 8) < a.M || history_ok(WalkSrc{g.walk, g.rev_edges, g.rev_start}, wc, wv, a.nflags, k, a.M, path, L, err)) : false;
                                     if (!ok) to = from;
                                 }
                                 const int tq = s < k - 1 - c ? s : k - 1 - c;
