@@ -1,0 +1,76 @@
+"""Properties of the compiled gfx950 kernels that the measured performance rests on (CPU only: hipcc cross-compiles).
+
+DESIGN.md 4.2: (1) no FLAT memory instruction in any kernel -- a struct of pointers that escapes to an out-of-line call
+turns every load through it into a FLAT load, which waits on the LDS counter as well as the memory counter (cost the
+general count kernel 22 %); only the out-of-line history_ok, whose pointers cross a call boundary, has them.
+(2) the walk kernels are latency-bound, their speed is the number of resident waves: the register and LDS footprints that
+give the measured occupancies are pinned here."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "graph_kmer_index_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC) or shutil.which("c++filt") is None, reason="needs hipcc and c++filt")
+
+
+@pytest.fixture(scope="module")
+def finder_asm(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("codegen") / "gki_finder.s")
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "--cuda-device-only", "-S",
+                    os.path.join(CSRC, "gki_finder.hip"), "-o", out], check=True, stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def _functions(txt):
+    found = {m.group(1): m.group(2) for m in re.finditer(r"\n(_Z\w+):[^\n]*\n(.*?)\n\.Lfunc_end\d+:", txt, re.S)}
+    names = list(found)
+    dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    return {re.sub(r"\(anonymous namespace\)::|void ", "", d): found[n] for n, d in zip(names, dem)}
+
+
+def _resources(txt):
+    res = {}
+    for blk in re.split(r"\n  - \.agpr_count:", txt)[1:]:
+        blk = ".agpr_count:" + blk
+        get = lambda key: re.search(r"\.%s:\s*(\S+)" % key, blk).group(1)
+        res[get("name")] = dict(vgpr=int(get("vgpr_count")) + int(get("agpr_count")), lds=int(get("group_segment_fixed_size")),
+                                scratch=int(get("private_segment_fixed_size")))
+    names = list(res)
+    dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    return {re.sub(r"\(anonymous namespace\)::|void ", "", d).split("(")[0]: res[n] for n, d in zip(names, dem)}
+
+
+def test_no_flat_memory_instructions_outside_history_ok(finder_asm):
+    funcs = _functions(finder_asm)
+    assert len(funcs) >= 28
+    offenders = {}
+    for name, body in funcs.items():
+        n = len(re.findall(r"\n\s*flat_(load|store|atomic)", body))
+        if n and not name.startswith("history_ok"):
+            offenders[name.split("(")[0]] = n
+    assert not offenders, "FLAT memory instructions (address space lost): %s" % offenders
+
+
+def test_occupancy_footprints_of_the_walk_kernels(finder_asm):
+    r = _resources(finder_asm)
+    waves_by_regs = lambda v: min(8, 512 // ((v + 7) // 8 * 8))
+    blocks_by_lds = lambda b: 163840 // b
+    # count pass: 8 waves per SIMD in every variant (the general one is held there by __launch_bounds__)
+    for v in ("k_count_boundary<false, false>", "k_count_boundary<true, false>", "k_count_boundary<true, true>"):
+        assert waves_by_regs(r[v]["vgpr"]) == 8, (v, r[v])
+        assert blocks_by_lds(r[v]["lds"]) >= 8, (v, r[v])
+    # emit pass, flat layouts (FMT 0 / 2): 4 workgroups per CU in one-node mode, 3 in all-nodes mode; registers never the limit
+    for lossy in ("false", "true"):
+        for fmt in ("0", "2"):
+            one = r["k_emit_boundary_one<%s, %s, false, false>" % (lossy, fmt)]
+            allm = r["k_emit_boundary_one<%s, %s, true, false>" % (lossy, fmt)]
+            assert blocks_by_lds(one["lds"]) == 4 and waves_by_regs(one["vgpr"]) >= 4, (lossy, fmt, one)
+            assert blocks_by_lds(allm["lds"]) == 3 and waves_by_regs(allm["vgpr"]) >= 3, (lossy, fmt, allm)
+    gen = r["k_emit_boundary_one<true, 2, false, true>"]
+    assert blocks_by_lds(gen["lds"]) == 4 and waves_by_regs(gen["vgpr"]) >= 4, gen
