@@ -27,6 +27,14 @@ def finder_asm(tmp_path_factory):
     return open(out).read()
 
 
+@pytest.fixture(scope="module")
+def forward_asm(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("codegen_fw") / "gki_forward.s")
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "--cuda-device-only", "-S",
+                    os.path.join(CSRC, "gki_forward.hip"), "-o", out], check=True, stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
 def _functions(txt):
     found = {m.group(1): m.group(2) for m in re.finditer(r"\n(_Z\w+):[^\n]*\n(.*?)\n\.Lfunc_end\d+:", txt, re.S)}
     names = list(found)
@@ -74,3 +82,13 @@ def test_occupancy_footprints_of_the_walk_kernels(finder_asm):
             assert blocks_by_lds(allm["lds"]) == 3 and waves_by_regs(allm["vgpr"]) >= 3, (lossy, fmt, allm)
     gen = r["k_emit_boundary_one<true, 2, false, true>"]
     assert blocks_by_lds(gen["lds"]) == 4 and waves_by_regs(gen["vgpr"]) >= 4, gen
+
+
+def test_forward_search_kernel_runs_at_full_occupancy(forward_asm):
+    # the early-stop search reads everything from global memory, one lane per start position: left alone the compiler
+    # builds it with 178 VGPRs (2 waves per SIMD) and it is 1.6-2.3x slower (csrc/gki_forward.hip, tools/bench_forward.py)
+    r = _resources(forward_asm)
+    for v in ("k_forward<false>", "k_forward<true>"):
+        assert r[v]["vgpr"] <= 64, (v, r[v])
+    for name, body in _functions(forward_asm).items():
+        assert not re.findall(r"\n\s*flat_(load|store|atomic)", body), name
