@@ -13,10 +13,11 @@ neither torch nor any other framework is imported -- the compute path is libgki_
 
 A step = gki_finder_count (boundary count kernel + prefix sums) + gki_finder_emit_flat (interior + boundary emit
 kernels) over the rank's shard, inputs (graph arrays) already in HBM.  Rank 0 prints one JSON line.  At N=1 the same
-line carries two secondary records measured after the timed region on the step's own output: `index_build`
+line carries three secondary records measured after the timed region on the step's own output and graph: `index_build`
 (CollisionFreeKmerIndex.from_flat_kmers of the variant index, collision_free_kmer_index.py:423-467) and `read_mapping`
 (BASELINE configs[4]: reads -> k-mers of both strands -> CollisionFreeKmerIndex.get -> node counts,
-read_kmers.py:67-70, collision_free_kmer_index.py:303-315).
+read_kmers.py:67-70, collision_free_kmer_index.py:303-315) and `early_stop_search` (the batched
+find_only_kmers_starting_at_position in UniqueVariantKmersFinder's call pattern, unique_variant_kmers.py:119-140).
 """
 import argparse
 import json
@@ -128,7 +129,44 @@ def secondary_records(lib, _lib, g, k, finder, out, n_reads, modulo=452930477, m
     for b in (d_letters, d_start, counts):
         b.free()
     idx.free()
-    return index_build, read_mapping
+    return index_build, read_mapping, early_stop_record(lib, _lib, g, k, finder)
+
+
+def early_stop_record(lib, _lib, g, k, finder, max_variant_nodes=4):
+    """SURVEY.md 8(f) row 4 on the step's own graph: the batched early-stop search in UniqueVariantKmersFinder's call
+    pattern (unique_variant_kmers.py:119-140) -- seven find_only_kmers_starting_at_position per SNP site, 2, 6, ... 26
+    bases before the variant, constructor defaults (all window nodes, max_variant_nodes 4) -- as one batch through
+    gki_forward_count + gki_forward_emit.  Same generator as tools/bench_forward.py."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_forward import start_positions
+    nodes, offs = start_positions(g, k)
+    n_pos = len(nodes)
+    graph = finder._device_graph()
+    d_nodes, d_offs = _lib.DeviceArray.from_host(nodes), _lib.DeviceArray.from_host(offs)
+    d_start = _lib.DeviceArray(n_pos + 1, np.int64)
+    n = C.c_int64(0)
+    head = (graph.handle, k, max_variant_nodes, 0, None, d_nodes.ptr, d_offs.ptr, n_pos)
+    _lib.check(lib.gki_forward_count(*head, d_start.ptr, C.byref(n)))
+    n_rec = n.value
+    bufs = [_lib.DeviceArray(max(1, n_rec), d) for d in (np.int64, np.int32, np.int16, np.int32, np.float64)]
+    times = []
+    for _ in range(4):                                   # the first pass warms the pool
+        t = time.perf_counter()
+        _lib.check(lib.gki_forward_count(*head, d_start.ptr, C.byref(n)))             # synchronous: returns the total
+        _lib.check(lib.gki_forward_emit(*head, d_start.ptr, *[b.ptr for b in bufs]))  # synchronises before returning
+        times.append(time.perf_counter() - t)
+    dt = float(np.median(times[1:]))
+    first_counts = np.diff(d_start.to_host(min(n_pos, 1 << 20) + 1))
+    rec = {"start_positions": int(n_pos), "records": int(n_rec), "ms": 1e3 * dt, "start_positions_per_s": n_pos / dt,
+           "records_per_s": n_rec / dt, "only_save_one_node_per_kmer": False, "max_variant_nodes": max_variant_nodes,
+           "every_start_has_a_record": bool(first_counts.min() >= 1),
+           "workload": "seven early-stop searches per SNP site (unique_variant_kmers.py:119-140), one batch",
+           "timed": "wall clock around gki_forward_count + gki_forward_emit, graph / start arrays / output columns in HBM"}
+    log("early-stop search: %d start positions, %d records in %.2f ms" % (n_pos, n_rec, 1e3 * dt))
+    for b in bufs + [d_nodes, d_offs, d_start]:
+        b.free()
+    return rec
 
 
 _CPU = {}
@@ -323,7 +361,7 @@ def main():
         if checks is not None:
             res["verify"] = checks
         if secondary is not None:
-            res["index_build"], res["read_mapping"] = secondary
+            res["index_build"], res["read_mapping"], res["early_stop_search"] = secondary
         res["cpu_baseline"] = cpu
         print(json.dumps(res), flush=True)
     plane.barrier()

@@ -298,7 +298,7 @@ def test_loopback_ranks_build_the_oracle_index(world):
 
 def test_bench_line_has_the_contract_fields(tmp_path):
     """bench.py end to end at a small size: one JSON line with the driver's fields, the roofline and CPU-baseline objects
-    and the two secondary records; a second run as two ranks (on this one GPU) over the socket control plane."""
+    and the three secondary records; a second run as two ranks (on this one GPU) over the socket control plane."""
     import json
     import os
     import subprocess
@@ -311,13 +311,16 @@ def test_bench_line_has_the_contract_fields(tmp_path):
     d = json.loads(out[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "timed_region", "index_build",
-                "read_mapping"):
+                "read_mapping", "early_stop_search"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["vs_baseline"] is None
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["bound"] == "hbm"
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 2 and d["cpu_baseline"]["value"] > 0
     assert d["index_build"]["records"] > 0 and d["read_mapping"]["kmers"] == 2 * 20000 * 120
+    es = d["early_stop_search"]            # seven starts per SNP site (fewer where the segment in front is short)
+    assert 5 * 30000 < es["start_positions"] <= 7 * 30000 and es["records"] >= es["start_positions"]
+    assert es["every_start_has_a_record"] and es["start_positions_per_s"] > 0
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline"] + small,
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
