@@ -96,7 +96,22 @@ def secondary_records(lib, _lib, g, k, finder, out, n_reads, modulo=452930477, m
     for x in some[:2000]:
         idx.get_small([int(x)], 10)
     index_build["scalar_get_calls_per_s"] = min(len(some), 2000) / (time.perf_counter() - t)
-    log("index build: %d records in %.1f ms; scalar get %.0f calls/s" % (nb, 1e3 * dt, index_build["scalar_get_calls_per_s"]))
+    # ReverseKmerIndex.from_flat_kmers (reverse_kmer_index.py:47-83) of the same records: the same
+    # stable radix sort keyed on the node id (gki_reverse_index_build), columns in HBM on both sides
+    r_pos, r_cnt = _lib.DeviceArray(g.n_nodes, np.uint32), _lib.DeviceArray(g.n_nodes, np.uint16)
+    r_kmers, r_refs = _lib.DeviceArray(nb, np.uint64), _lib.DeviceArray(nb, np.uint64)
+    for _ in range(2):                                   # the second build is the measurement
+        sync()
+        t = time.perf_counter()
+        _lib.check(lib.gki_reverse_index_build(bnd.nodes.ptr, bnd.hashes.ptr, bnd.ref_offsets.ptr, nb, g.n_nodes, r_pos.ptr,
+                                               r_cnt.ptr, r_kmers.ptr, r_refs.ptr))
+        sync()
+        dt_rev = time.perf_counter() - t
+    index_build["reverse_index"] = {"ms": 1e3 * dt_rev, "records_per_s": nb / dt_rev, "n_nodes": int(g.n_nodes),
+                                    "run_lengths_sum_to_records": bool(int(r_cnt.to_host().astype(np.int64).sum()) == nb)}
+    for b in (r_pos, r_cnt, r_kmers, r_refs):
+        b.free()
+    log("index build: %d records in %.1f ms; scalar get %.0f calls/s; reverse index %.1f ms" % (nb, 1e3 * dt, index_build["scalar_get_calls_per_s"], 1e3 * dt_rev))
 
     t = time.perf_counter()
     letters = make_reads(synthetic_haplotype_sequence(g), n_reads, np.random.default_rng(99))

@@ -318,6 +318,7 @@ def test_bench_line_has_the_contract_fields(tmp_path):
     assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["bound"] == "hbm"
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 2 and d["cpu_baseline"]["value"] > 0
     assert d["index_build"]["records"] > 0 and d["read_mapping"]["kmers"] == 2 * 20000 * 120
+    assert d["index_build"]["reverse_index"]["run_lengths_sum_to_records"] and d["index_build"]["reverse_index"]["ms"] > 0
     es = d["early_stop_search"]            # seven starts per SNP site (fewer where the segment in front is short)
     assert 5 * 30000 < es["start_positions"] <= 7 * 30000 and es["records"] >= es["start_positions"]
     assert es["every_start_has_a_record"] and es["start_positions_per_s"] > 0
