@@ -1085,12 +1085,13 @@ static int tuning_int(const char *name, int dflt) { const char *v = getenv(name)
 template <int FMT, bool ALL>
 static int launch_boundary_mode(gki_finder *f, const DevGraph &d, const FindArgs &a, typename OutSel<FMT>::T out, hipStream_t s2,
                                 const dim3 grid, const dim3 block, const int64_t *base, const int64_t *shift) {
+    const int emit_pad = GKI_KNOB("GKI_EMIT_LDS_PAD", 0);  // tuning builds: unused dynamic LDS, to lower the occupancy
     if (a.nflags)          // general graphs always carry a lossy table (0xFFFF everywhere when there is none)
-        hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, true>), grid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
+        hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, true>), grid, block, emit_pad, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
     else if (a.has_lossy)
-        hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, false>), grid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
+        hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, false>), grid, block, emit_pad, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
     else
-        hipLaunchKernelGGL((k_emit_boundary_one<false, FMT, ALL, false>), grid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
+        hipLaunchKernelGGL((k_emit_boundary_one<false, FMT, ALL, false>), grid, block, emit_pad, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
     HIP_TRY(hipGetLastError());
     return GKI_OK;
 }
