@@ -501,7 +501,12 @@ __global__ __launch_bounds__(256, GEN ? 8 : 1) void k_count_boundary(DevGraph g,
 // RECORD (prefix sum of the step sizes, binary search of the lane's step in LDS) and streams the column
 // stores with no load in between.  Keeping the stores out of the walk matters on gfx950: loads and stores
 // retire in order through one counter, so a store inside the walk stalls the next dependent load.
-constexpr int EVQ = 128;            // step descriptors per wave queue (a walk round adds at most 64)
+#ifndef GKI_EVQ
+#define GKI_EVQ 128
+#endif
+constexpr int EVQ = GKI_EVQ;        // step descriptors per wave queue (a walk round adds at most 64)
+constexpr int MW = EVQ * 32 / 64;   // words of the window bitmap (a step holds at most 31 windows)
+static_assert(EVQ > 64 && EVQ <= 128 && EVQ % 2 == 0 && MW <= 64, "two steps per lane, one bitmap word per lane");
 
 constexpr int NLQ = 6;              // all-nodes mode: node lists of up to NLQ nodes travel through the queue
 
@@ -551,7 +556,6 @@ template <int FMT, bool ALL>
 __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int my_cnt, typename OutSel<FMT>::T out, int k,
                                              uint64_t kmask, int lane) {
     if (GKI_DBG_SKIP_EXPAND_IS(1) || GKI_DBG_SKIP_EXPAND_IS(3) || GKI_DBG_SKIP_EXPAND_IS(4)) return;
-    static_assert(EVQ == 128, "two steps per lane");
     {
         int ps = my_cnt;
 #pragma unroll
@@ -592,7 +596,6 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
     // that a store instruction covers whole cache lines of every column wherever the steps are contiguous.  In
     // all-nodes mode a window has one record per distinct node: the lane writes them in turn (neighbouring lanes then
     // write `nl` records apart and the following turns fill the gaps while the lines are still in L2).
-    static_assert(EVQ * 32 / 64 == 64, "one bitmap word per lane");
     const int c0 = lane < n_ev ? (int)q.cnt[q.order[lane]] : 0;
     const int c1 = lane + 64 < n_ev ? (int)q.cnt[q.order[lane + 64]] : 0;
     int s0 = c0, s1 = c1;
@@ -604,18 +607,19 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
     const int tot0 = __shfl(s0, 63, 64);
     const int T = tot0 + __shfl(s1, 63, 64);
     const int ex0 = s0 - c0, ex1 = tot0 + s1 - c1;
-    q.pre[lane] = (uint16_t)ex0; q.pre[lane + 64] = (uint16_t)ex1;
-    q.marks[lane] = 0ull;
+    q.pre[lane] = (uint16_t)ex0;
+    if (lane + 64 < EVQ) q.pre[lane + 64] = (uint16_t)ex1;
+    if (lane < MW) q.marks[lane] = 0ull;
     __builtin_amdgcn_wave_barrier();
     unsigned int *marks32 = reinterpret_cast<unsigned int *>(q.marks);
     if (c0) atomicOr(&marks32[ex0 >> 5], 1u << (ex0 & 31));
     if (c1) atomicOr(&marks32[ex1 >> 5], 1u << (ex1 & 31));
     __builtin_amdgcn_wave_barrier();
-    const int pc = __popcll(q.marks[lane]);
+    const int pc = lane < MW ? __popcll(q.marks[lane]) : 0;
     int ps = pc;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(ps, d, 64); if (lane >= d) ps += t; }
-    q.wrank[lane] = (uint16_t)(ps - pc);
+    if (lane < MW) q.wrank[lane] = (uint16_t)(ps - pc);
     __builtin_amdgcn_wave_barrier();
     const int shift = ALL ? 0 : (int)(mn_idx & 15);
     for (int r0 = -shift; r0 < T; r0 += 64) {
@@ -808,8 +812,8 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                 // scratch loads; on the 3 Gbp SNP graph those stragglers were 3.4 of the kernel's 12 ms.
                 uint64_t ovf = __ballot(ev && e_nl > NLQ);
                 if (ovf) {
-                    int32_t *stage = reinterpret_cast<int32_t *>(q.marks);     // 128 words, idle outside expand_queue
-                    static_assert(MAXN <= 64 && sizeof(q.marks) >= 128 * sizeof(int32_t), "staging for one node list");
+                    int32_t *stage = reinterpret_cast<int32_t *>(q.marks);     // 2 * MAXN words, idle outside expand_queue
+                    static_assert(MAXN <= 64 && sizeof(q.marks) >= 2 * MAXN * sizeof(int32_t), "staging for one node list");
                     const bool filt = GEN && a.store;
                     while (ovf) {
                         const int owner = __ffsll((unsigned long long)ovf) - 1;
@@ -833,13 +837,13 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                             const int32_t v = stage[lane];
                             int rank = 0;
                             for (int b2 = 0; b2 < nls; b2++) rank += stage[b2] < v ? 1 : 0;
-                            stage[64 + rank] = v;
+                            stage[MAXN + rank] = v;
                         }
                         __builtin_amdgcn_wave_barrier();
                         for (int rec = lane; rec < n_rec; rec += 64) {          // per offset the distinct nodes ascending
                             const int w = rec / nls, o = from + w;
                             const uint64_t h = ((cx >> (2 * o)) | (ow << (2 * (k - 1 - o)))) & kmask;
-                            put(out, ix + rec, h, stage[64 + rec - w * nls], nn, o, p0 + o, maf);
+                            put(out, ix + rec, h, stage[MAXN + rec - w * nls], nn, o, p0 + o, maf);
                         }
                         __builtin_amdgcn_wave_barrier();
                         if (lane == owner) { idx += n_rec; ev = false; }
