@@ -494,13 +494,18 @@ __global__ __launch_bounds__(256, GEN ? 8 : 1) void k_count_boundary(DevGraph g,
 }
 
 // Emit pass (ALL = false: only_save_one_node_per_kmer, the CLI `index` configuration; ALL = true: one record per
-// distinct window node, the constructor's default): walk and write are separated
-// inside the wave.  Phase A -- the lanes walk their nodes (loads only) and park every finished step as a
-// 50-byte descriptor in the wave's LDS queue: {context register, own bases, first record slot, ...}.
-// Phase B -- when the queue fills up or the walk is over, the wave expands the queue with one lane per
-// RECORD (prefix sum of the step sizes, binary search of the lane's step in LDS) and streams the column
-// stores with no load in between.  Keeping the stores out of the walk matters on gfx950: loads and stores
-// retire in order through one counter, so a store inside the walk stalls the next dependent load.
+// distinct window node, the constructor's default): walk and write are separated inside the wave.
+// Phase A -- the lanes walk their nodes (loads only) and park every finished step in the wave's LDS queue: per step
+// {context register, first record slot, allele-frequency minimum, smallest node, offsets, owning lane [, node list]},
+// per lane {own bases, position id, node}.  A step whose window spans more than NLQ nodes does not fit the queue and is
+// written by the whole wave at once (all-nodes mode).
+// Phase B (expand_queue) -- when the queue fills up, a node group ends or the walk is over, the wave writes the queue
+// in output order with one lane per WINDOW: positions from a wave scan, the step of window r from a bitmap + popcount,
+// in all-nodes mode the step's nodes sorted by a fixed network first; the column stores stream with no load in between.
+// Keeping the stores out of the walk matters on gfx950: loads and stores retire in order through one counter, so a
+// store inside the walk stalls the next dependent load.
+// EVQ: 128 steps per queue; 96 would save 4.5 KB of LDS per workgroup but is ~7 % slower at equal occupancy (fewer steps
+// per flush), which is why the LDS diet for a fifth workgroup per CU was dropped.
 #ifndef GKI_EVQ
 #define GKI_EVQ 128
 #endif
