@@ -371,6 +371,9 @@ __global__ __launch_bounds__(256, GEN ? 8 : 1) void k_count_boundary(DevGraph g,
     LevelLo below[MAXN];
     LevelLo below0 = {0, 0, 0, 0, 0};  // the first suspended level stays in registers (SNP/indel graphs never go deeper)
     int32_t path[GEN ? MAXN : 1];      // general graphs: the node of every level (level 0 = the end node)
+    // levels 1 and 2 of `path` live in registers and reach scratch only right before the rare calls that read the array
+    // (history_ok, stored_nodes): a scratch store at every step of the walk sits in front of the next load (in-order vmcnt)
+    int32_t pr1 = 0, pr2 = 0;
     const int k = a.k;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(256, GEN ? 8 : 1) void k_count_boundary(DevGraph g,
                     const uint16_t fq = GEN ? cached_flag(a.nflags, wc, wv, q) : (uint16_t)0;
                     if (GEN) {
                         if (fq & GKI_NODE_DEAD) continue;
-                        if ((fq & GKI_NODE_HFS) && !(a.nflags[path[L - 1]] & GKI_NODE_FORCED)) continue;
+                        if ((fq & GKI_NODE_HFS) && !(a.nflags[L == 1 ? (int32_t)n : L == 2 ? pr1 : L == 3 ? pr2 : path[L - 1]] & GKI_NODE_FORCED)) continue;
                     }
                     const int vq = t_vc + (GEN ? ((fq & GKI_NODE_REF) ? 0 : 1) : (wq.is_ref ? 0 : 1));
                     int aq = 0;
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(256, GEN ? 8 : 1) void k_count_boundary(DevGraph g,
                         if (aq && vq - aq >= a.M) continue;
                     }
                     if (L >= MAXN - 1) { *err = GKI_ERR_WINDOW_TOO_DEEP; continue; }
-                    if (GEN) path[L] = q;
+                    if (GEN) { if (L == 1) pr1 = q; else if (L == 2) pr2 = q; else path[L] = q; }
                     const int s = wq.size, c = t_cum;
                     bool deeper;
                     int new_cum;
@@ -457,14 +460,14 @@ __global__ __launch_bounds__(256, GEN ? 8 : 1) void k_count_boundary(DevGraph g,
                         if (GEN && from < to) {
                             bool ok = true;                          // a history before the window's first node?
                             if (!(fq & (GKI_NODE_T | GKI_NODE_SIMPLE)))
-                                ok = (fq & GKI_NODE_NESTED) ? (vq + (int)(fq >> 8) < a.M || history_ok(WalkSrc{g.walk, g.rev_edges, g.rev_start}, wc, wv, a.nflags, k, a.M, path, L, err)) : false;
+                                ok = (fq & GKI_NODE_NESTED) ? (vq + (int)(fq >> 8) < a.M || (path[1] = pr1, path[2] = pr2, history_ok(WalkSrc{g.walk, g.rev_edges, g.rev_start}, wc, wv, a.nflags, k, a.M, path, L, err))) : false;
                             if (ok && chk && from <= oc && oc < to && vq >= a.M) *err = GKI_ERR_NOT_ONE_REF_SUCC;
                             if (!ok) to = from;
                         }
                         if (GEN && from < 0 && from < to) from = 0;      // offset -1 has no record
                         if (from < to) {
                             uint32_t per_window = a.one_node ? 1u : (uint32_t)(L + 1);
-                            if (GEN && a.store) per_window = (uint32_t)stored_nodes(a.store, path, L + 1, a.one_node != 0);
+                            if (GEN && a.store) { path[1] = pr1; path[2] = pr2; per_window = (uint32_t)stored_nodes(a.store, path, L + 1, a.one_node != 0); }
                             count += (uint32_t)(to - from) * per_window;
                         }
                         // the graph ends before the window of oc is complete (graph start): the search saw what there is
@@ -656,7 +659,8 @@ struct LevelEmit {               // a suspended level of the emit walk
 };
 
 template <bool HAS_LOSSY, int FMT, bool ALL, bool GEN>
-__global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
+// (general one-node variants in the flat layouts: LDS allows 4 workgroups per CU; without the request they take 129 VGPRs)
+__global__ __launch_bounds__(256, (GEN && !ALL && FMT != 1) ? 4 : 1) void k_emit_boundary_one(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
                                                            const uint32_t *__restrict__ bcount,
                                                            const int64_t *__restrict__ rec_base,
                                                            const int64_t *__restrict__ bnd_shift,
@@ -670,6 +674,9 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
     below0.ctx = 0; below0.maf = 0.0; below0.cur = below0.end = below0.mn = 0; below0.cum = below0.vc = below0.evf = below0.evt = 0;
     int32_t path[(ALL || GEN) ? MAXN : 1]; // all-nodes mode / general graphs: the node of every level of the walk (level 0 = the end node)
     uint8_t lvl_a[GEN ? MAXN : 1];         // general graphs: `a` of the suspended levels (see history_ok)
+    constexpr bool LAZY = GEN && !ALL;     // path levels 1, 2 and lvl_a[1] in registers, see k_count_boundary
+    int32_t pr1 = 0, pr2 = 0;
+    uint8_t a_l1 = 0;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     EvQueue<FMT, ALL> &q = s_q[wib];
@@ -741,7 +748,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                         const LevelEmit b = L == 1 ? below0 : below[L - 1];
                         t_cur = b.cur; t_end = b.end; t_cum = b.cum; t_vc = b.vc; t_evf = b.evf; t_evt = b.evt;
                         t_ctx = b.ctx; t_mn = b.mn; t_maf = b.maf;
-                        if (GEN) t_a = lvl_a[L];
+                        if (GEN) t_a = (LAZY && L == 1) ? a_l1 : lvl_a[L];
                     }
                 } else {
                     const int32_t qn = cached_preds_next(g, wc, wv, &t_cur);
@@ -755,14 +762,15 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                     } else {
                         aq = t_a ? t_a : ((fq & (GKI_NODE_REF | GKI_NODE_FORCED)) ? 0 : vq);
                         take = !(fq & GKI_NODE_DEAD) && !(aq && vq - aq >= a.M) &&
-                               !((fq & GKI_NODE_HFS) && !(a.nflags[path[L - 1]] & GKI_NODE_FORCED));
+                               !((fq & GKI_NODE_HFS) && !(a.nflags[!LAZY ? path[L - 1] : L == 1 ? (int32_t)n : L == 2 ? pr1 : L == 3 ? pr2 : path[L - 1]] & GKI_NODE_FORCED));
                     }
                     if (take) {
                         if (L >= MAXN - 1) {
                             *err = GKI_ERR_WINDOW_TOO_DEEP;
                         } else {
                             const int s = wq.size, c = t_cum;
-                            if (ALL || GEN) path[L] = qn;
+                            if (LAZY) { if (L == 1) pr1 = qn; else if (L == 2) pr2 = qn; else path[L] = qn; }
+                            else if (ALL || GEN) path[L] = qn;
                             const int32_t mn = qn < t_mn ? qn : t_mn;
                             const double maf = fmin(t_maf, FMT == 1 ? g.allele_freq[qn] : (double)wq.af);   // np.min, kmer_finder.py:143
                             bool deeper;
@@ -778,7 +786,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                                 if (GEN && from < to && !(fq & (GKI_NODE_T | GKI_NODE_SIMPLE))) {      // a history before q?
                                     // (fq >> 8: no history holds more variant nodes in the k bases before q -- if even
                                     // that many fit under the limit, any history that enters q will do, and q is entered)
-                                    const bool ok = (fq & GKI_NODE_NESTED) ? (vq + (int)(fq >> 8) < a.M || history_ok(WalkSrc{g.walk, g.rev_edges, g.rev_start}, wc, wv, a.nflags, k, a.M, path, L, err)) : false;
+                                    const bool ok = (fq & GKI_NODE_NESTED) ? (vq + (int)(fq >> 8) < a.M || (LAZY ? (void)(path[1] = pr1, path[2] = pr2) : (void)0, history_ok(WalkSrc{g.walk, g.rev_edges, g.rev_start}, wc, wv, a.nflags, k, a.M, path, L, err))) : false;
                                     if (!ok) to = from;
                                 }
                                 const int tq = s < k - 1 - c ? s : k - 1 - c;
@@ -791,7 +799,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
                                 b.cur = t_cur; b.end = t_end; b.cum = (uint8_t)t_cum; b.vc = (uint8_t)t_vc;
                                 b.evf = (uint8_t)t_evf; b.evt = (uint8_t)t_evt; b.ctx = t_ctx; b.mn = t_mn; b.maf = t_maf;
                                 if (L == 1) below0 = b; else below[L - 1] = b;
-                                if (GEN) { lvl_a[L] = (uint8_t)t_a; t_a = aq; }
+                                if (GEN) { if (LAZY && L == 1) a_l1 = (uint8_t)t_a; else lvl_a[L] = (uint8_t)t_a; t_a = aq; }
                                 preds_begin(g, wq, qn, &t_cur, &t_end);
                                 t_cum = new_cum; t_vc = vq;
                                 t_evf = from < to ? from : 0; t_evt = from < to ? to : 0;
@@ -806,6 +814,7 @@ __global__ __launch_bounds__(256) void k_emit_boundary_one(DevGraph g, FindArgs 
             }
             int e_nls = e_nl;                        // nodes of the window that get a record (only_store_nodes)
             if (GEN && a.store && ev) {
+                if (LAZY) { path[1] = pr1; path[2] = pr2; }
                 e_nls = stored_nodes(a.store, path, e_nl, !ALL);
                 if (e_nls == 0) ev = false;
             }
