@@ -1104,8 +1104,12 @@ template <int FMT, bool ALL>
 static int launch_boundary_mode(gki_finder *f, const DevGraph &d, const FindArgs &a, typename OutSel<FMT>::T out, hipStream_t s2,
                                 const dim3 grid, const dim3 block, const int64_t *base, const int64_t *shift) {
     const int emit_pad = GKI_KNOB("GKI_EMIT_LDS_PAD", 0);  // tuning builds: unused dynamic LDS, to lower the occupancy
-    if (a.nflags)          // general graphs always carry a lossy table (0xFFFF everywhere when there is none)
+    // the lossy-restart logic costs 0.4-0.5 ms (emit) + 0.1-0.2 ms (count) per step on the 3 Gbp graphs even when the run has
+    // no such point (a lossy[q] load per predecessor step): every variant exists without it
+    if (a.nflags && a.has_lossy)
         hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, true>), grid, block, emit_pad, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
+    else if (a.nflags)
+        hipLaunchKernelGGL((k_emit_boundary_one<false, FMT, ALL, true>), grid, block, emit_pad, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
     else if (a.has_lossy)
         hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, false>), grid, block, emit_pad, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
     else
@@ -1304,7 +1308,6 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
         if (!f->nflags) HIP_TRY(gki_dev_malloc((void **)&f->nflags, (size_t)d.n_nodes * 2));
         HIP_TRY(hipMemcpyAsync(f->nflags, p->h_node_flags, (size_t)d.n_nodes * 2, hipMemcpyHostToDevice, s));
         a.nflags = f->nflags;
-        if (!a.has_lossy) HIP_TRY(hipMemsetAsync(f->lossy, 0xFF, (size_t)d.n_nodes * 2, s));   // the general kernels always read it
     }
     if (p->h_node_rank) {
         // node ids are not topological: membership by rank, every node is looked at
@@ -1328,8 +1331,11 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
         const int64_t want = ceil_div(n_run, 256), cap = GKI_KNOB("GKI_CNT_BLOCKS", 1 << 30);
         const int count_grid = (int)(want < cap ? want : cap);
         const int cnt_pad = GKI_KNOB("GKI_CNT_LDS_PAD", 0);   // tuning builds: unused dynamic LDS, to lower the occupancy
-        if (a.nflags)
+        if (a.nflags && a.has_lossy)
             hipLaunchKernelGGL((k_count_boundary<true, true>), dim3(count_grid), dim3(256), cnt_pad, s, d, a, f->lossy,
+                               f->bcount, f->total, f->d_err);
+        else if (a.nflags)
+            hipLaunchKernelGGL((k_count_boundary<false, true>), dim3(count_grid), dim3(256), cnt_pad, s, d, a, f->lossy,
                                f->bcount, f->total, f->d_err);
         else if (a.has_lossy)
             hipLaunchKernelGGL((k_count_boundary<true, false>), dim3(count_grid), dim3(256), cnt_pad, s, d, a, f->lossy,

@@ -29,6 +29,8 @@ def funcs(txt):
             if re.match(r"\s*\.(loc|file|cfi)", l) or re.match(r"\s*;", l):
                 continue
             l = l.split(";")[0].rstrip()
+            l = re.sub(r"\.LBB\d+_", ".LBB_", l)       # block labels carry the function's index in the file
+            l = re.sub(r"\.L(tmp|func_begin|func_end|JTI)\d+(_\d+)?", r".L\1", l)
             if l:
                 lines.append(l)
         res[m.group(1)] = lines
