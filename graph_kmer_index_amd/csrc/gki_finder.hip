@@ -117,14 +117,15 @@ constexpr int WC_REV = 192;
 struct WalkCache {
     uint4 rec[2 * (WC_HALO + 64)];
     int32_t rev[WC_REV];
-    uint16_t flg[WC_HALO + 64];      // general graphs: the flag word of the staged nodes
+    uint32_t flg[WC_HALO + 64];      // per staged node: flag word (general graphs) | lossy-restart offset << 16 (runs with such points)
 };
 struct WalkView {                // wave-uniform bounds of what the cache holds
     int64_t lo, hi;              // nodes
     int64_t r0, r1;              // rev_edges entries
 };
 __device__ __forceinline__ WalkView stage_walk(const DevGraph &g, WalkCache &wc, int64_t base, int lane,
-                                               const uint16_t *__restrict__ nflags = nullptr) {
+                                               const uint16_t *__restrict__ nflags = nullptr,
+                                               const uint16_t *__restrict__ lossy = nullptr) {
     WalkView v;
     v.lo = base - WC_HALO < 0 ? 0 : base - WC_HALO;
     v.hi = base + 64 > g.n_nodes ? g.n_nodes : base + 64;
@@ -142,16 +143,22 @@ __device__ __forceinline__ WalkView stage_walk(const DevGraph &g, WalkCache &wc,
     for (int u = 0; u < RC; u++) { const int j = u * 64 + lane; t[u] = j < n16 ? src[j] : make_uint4(0, 0, 0, 0); }
 #pragma unroll
     for (int u = 0; u < VC; u++) { const int j = u * 64 + lane; r[u] = j < n_rev ? g.rev_edges[v.r0 + j] : 0; }
-    uint16_t fl[2] = {0, 0};
-    if (nflags) {
+    // flags and lossy-restart offsets (0xFFFF = none) of the staged nodes share one LDS word: the walk asks for both at
+    // every predecessor step, and lossy[q] from global memory was a dependent load per step (+0.15 ms count, +0.38 ms emit
+    // on the 3 Gbp graph); a separate LDS array for it pushed the general emit variant into spilling (+0.6 ms)
+    uint32_t fl[2] = {0xFFFF0000u, 0xFFFF0000u};
+    if (nflags || lossy) {
 #pragma unroll
-        for (int u = 0; u < 2; u++) { const int j = u * 64 + lane; if (j < (int)(v.hi - v.lo)) fl[u] = nflags[v.lo + j]; }
+        for (int u = 0; u < 2; u++) {
+            const int j = u * 64 + lane;
+            if (j < (int)(v.hi - v.lo)) fl[u] = (nflags ? (uint32_t)nflags[v.lo + j] : 0u) | ((lossy ? (uint32_t)lossy[v.lo + j] : 0xFFFFu) << 16);
+        }
     }
 #pragma unroll
     for (int u = 0; u < RC; u++) wc.rec[u * 64 + lane] = t[u];
 #pragma unroll
     for (int u = 0; u < VC; u++) wc.rev[u * 64 + lane] = r[u];
-    if (nflags) {
+    if (nflags || lossy) {
         wc.flg[lane] = fl[0];
         if (lane < WC_HALO) wc.flg[64 + lane] = fl[1];
     }
@@ -162,27 +169,6 @@ __device__ __forceinline__ WalkView stage_walk(const DevGraph &g, WalkCache &wc,
 // of a selected address, which takes the global address path either way (seen in the ISA: flat_load_dwordx4, no ds_read)
 __device__ __forceinline__ void opaque(uint4 &x) { asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w)); }
 __device__ __forceinline__ void opaque(int32_t &x) { asm volatile("" : "+v"(x)); }
-
-// Lossy-restart offsets (uint16 per node, 0xFFFF = none) of the staged nodes, next to the walk cache: the walk asks for
-// lossy[q] at every predecessor step, and from global memory that was a dependent load per step (+0.15 ms count,
-// +0.38 ms emit on the 3 Gbp graph for a run with no such point at all; staged: +0.09 / +0.07 ms).  Same window as
-// stage_walk.  Not used by the general variants: measured no gain there (count unchanged, emit +0.08 ms), DESIGN.md 4.2.
-__device__ __forceinline__ void stage_lossy(uint16_t *lsy, const uint16_t *__restrict__ lossy, const DevGraph &g, int64_t base, int lane) {
-    const int64_t lo = base - WC_HALO < 0 ? 0 : base - WC_HALO, hi = base + 64 > g.n_nodes ? g.n_nodes : base + 64;
-    const int nn = (int)(hi - lo);
-    const uint16_t x0 = lane < nn ? lossy[lo + lane] : (uint16_t)0xFFFF;
-    const uint16_t x1 = (lane < WC_HALO && 64 + lane < nn) ? lossy[lo + 64 + lane] : (uint16_t)0xFFFF;
-    lsy[lane] = x0;
-    if (lane < WC_HALO) lsy[64 + lane] = x1;
-    __builtin_amdgcn_wave_barrier();
-}
-__device__ __forceinline__ int cached_lossy(const uint16_t *__restrict__ lossy, const uint16_t *lsy, const WalkView &v, int64_t q) {
-    const bool in = q >= v.lo && q < v.hi;
-    int32_t c = lsy[in ? q - v.lo : 0];
-    opaque(c);
-    if (!in) c = lossy[q];
-    return c == 0xFFFF ? -1 : c;
-}
 
 __device__ __forceinline__ NodeWalk cached_walk(const DevGraph &g, const WalkCache &wc, const WalkView &v, int64_t q) {
     const bool in = q >= v.lo && q < v.hi;
@@ -204,13 +190,16 @@ __device__ __forceinline__ NodeWalk cached_walk(const DevGraph &g, const WalkCac
     w.pad = 0;
     return w;
 }
-__device__ __forceinline__ uint16_t cached_flag(const uint16_t *__restrict__ nflags, const WalkCache &wc, const WalkView &v, int64_t q) {
+// flag word (low 16 bits, 0 without nflags) and lossy-restart offset (high 16 bits, 0xFFFF = none) of node q
+__device__ __forceinline__ uint32_t cached_flag(const uint16_t *__restrict__ nflags, const uint16_t *__restrict__ lossy,
+                                                const WalkCache &wc, const WalkView &v, int64_t q) {
     const bool in = q >= v.lo && q < v.hi;
-    int32_t f = wc.flg[in ? q - v.lo : 0];
+    int32_t f = (int32_t)wc.flg[in ? q - v.lo : 0];
     opaque(f);
-    if (!in) f = nflags[q];
-    return (uint16_t)f;
+    if (!in) f = (int32_t)((nflags ? (uint32_t)nflags[q] : 0u) | ((lossy ? (uint32_t)lossy[q] : 0xFFFFu) << 16));
+    return (uint32_t)f;
 }
+__device__ __forceinline__ int lossy_in(uint32_t fw) { const int c = (int)(fw >> 16); return c == 0xFFFF ? -1 : c; }
 __device__ __forceinline__ int32_t cached_preds_next(const DevGraph &g, const WalkCache &wc, const WalkView &v, int32_t *cur) {
     if (*cur < 0) { const int32_t q = ~*cur; *cur = 0; return q; }
     const int32_t i = (*cur)++;
@@ -279,7 +268,7 @@ __device__ __noinline__ bool history_ok(const WalkSrc gs, const WalkCache &wc, c
         int between = 0, c = 0;                  // bases / variant nodes of path[i+1..L]
         for (int i = L; i >= 0; i--) {
             const int32_t y = path[i];
-            const uint16_t fy = cached_flag(nf, wc, wv, y);
+            const uint16_t fy = (uint16_t)cached_flag(nf, nullptr, wc, wv, y);
             if (!(fy & (GKI_NODE_REF | GKI_NODE_FORCED))) {
                 const int m = M - c;
                 if (m <= 0) return false;
@@ -304,7 +293,7 @@ __device__ __noinline__ bool history_ok(const WalkSrc gs, const WalkCache &wc, c
         if (budget == 0) { *err = GKI_ERR_WINDOW_TOO_DEEP; return false; }
         if (hcur[h] >= hend[h]) { if (h == 0) return false; h--; continue; }
         const int32_t p = cached_preds_next(g, wc, wv, &hcur[h]);
-        const uint8_t fp = (uint8_t)cached_flag(nf, wc, wv, p);
+        const uint8_t fp = (uint8_t)cached_flag(nf, nullptr, wc, wv, p);
         if (fp & GKI_NODE_DEAD) continue;
         const int32_t child = h == 0 ? path[L] : hn[h - 1];
         if ((fp & GKI_NODE_HFS) && !(nf[child] & GKI_NODE_FORCED)) continue;      // edge removed by a forced sibling
@@ -366,8 +355,6 @@ __global__ __launch_bounds__(256, GEN ? 8 : 1) void k_count_boundary(DevGraph g,
                                                         uint32_t *__restrict__ bcount, uint32_t *__restrict__ total,
                                                         int *__restrict__ err) {
     __shared__ WalkCache s_wc[4];
-    constexpr bool LSY = HAS_LOSSY && !GEN;      // staged lossy offsets: see stage_lossy (no gain in the general variants)
-    __shared__ uint16_t s_lsy[LSY ? 4 : 1][WC_HALO + 64];
     LevelLo below[MAXN];
     LevelLo below0 = {0, 0, 0, 0, 0};  // the first suspended level stays in registers (SNP/indel graphs never go deeper)
     int32_t path[GEN ? MAXN : 1];      // general graphs: the node of every level (level 0 = the end node)
@@ -380,14 +367,12 @@ __global__ __launch_bounds__(256, GEN ? 8 : 1) void k_count_boundary(DevGraph g,
     WalkCache &wc = s_wc[wib];
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t base = a.n0 + (int64_t)blockIdx.x * blockDim.x + wib * 64; base < a.n1; base += stride) {
-        uint16_t *lsy = s_lsy[LSY ? wib : 0];
-        if (LSY) stage_lossy(lsy, lossy, g, base, lane);
-        const WalkView wv = stage_walk(g, wc, base, lane, GEN ? a.nflags : nullptr);
+        const WalkView wv = stage_walk(g, wc, base, lane, GEN ? a.nflags : nullptr, HAS_LOSSY ? lossy : nullptr);
         const int64_t n = base + lane;
         if (n >= a.n1) continue;
         const NodeWalk wn = cached_walk(g, wc, wv, n);
         const int32_t size = wn.size;
-        const uint16_t fn = GEN ? cached_flag(a.nflags, wc, wv, n) : (uint16_t)0;
+        const uint16_t fn = GEN ? (uint16_t)cached_flag(a.nflags, HAS_LOSSY ? lossy : nullptr, wc, wv, n) : (uint16_t)0;
         const bool reach_n = !(GEN && (fn & GKI_NODE_DEAD));
         const int32_t bl = bnd_len_of(g, a, lossy, n, size);
         uint32_t count = 0;
@@ -427,7 +412,8 @@ __global__ __launch_bounds__(256, GEN ? 8 : 1) void k_count_boundary(DevGraph g,
                     }
                     const int32_t q = cached_preds_next(g, wc, wv, &t_cur);
                     const NodeWalk wq = cached_walk(g, wc, wv, q);
-                    const uint16_t fq = GEN ? cached_flag(a.nflags, wc, wv, q) : (uint16_t)0;
+                    const uint32_t fwq = (GEN || HAS_LOSSY) ? cached_flag(GEN ? a.nflags : nullptr, HAS_LOSSY ? lossy : nullptr, wc, wv, q) : 0u;
+                    const uint16_t fq = (uint16_t)fwq;
                     if (GEN) {
                         if (fq & GKI_NODE_DEAD) continue;
                         if ((fq & GKI_NODE_HFS) && !(a.nflags[L == 1 ? (int32_t)n : L == 2 ? pr1 : L == 3 ? pr2 : path[L - 1]] & GKI_NODE_FORCED)) continue;
@@ -450,7 +436,7 @@ __global__ __launch_bounds__(256, GEN ? 8 : 1) void k_count_boundary(DevGraph g,
                     } else {
                         int from = k - 1 - c - s; if (from < w_lo) from = w_lo;
                         int to = k - 1 - c; if (to > hi) to = hi;
-                        const int cq = LSY ? cached_lossy(lossy, lsy, wv, q) : (HAS_LOSSY ? lossy_of(lossy, q) : -1);
+                        const int cq = HAS_LOSSY ? lossy_in(fwq) : -1;
                         if (HAS_LOSSY && cq >= 0) {
                             const int min_ok = k - 1 - c - s + cq; if (from < min_ok) from = min_ok;
                             // the search restarted at (q, cq) with no history: at an end position whose window would
@@ -667,8 +653,6 @@ __global__ __launch_bounds__(256, (GEN && !ALL && FMT != 1) ? 4 : 1) void k_emit
                                                            typename OutSel<FMT>::T out, int *__restrict__ err) {
     __shared__ EvQueue<FMT, ALL> s_q[4];
     __shared__ WalkCache s_wc[4];
-    constexpr bool LSY = HAS_LOSSY && !GEN;      // staged lossy offsets: see stage_lossy (no gain in the general variants)
-    __shared__ uint16_t s_lsy[LSY ? 4 : 1][WC_HALO + 64];
     LevelEmit below[MAXN];
     LevelEmit below0;                  // the first suspended level stays in registers
     below0.ctx = 0; below0.maf = 0.0; below0.cur = below0.end = below0.mn = 0; below0.cum = below0.vc = below0.evf = below0.evt = 0;
@@ -687,9 +671,7 @@ __global__ __launch_bounds__(256, (GEN && !ALL && FMT != 1) ? 4 : 1) void k_emit
     const int64_t n_threads = (int64_t)gridDim.x * blockDim.x;
     int n_ev = 0, my_cnt = 0;              // steps in the queue; of them, queued by this lane
     for (int64_t base = a.n0 + (int64_t)blockIdx.x * blockDim.x + wib * 64; base < a.n1; base += n_threads) {
-        uint16_t *lsy = s_lsy[LSY ? wib : 0];
-        if (LSY) stage_lossy(lsy, lossy, g, base, lane);
-        const WalkView wv = stage_walk(g, wc, base, lane, GEN ? a.nflags : nullptr);
+        const WalkView wv = stage_walk(g, wc, base, lane, GEN ? a.nflags : nullptr, HAS_LOSSY ? lossy : nullptr);
         const int64_t n = base + lane;
         int L = 0, o_lo = 0, hi = 0;
         int64_t idx = 0, pos0 = 0;
@@ -702,7 +684,7 @@ __global__ __launch_bounds__(256, (GEN && !ALL && FMT != 1) ? 4 : 1) void k_emit
         int t_a = 0;
         if (n < a.n1 && bcount[n] > 0) {
             const NodeWalk wn = cached_walk(g, wc, wv, n);
-            const uint16_t fn = GEN ? cached_flag(a.nflags, wc, wv, n) : (uint16_t)0;
+            const uint16_t fn = GEN ? (uint16_t)cached_flag(a.nflags, HAS_LOSSY ? lossy : nullptr, wc, wv, n) : (uint16_t)0;
             const int32_t bl = bnd_len_of(g, a, lossy, n, wn.size);
             idx = rec_base[n] + *bnd_shift;
             pos0 = g.pos_base[n];
@@ -753,7 +735,8 @@ __global__ __launch_bounds__(256, (GEN && !ALL && FMT != 1) ? 4 : 1) void k_emit
                 } else {
                     const int32_t qn = cached_preds_next(g, wc, wv, &t_cur);
                     const NodeWalk wq = cached_walk(g, wc, wv, qn);
-                    const uint16_t fq = GEN ? cached_flag(a.nflags, wc, wv, qn) : (uint16_t)0;
+                    const uint32_t fwq = (GEN || HAS_LOSSY) ? cached_flag(GEN ? a.nflags : nullptr, HAS_LOSSY ? lossy : nullptr, wc, wv, qn) : 0u;
+                    const uint16_t fq = (uint16_t)fwq;
                     const int vq = t_vc + (GEN ? ((fq & GKI_NODE_REF) ? 0 : 1) : (wq.is_ref ? 0 : 1));
                     bool take;
                     int aq = 0;
@@ -781,7 +764,7 @@ __global__ __launch_bounds__(256, (GEN && !ALL && FMT != 1) ? 4 : 1) void k_emit
                             } else {
                                 from = k - 1 - c - s; if (from < o_lo) from = o_lo;
                                 to = k - 1 - c; if (to > hi) to = hi;
-                                const int cq = LSY ? cached_lossy(lossy, lsy, wv, qn) : (HAS_LOSSY ? lossy_of(lossy, qn) : -1);
+                                const int cq = HAS_LOSSY ? lossy_in(fwq) : -1;
                                 if (HAS_LOSSY && cq >= 0) { const int min_ok = k - 1 - c - s + cq; if (from < min_ok) from = min_ok; }
                                 if (GEN && from < to && !(fq & (GKI_NODE_T | GKI_NODE_SIMPLE))) {      // a history before q?
                                     // (fq >> 8: no history holds more variant nodes in the k bases before q -- if even
