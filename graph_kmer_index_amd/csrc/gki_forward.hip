@@ -129,6 +129,8 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
 // the occupancy request the compiler expands the per-level stacks into register select chains (178 VGPRs = 2 waves per
 // SIMD, 2 200 instructions); with it 25-32 VGPRs, 700 instructions, 8 waves.  tools/bench_forward.py, 1.14e7 starts on the
 // 1 Gbp graph, same box: 8.29 -> 5.15 ms per batch (all nodes), 6.81 -> 3.0 ms (one node per k-mer).
+// Tried and dropped: carrying the path's smallest node and minimum allele frequency down the walk instead of looping
+// over the path at every finished k-mer -- two more scratch stores per step cost more than the loops (5.0 -> 5.2 ms).
 template <bool EMIT>
 __global__ __launch_bounds__(64, 8) void k_forward(DevGraph g, int k, int M, int one_node, const uint8_t *__restrict__ follow,
                                                 const int32_t *__restrict__ nodes,
