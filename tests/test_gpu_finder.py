@@ -398,6 +398,34 @@ def test_kmers_from_positions_random_vs_oracle():
         assert_same_records(got, exp, exact_order=True)
 
 
+def test_kmers_from_positions_when_node_ids_do_not_grow_along_the_path():
+    # an allele that bridges a bubble is numbered after the nodes it skips (overlapping_bubble_graph): a forward path through
+    # it visits node ids out of order, and the records of a k-mer still come per distinct node in ascending order
+    # (np.unique, kmer_finder.py:134) -- the kernel's selection path, not its ascending-path shortcut
+    rng = np.random.default_rng(33)
+    out_of_order = 0
+    for it in range(40):
+        k = int(rng.integers(4, 14))
+        M = int(rng.choice([2, 4, 100]))
+        seqs, edges, lin, af = overlapping_bubble_graph(rng, n_var=int(rng.integers(3, 10)), min_ref=1, max_ref=k)
+        g = GraphArrays.from_dicts(seqs, edges, lin, af)
+        nodes = rng.integers(0, g.n_nodes, size=16)
+        offs = [int(rng.integers(0, max(1, g.node_size[n]))) for n in nodes]
+        f = DenseKmerFinder(g, k, only_save_one_node_per_kmer=False, max_variant_nodes=M)
+        try:
+            exp = [oracle.find_from_position(g, k, int(n), int(o), False, M) for n, o in zip(nodes, offs)]
+        except oracle.OracleError:
+            continue
+        f.find_kmers_starting_at_positions(nodes, offs)
+        got = finder_cols(f)
+        exp = {key: np.concatenate([e[key] for e in exp]) for key in exp[0]}
+        assert_same_records(got, exp, exact_order=True)
+        # did a k-mer's window really contain the bridging allele (the highest id) before a lower one?
+        bridge = g.n_nodes - 1
+        out_of_order += int(np.any((exp["nodes"] == bridge) & (exp["start_nodes"] < bridge)))
+    assert out_of_order >= 5
+
+
 def test_only_follow_nodes_from_position():
     # unique_variant_kmers.py:91-96: only_store_nodes = only_follow_nodes = {variant node}, early-stop search
     rng = np.random.default_rng(41)
