@@ -229,3 +229,23 @@ def test_product_library_has_no_tuning_or_debug_switches():
     for name in (b"GKI_DBG", b"GKI_SW", b"GKI_NE_CAP", b"GKI_RUN_BLOCKS", b"GKI_BND_BLOCKS", b"GKI_INT_BLOCKS",
                  b"GKI_OVERLAP_EMIT", b"GKI_BOUNDARY_FIRST", b"g_dbg_skip_expand"):
         assert name not in blob, name
+
+
+def test_early_stop_bench_start_positions_follow_the_reference_pattern():
+    # bench.py's `early_stop_search` record and tools/bench_forward.py share this generator: per SNP site the linear-ref
+    # positions 2, 6, ... 26 bases before the variant (unique_variant_kmers.py:119-140 at k=31), on the segment in front
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_forward import start_positions
+    from graph_kmer_index_amd.graph import synthetic_snp_graph
+    g = synthetic_snp_graph(300000, 400, k=31, seed=7)
+    nodes, offs = start_positions(g, 31)
+    assert nodes.dtype == np.int32 and offs.dtype == np.int32 and len(nodes) == len(offs)
+    n_sites = int(((g.is_ref == 0) & (g.node_size == 1)).sum())
+    assert 5 * n_sites < len(nodes) <= 7 * n_sites
+    assert np.all(g.is_ref[nodes] == 1) and np.all(offs >= 0) and np.all(offs <= g.node_size[nodes])
+    assert sorted(set((g.node_size[nodes] - offs).tolist())) == [2, 6, 10, 14, 18, 22, 26]
+    assert np.all(np.diff(nodes.astype(np.int64)) >= 0)          # site order, like a loop over the variants
+    # every start's segment is followed by a bubble: its successors are a ref allele and the alt allele
+    succ_n = g.edge_start[nodes.astype(np.int64) + 1] - g.edge_start[nodes.astype(np.int64)]
+    assert np.all(succ_n == 2)
