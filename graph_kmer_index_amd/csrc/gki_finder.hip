@@ -531,7 +531,7 @@ struct EvQueue {
 };
 
 #ifdef GKI_TUNING
-__device__ int g_dbg_skip_expand = 0;     // tools/exp builds only (make tuning): 1 = phase A alone, 2 = no sort,
+__device__ int g_dbg_skip_expand = 0;     // tools/exp builds only (make tuning): 1 = phase A alone (the walk, no expansion),
                                           // 3 = phase A alone and no node lists built (all-nodes mode; nothing reads them)
                                           // 4 = phase A alone and windows over more than NLQ nodes dropped (output incomplete)
 #define GKI_DBG_SKIP_EXPAND_IS(v) (g_dbg_skip_expand == (v))
