@@ -9,7 +9,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgki_hip.so")
+# GKI_LIB selects another build of the same C ABI (the A/B scripts of tools/exp compare builds this way instead of
+# copying a variant over the product library)
+LIB_PATH = os.environ.get("GKI_LIB") or os.path.join(_HERE, "libgki_hip.so")
 
 
 class GkiError(RuntimeError):
@@ -87,6 +89,7 @@ SYMBOLS = {
     "gki_index_build": (_I32, [_P, _P, _P, _P, _I64, _U64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gki_partition_by_bucket_range": (_I32, [_P, _P, _P, _P, _I64, _U64, _I32, _P, _P, _P, _P, C.POINTER(_I64)]),
     "gki_index_build_range": (_I32, [_P, _P, _P, _P, _I64, _U64, _U64, _U64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gki_index_build_pairs": (_I32, [_P, _P, _P, _P, _I64, _U64, _U64, _U64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gki_reverse_index_build": (_I32, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
     "gki_index_lookup_count": (_I32, [C.POINTER(IndexView), _P, _I64, _I64, _P, C.POINTER(_I64)]),
     "gki_index_count_nodes": (_I32, [C.POINTER(IndexView), _P, _I64, _I64, _P, _I64]),
@@ -100,9 +103,16 @@ SYMBOLS = {
     "gki_probe_count_nodes": (_I32, [_P, _P, _I64, _I64, _P, _I64, C.POINTER(_I64)]),
     "gki_probe_reads_count_nodes": (_I32, [_P, _P, _P, _I64, _I32, _I32, _I64, _P, _I64, C.POINTER(_I64), C.POINTER(_I64)]),
     "gki_measure_random_loads": (_I32, [_I64, _I64, C.POINTER(C.c_double)]),
+    "gki_measure_store_bw": (_I32, [_P, _P, _P, _P, _I64, C.POINTER(C.c_double)]),
+    "gki_simulate_reads": (_I32, [_P, _I64, _I64, _I32, _U64, C.c_double, C.c_double, _I64, _P]),
     "gki_comm_get_unique_id": (_I32, [_P]),
     "gki_comm_create": (_I32, [C.POINTER(_P), _I32, _I32, _P]),
     "gki_comm_destroy": (_I32, [_P]),
+    "gki_comm_info": (_I32, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gki_device_bus_id": (_I32, [C.c_char_p, _I32]),
+    "gki_ipc_export": (_I32, [_P, _P, C.POINTER(_I64)]),
+    "gki_ipc_open": (_I32, [_P, C.POINTER(_P)]),
+    "gki_ipc_close": (_I32, [_P]),
     "gki_comm_alltoall_flat": (_I32, [_P, C.POINTER(_I64), _P, _P, _P, _P, C.POINTER(_I64), _P, _P, _P, _P]),
     "gki_comm_allreduce_u32": (_I32, [_P, _P, _I64]),
     "gki_comm_allgather_flat": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

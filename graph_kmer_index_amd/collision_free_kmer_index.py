@@ -34,9 +34,11 @@ class DeviceIndex:
                               self.modulo, self.n, self.bucket_begin, self.n_buckets)
 
     @classmethod
-    def build(cls, dflat, modulo=452930477, skip_frequencies=False, want_permutation=False, bucket_begin=0, n_buckets=None):
+    def build(cls, dflat, modulo=452930477, skip_frequencies=False, want_permutation=False, bucket_begin=0, n_buckets=None,
+              pairs_form=False):
         """gki_index_build(_range) on device-resident FlatKmers columns.  With a bucket range, `dflat` must hold only
-        records of that range (one slice of `partition_by_bucket_range`)."""
+        records of that range (one slice of `partition_by_bucket_range`).  pairs_form=True runs the pair-sorting form of
+        the build (gki_index_build_pairs) instead of the row-carrying one; the results are identical."""
         _lib.require_device()
         n = dflat.n
         na = max(n, 1)
@@ -46,7 +48,8 @@ class DeviceIndex:
                   _lib.DeviceArray(na, np.float32), _lib.DeviceArray(na, np.uint16), bucket_begin, nb)
         perm = _lib.DeviceArray(na, np.uint32) if want_permutation else None
         out.permutation = perm
-        _lib.check(_lib.load().gki_index_build_range(
+        fn = _lib.load().gki_index_build_pairs if pairs_form else _lib.load().gki_index_build_range
+        _lib.check(fn(
             dflat.hashes.ptr, dflat.nodes.ptr, dflat.ref_offsets.ptr, dflat.allele_frequencies.ptr, n, int(modulo),
             int(bucket_begin), nb, int(bool(skip_frequencies)), out.hashes_to_index.ptr, out.n_kmers.ptr, out.kmers.ptr,
             out.nodes.ptr, out.ref_offsets.ptr, out.allele_frequencies.ptr, out.frequencies.ptr,

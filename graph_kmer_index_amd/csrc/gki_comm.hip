@@ -29,6 +29,8 @@ struct Rccl {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
@@ -44,6 +46,7 @@ int load_rccl() {
     SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
     SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd")
     SYM(GetErrorString, "ncclGetErrorString") SYM(AllReduce, "ncclAllReduce")
+    SYM(CommCount, "ncclCommCount") SYM(CommUserRank, "ncclCommUserRank")
 #undef SYM
     g_rccl.h = h;
     return GKI_OK;
@@ -76,6 +79,14 @@ int gki_comm_create(gki_comm **out, int world_size, int rank, const void *h_id) 
     HIP_TRY(hipStreamCreate(&c->stream));
     NCCL_TRY(g_rccl.CommInitRank(&c->comm, world_size, id, rank));
     *out = c;
+    return GKI_OK;
+}
+
+int gki_comm_info(gki_comm *c, int *rccl_world, int *rccl_rank) {
+    *rccl_world = 0; *rccl_rank = -1;
+    if (!c) return gki_set_error(GKI_ERR_BAD_ARG, "no communicator");
+    NCCL_TRY(g_rccl.CommCount(c->comm, rccl_world));
+    NCCL_TRY(g_rccl.CommUserRank(c->comm, rccl_rank));
     return GKI_OK;
 }
 
@@ -170,6 +181,42 @@ int gki_comm_allreduce_u32(gki_comm *c, void *d_buf, int64_t n) {
     HIP_TRY(hipDeviceSynchronize());                  // the counts were produced on other streams
     if (c->world > 1) NCCL_TRY(g_rccl.AllReduce(d_buf, d_buf, (size_t)n, ncclUint32, ncclSum, c->comm, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return GKI_OK;
+}
+
+// ---- ranks that share ONE device (a multi-rank run rehearsed on a single GPU): RCCL refuses a communicator with two
+// ranks on the same device ("invalid usage", duplicate GPU), so such ranks exchange through HIP IPC handles instead --
+// every rank exports its buffers, the peers open them and copy device-to-device.  The handles travel over the
+// control plane (parallel.SharedDeviceComm).
+int gki_device_bus_id(char *buf, int len) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetPCIBusId(buf, len, dev));
+    return GKI_OK;
+}
+
+int gki_ipc_export(const void *d_ptr, void *h_handle, int64_t *offset) {
+    static_assert(sizeof(hipIpcMemHandle_t) == GKI_IPC_HANDLE_BYTES, "hipIpcMemHandle_t size");
+    void *base = nullptr;
+    size_t size = 0;
+    HIP_TRY(hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)d_ptr));
+    hipIpcMemHandle_t h;
+    HIP_TRY(hipIpcGetMemHandle(&h, base));
+    memcpy(h_handle, &h, sizeof(h));
+    *offset = (int64_t)((const char *)d_ptr - (const char *)base);
+    return GKI_OK;
+}
+
+int gki_ipc_open(const void *h_handle, void **d_base) {
+    hipIpcMemHandle_t h;
+    memcpy(&h, h_handle, sizeof(h));
+    *d_base = nullptr;
+    HIP_TRY(hipIpcOpenMemHandle(d_base, h, hipIpcMemLazyEnablePeerAccess));
+    return GKI_OK;
+}
+
+int gki_ipc_close(void *d_base) {
+    if (d_base) HIP_TRY(hipIpcCloseMemHandle(d_base));
     return GKI_OK;
 }
 

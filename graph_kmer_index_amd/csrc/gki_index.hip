@@ -13,6 +13,14 @@
 #include "gki_common.h"
 #include <mutex>
 
+int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
+                         uint64_t modulo, uint64_t bucket_begin, uint64_t n_buckets, int skip_frequencies,
+                         void *d_hashes_to_index, void *d_n_kmers, void *d_out_kmers, void *d_out_nodes,
+                         void *d_out_ref_offsets, void *d_out_af32, void *d_out_frequencies, void *d_out_permutation, int *done);
+int gki_frequencies_for_rows(const int64_t *d_row_begin, const int64_t *d_row_end, int n_ranges, uint64_t modulo,
+                             uint64_t bucket_begin, const void *d_hashes_to_index, const void *d_n_kmers,
+                             const void *d_kmers, const void *d_refs, void *d_freq, int64_t n, hipStream_t s);
+
 namespace {
 
 constexpr int RB = 256;             // threads per block in the radix kernels
@@ -476,9 +484,97 @@ __global__ __launch_bounds__(256) void k_gather_pairs(const uint32_t *__restrict
 
 }  // namespace
 
+// Frequencies of the buckets in large_list (more than SMALL_BUCKET records each): sizes -> scratch offsets -> one block
+// per bucket.  `sizes` is scratch for n_large uint32.
+static int frequencies_large_pass(const uint32_t *large_list, unsigned int n_large, uint32_t *sizes, const void *d_hashes_to_index,
+                                  const void *d_n_kmers, const void *d_kmers, const void *d_refs, void *d_freq, hipStream_t s) {
+    int64_t *starts = nullptr;
+    Pair *scratch = nullptr;
+    void *tmp2 = nullptr;
+    hipLaunchKernelGGL(k_large_sizes, dim3(stream_grid(n_large, 256)), dim3(256), 0, s, large_list, n_large,
+                       (const uint32_t *)d_n_kmers, sizes);
+    HIP_TRY(hipGetLastError());
+    const int64_t tmp2_bytes = gki_scan_tmp_bytes(n_large);
+    int r = GKI_OK;
+    if (gki_dev_malloc((void **)&starts, ((size_t)n_large + 1) * 8) != hipSuccess) r = GKI_ERR_HIP;
+    if (r == GKI_OK && gki_dev_malloc(&tmp2, (size_t)tmp2_bytes) != hipSuccess) r = GKI_ERR_HIP;
+    if (r == GKI_OK) r = gki_scan_u32_to_i64(sizes, n_large, starts, tmp2, tmp2_bytes, s);
+    int64_t total = 0;
+    if (r == GKI_OK && hipMemcpy(&total, starts + n_large, 8, hipMemcpyDeviceToHost) != hipSuccess) r = GKI_ERR_HIP;
+    if (r == GKI_OK && gki_dev_malloc((void **)&scratch, (size_t)total * sizeof(Pair)) != hipSuccess) r = GKI_ERR_HIP;
+    if (r == GKI_OK) {
+        const unsigned grid = n_large < 2048 ? n_large : 2048;
+        hipLaunchKernelGGL(k_frequencies_large, dim3(grid), dim3(256), 0, s, large_list, n_large, (const int32_t *)d_hashes_to_index,
+                           (const uint32_t *)d_n_kmers, (const uint64_t *)d_kmers, (const uint64_t *)d_refs, starts, scratch,
+                           (uint16_t *)d_freq);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) r = GKI_ERR_HIP;
+    }
+    (void)gki_dev_free(starts); (void)gki_dev_free(tmp2); (void)gki_dev_free(scratch);
+    if (r != GKI_OK) return gki_set_error(r, "large-bucket frequency pass failed");
+    return GKI_OK;
+}
+
+// The frequency pass of the row-carrying form (gki_index_rows.hip) for the rows it left open: ranges [begin, end) of the
+// finished columns, each a whole number of buckets.  Same rule as k_frequencies_small, the bucket recomputed from the
+// k-mer.
+__global__ __launch_bounds__(256) void k_frequencies_ranges(const int64_t *__restrict__ rb, const int64_t *__restrict__ re, int n_ranges,
+                                                            uint64_t modulo, uint64_t bucket_begin,
+                                                            const int32_t *__restrict__ hashes_to_index, const uint32_t *__restrict__ n_kmers,
+                                                            const uint64_t *__restrict__ kmers, const uint64_t *__restrict__ refs,
+                                                            uint16_t *__restrict__ freq, uint32_t *__restrict__ large_list,
+                                                            unsigned int *__restrict__ n_large) {
+    for (int q = blockIdx.x; q < n_ranges; q += gridDim.x) {
+        for (int64_t i = rb[q] + threadIdx.x; i < re[q]; i += blockDim.x) {
+            const uint64_t km = kmers[i];
+            const uint64_t b = km % modulo - bucket_begin;
+            const int64_t s = hashes_to_index[b];
+            const int64_t m = n_kmers[b];
+            if (m > SMALL_BUCKET) {
+                if (i == s) large_list[atomicAdd(n_large, 1u)] = (uint32_t)b;
+                continue;
+            }
+            int count = 0;
+            for (int64_t j = s; j < s + m; j++) {
+                if (kmers[j] != km) continue;
+                const uint64_t r = refs[j];
+                bool dup = false;
+                for (int64_t c = s; c < j; c++) dup |= (kmers[c] == km && refs[c] == r);
+                count += dup ? 0 : 1;
+            }
+            freq[i] = (uint16_t)count;
+        }
+    }
+}
+
+int gki_frequencies_for_rows(const int64_t *d_row_begin, const int64_t *d_row_end, int n_ranges, uint64_t modulo,
+                             uint64_t bucket_begin, const void *d_hashes_to_index, const void *d_n_kmers, const void *d_kmers,
+                             const void *d_refs, void *d_freq, int64_t n, hipStream_t s) {
+    if (n_ranges <= 0) return GKI_OK;
+    uint32_t *large_list = nullptr, *sizes = nullptr;
+    unsigned int *n_large_d = nullptr;
+    const size_t cap = (size_t)(n / SMALL_BUCKET + 1);
+    int rc = GKI_OK;
+    if (gki_dev_malloc((void **)&large_list, cap * 4) != hipSuccess || gki_dev_malloc((void **)&sizes, cap * 4) != hipSuccess ||
+        gki_dev_malloc((void **)&n_large_d, 16) != hipSuccess || hipMemsetAsync(n_large_d, 0, 4, s) != hipSuccess)
+        rc = gki_set_error(GKI_ERR_HIP, "frequency pass: allocation failed");
+    unsigned int n_large = 0;
+    if (rc == GKI_OK) {
+        hipLaunchKernelGGL(k_frequencies_ranges, dim3(n_ranges < 4096 ? n_ranges : 4096), dim3(256), 0, s, d_row_begin, d_row_end,
+                           n_ranges, modulo, bucket_begin, (const int32_t *)d_hashes_to_index, (const uint32_t *)d_n_kmers,
+                           (const uint64_t *)d_kmers, (const uint64_t *)d_refs, (uint16_t *)d_freq, large_list, n_large_d);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&n_large, n_large_d, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess)
+            rc = gki_set_error(GKI_ERR_HIP, "frequency pass over open rows failed");
+    }
+    if (rc == GKI_OK && n_large > 0)
+        rc = frequencies_large_pass(large_list, n_large, sizes, d_hashes_to_index, d_n_kmers, d_kmers, d_refs, d_freq, s);
+    (void)gki_dev_free(large_list); (void)gki_dev_free(sizes); (void)gki_dev_free(n_large_d);
+    return rc;
+}
+
 extern "C" {
 
-int gki_index_build_range(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
+int gki_index_build_pairs(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
                           uint64_t modulo, uint64_t bucket_begin, uint64_t n_buckets, int skip_frequencies,
                           void *d_hashes_to_index, void *d_n_kmers, void *d_out_kmers, void *d_out_nodes,
                           void *d_out_ref_offsets, void *d_out_af32, void *d_out_frequencies, void *d_out_permutation) {
@@ -552,30 +648,9 @@ int gki_index_build_range(const void *d_kmers, const void *d_nodes, const void *
             HIP_G(hipMemcpyAsync(&n_large, n_large_d, 4, hipMemcpyDeviceToHost, s));
             HIP_G(hipStreamSynchronize(s));
             if (n_large > 0) {
-                uint32_t *sizes = vals[1 - cur];
-                int64_t *starts = nullptr;
-                Pair *scratch = nullptr;
-                hipLaunchKernelGGL(k_large_sizes, dim3(stream_grid(n_large, 256)), dim3(256), 0, s, large_list, n_large,
-                                   (const uint32_t *)d_n_kmers, sizes);
-                HIP_G(hipGetLastError());
-                HIP_G(gki_dev_malloc((void **)&starts, ((size_t)n_large + 1) * 8));
-                void *tmp2 = nullptr;
-                int64_t tmp2_bytes = gki_scan_tmp_bytes(n_large);
-                hipError_t e2 = gki_dev_malloc(&tmp2, (size_t)tmp2_bytes);
-                int r = e2 == hipSuccess ? gki_scan_u32_to_i64(sizes, n_large, starts, tmp2, tmp2_bytes, s) : GKI_ERR_HIP;
-                int64_t total = 0;
-                if (r == GKI_OK && hipMemcpy(&total, starts + n_large, 8, hipMemcpyDeviceToHost) != hipSuccess) r = GKI_ERR_HIP;
-                if (r == GKI_OK && gki_dev_malloc((void **)&scratch, (size_t)total * sizeof(Pair)) != hipSuccess) r = GKI_ERR_HIP;
-                if (r == GKI_OK) {
-                    unsigned grid = n_large < 2048 ? n_large : 2048;
-                    hipLaunchKernelGGL(k_frequencies_large, dim3(grid), dim3(256), 0, s, large_list, n_large,
-                                       (const int32_t *)d_hashes_to_index, (const uint32_t *)d_n_kmers,
-                                       (const uint64_t *)d_out_kmers, (const uint64_t *)d_out_ref_offsets, starts, scratch,
-                                       (uint16_t *)d_out_frequencies);
-                    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) r = GKI_ERR_HIP;
-                }
-                (void)gki_dev_free(starts); (void)gki_dev_free(tmp2); (void)gki_dev_free(scratch);
-                if (r != GKI_OK) CLEANUP_RETURN(gki_set_error(r, "large-bucket frequency pass failed"));
+                int r = frequencies_large_pass(large_list, n_large, vals[1 - cur], d_hashes_to_index, d_n_kmers, d_out_kmers,
+                                               d_out_ref_offsets, d_out_frequencies, s);
+                if (r != GKI_OK) CLEANUP_RETURN(r);
             }
         }
         HIP_G(hipStreamSynchronize(s));
@@ -586,6 +661,30 @@ done:
 #undef HIP_G
 #undef CLEANUP_RETURN
     return rc;
+}
+
+int gki_index_build_range(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
+                          uint64_t modulo, uint64_t bucket_begin, uint64_t n_buckets, int skip_frequencies,
+                          void *d_hashes_to_index, void *d_n_kmers, void *d_out_kmers, void *d_out_nodes,
+                          void *d_out_ref_offsets, void *d_out_af32, void *d_out_frequencies, void *d_out_permutation) {
+    if (modulo == 0 || modulo > 0xFFFFFFFFull) return gki_set_error(GKI_ERR_BAD_ARG, "modulo must be in 1..2^32-1");
+    if (n_buckets == 0 || bucket_begin + n_buckets > modulo)
+        return gki_set_error(GKI_ERR_BAD_ARG, "bucket range [%llu, +%llu) outside [0, modulo)", (unsigned long long)bucket_begin,
+                             (unsigned long long)n_buckets);
+    if (n >= (1ll << 31))
+        return gki_set_error(GKI_ERR_OVERFLOW, "%lld records: the reference's directory is int32 "
+                             "(collision_free_kmer_index.py:453); shard the build", (long long)n);
+    if (n > 0) {
+        // the row-carrying form (gki_index_rows.hip); the pair-sorting form below takes over for inputs outside its domain
+        int done = 0;
+        GKI_TRY(gki_index_build_rows(d_kmers, d_nodes, d_ref_offsets, d_af32, n, modulo, bucket_begin, n_buckets, skip_frequencies,
+                                     d_hashes_to_index, d_n_kmers, d_out_kmers, d_out_nodes, d_out_ref_offsets, d_out_af32,
+                                     d_out_frequencies, d_out_permutation, &done));
+        if (done) return GKI_OK;
+    }
+    return gki_index_build_pairs(d_kmers, d_nodes, d_ref_offsets, d_af32, n, modulo, bucket_begin, n_buckets, skip_frequencies,
+                                 d_hashes_to_index, d_n_kmers, d_out_kmers, d_out_nodes, d_out_ref_offsets, d_out_af32,
+                                 d_out_frequencies, d_out_permutation);
 }
 
 int gki_index_build(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,

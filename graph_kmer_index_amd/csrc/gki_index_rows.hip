@@ -1,0 +1,658 @@
+// CollisionFreeKmerIndex build, row-carrying form (collision_free_kmer_index.py:423-467, set_frequencies :267-293).
+//
+// The first form of the build (gki_index.hip) sorts (bucket, index) pairs and then GATHERS the payload by the sorted
+// index: 3.1e8 random 32-byte rows at the chip's lane-request rate, 12 of its 31 ms.  This form never issues a random
+// request: the 24-byte payload row travels WITH its key through stable partition passes whose writes leave a tile as
+// contiguous runs per digit, and the last step sorts a group of a few hundred to a few thousand rows inside LDS.
+//
+//   k_bucket_keys (gki_index.hip)   key = kmer % modulo - bucket_begin                       8 R + 4 W per record
+//   per partition pass (1..3, most significant digits last = LSD over the TOP bits of the key, each pass stable):
+//     k_digit_hist                  per-tile digit histogram                                  4 R
+//     scan                          bin-major exclusive scan -> first row of every (digit, tile) run
+//     k_partition_rows              rows (or the four input columns) + keys -> rows + keys    28 R + 28 W
+//   k_group_bounds / k_group_scan   first row / row count of every group (= key >> L)         4 R
+//   k_group_finish                  one workgroup per group: counting sort on the low L bits in LDS, the directory of
+//                                   the group's 2^L buckets (streamed, no memset + scatter), frequencies, and the
+//                                   four output columns + frequency column, all coalesced      28 R + 26 W + 8 B/bucket
+//   k_group_large                   a group with more rows than LDS holds: one workgroup streams it (count, scan,
+//                                   ordered scatter); frequencies of its buckets by the kernels of the first form
+//
+// Stability: every pass keeps equal digits in input order and the in-LDS sort ranks equal buckets by row position, so
+// the result equals the first form's (and the oracle's stable build) element by element.
+#include "gki_common.h"
+
+int gki_frequencies_for_rows(const int64_t *d_row_begin, const int64_t *d_row_end, int n_ranges, uint64_t modulo,
+                             uint64_t bucket_begin, const void *d_hashes_to_index, const void *d_n_kmers,
+                             const void *d_kmers, const void *d_refs, void *d_freq, int64_t n, hipStream_t s);
+
+namespace {
+
+constexpr int MAXB_BITS = 10;
+constexpr int MAXB = 1 << MAXB_BITS;          // digits of one partition pass
+constexpr int GROUP_CAP = 2048;               // rows a group may hold to be finished in LDS
+constexpr int GROUP_LMAX = 11;                // low key bits resolved in LDS
+constexpr int GROUP_THREADS = 512;
+constexpr int SMALL_BUCKET = 24;              // as in gki_index.hip: buckets up to this size count frequencies per lane
+
+struct PartArgs {
+    const uint32_t *keys_in;
+    const uint64_t *c_kmers; const uint32_t *c_nodes; const uint64_t *c_refs; const uint32_t *c_af;   // SRC_COLS
+    const uint64_t *rows_in;                                                                          // !SRC_COLS
+    int64_t n, n_tiles;
+    int shift, bits;
+    const uint32_t *offs;          // [bins * n_tiles] exclusive scan of the bin-major tile histograms
+    uint64_t *rows_out; uint32_t *keys_out;
+    int carry_index;               // the row's input index rides in place of the allele frequency (permutation wanted)
+    int xcd_tiles;                 // > 0: block b works on tile (b % 8) * xcd_tiles + b / 8, so that neighbouring tiles
+                                   // (whose runs are adjacent in memory) go through the same XCD's L2
+};
+
+__device__ __forceinline__ int64_t tile_of_block(int64_t n_tiles, int xcd_tiles) {
+    if (xcd_tiles <= 0) return blockIdx.x;
+    return (int64_t)(blockIdx.x & 7) * xcd_tiles + (blockIdx.x >> 3);
+}
+
+template <int THREADS, int RI>
+__global__ __launch_bounds__(THREADS) void k_digit_hist(const uint32_t *__restrict__ keys, int64_t n, int shift, int bits,
+                                                        uint32_t *__restrict__ hist, int64_t n_tiles) {
+    __shared__ uint32_t h[MAXB];
+    const int bins = 1 << bits;
+    for (int d = threadIdx.x; d < bins; d += THREADS) h[d] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * (THREADS * RI);
+    const uint32_t mask = (uint32_t)bins - 1u;
+#pragma unroll
+    for (int r = 0; r < RI; r++) {
+        const int64_t i = base + r * THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < bins; d += THREADS) hist[(int64_t)d * n_tiles + blockIdx.x] = h[d];
+}
+
+// Exclusive scan of v over the THREADS threads of the block (lds: THREADS / 64 + 1 words)
+template <int THREADS>
+__device__ __forceinline__ uint32_t block_excl(uint32_t v, uint32_t *lds, uint32_t *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const uint32_t o = __shfl_up(inc, s, 64);
+        if (lane >= s) inc += o;
+    }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; w++) { const uint32_t c = lds[w]; if (w < wave) woff += c; tot += c; }
+    __syncthreads();
+    *total = tot;
+    return woff + inc - v;
+}
+
+// Rank of every element among the earlier elements of its wave with the same digit, and the wave's digit counts.
+// Element order inside a tile is (wave, round, lane): wave w owns a contiguous slice, round r its r-th group of 64.
+template <int RI>
+__device__ __forceinline__ void wave_rank(const uint32_t (&dig)[RI], const bool (&valid)[RI], int bits, uint16_t *wcnt /* this wave's [bins] */,
+                                          uint32_t (&rank)[RI]) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < RI; r++) {
+        const uint32_t d = dig[r];
+        uint64_t same = __ballot(valid[r]);
+        for (int b = 0; b < bits; b++) {
+            const uint64_t bit = __ballot((d >> b) & 1u);
+            same &= ((d >> b) & 1u) ? bit : ~bit;
+        }
+        const uint32_t before = (uint32_t)__popcll(same & lt_mask);
+        uint32_t prev = 0;
+        if (valid[r]) prev = wcnt[d];                       // all lanes of the group read the same value ...
+        rank[r] = prev + before;
+        if (valid[r] && before == 0) wcnt[d] = (uint16_t)(prev + (uint32_t)__popcll(same));   // ... then its first lane publishes
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// One stable partition pass over a tile of THREADS * RI rows.
+template <int THREADS, int RI, bool SRC_COLS>
+__global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
+    constexpr int TILE = THREADS * RI, W = THREADS / 64, SLICE = TILE / W;
+    __shared__ uint64_t s_rows[TILE * 3];
+    __shared__ uint32_t s_keys[TILE];
+    __shared__ uint16_t s_dest[TILE];
+    __shared__ uint16_t s_wcnt[W][MAXB];
+    __shared__ uint32_t s_dstart[MAXB];
+    __shared__ uint32_t s_toff[MAXB];
+    __shared__ uint32_t s_scan[W + 1];
+    const int64_t tile = tile_of_block(a.n_tiles, a.xcd_tiles);
+    if (tile >= a.n_tiles) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bins = 1 << a.bits;
+    const uint32_t mask = (uint32_t)bins - 1u;
+    const int64_t tile_base = tile * TILE;
+    const int n_here = (int)((a.n - tile_base) < TILE ? (a.n - tile_base) : TILE);
+
+    // (1) everything this thread will need from global memory, issued up front: the keys of its ranking slots and the
+    // payload words it will carry into LDS (words are assigned to threads by position, not by row: coalesced)
+    uint32_t key[RI], dig[RI];
+    bool valid[RI];
+#pragma unroll
+    for (int r = 0; r < RI; r++) {
+        const int e = wave * SLICE + r * 64 + lane;
+        valid[r] = e < n_here;
+        key[r] = valid[r] ? a.keys_in[tile_base + e] : 0u;
+        dig[r] = valid[r] ? ((key[r] >> a.shift) & mask) : 0u;
+    }
+    uint64_t w0[RI], w1[RI], w2[RI];
+    if (SRC_COLS) {
+#pragma unroll
+        for (int r = 0; r < RI; r++) {
+            const int e = r * THREADS + threadIdx.x;
+            const bool ok = e < n_here;
+            w0[r] = ok ? a.c_kmers[tile_base + e] : 0ull;
+            w1[r] = ok ? a.c_refs[tile_base + e] : 0ull;
+            w2[r] = ok ? ((uint64_t)a.c_nodes[tile_base + e] |
+                          ((uint64_t)(a.carry_index ? (uint32_t)(tile_base + e) : a.c_af[tile_base + e]) << 32)) : 0ull;
+        }
+    } else {
+        const uint64_t *src = a.rows_in + tile_base * 3;
+#pragma unroll
+        for (int r = 0; r < RI; r++) {
+            const int j = r * THREADS + threadIdx.x;            // word j of the tile's 3 * n_here words
+            w0[r] = j < 3 * n_here ? src[j] : 0ull;
+            w1[r] = j + TILE < 3 * n_here ? src[j + TILE] : 0ull;
+            w2[r] = j + 2 * TILE < 3 * n_here ? src[j + 2 * TILE] : 0ull;
+        }
+    }
+    for (int d = threadIdx.x; d < W * MAXB; d += THREADS) (&s_wcnt[0][0])[d] = 0;
+    __syncthreads();
+
+    // (2) ranks inside the wave, digit counts per wave
+    uint32_t rank[RI];
+    wave_rank<RI>(dig, valid, a.bits, s_wcnt[wave], rank);
+    __syncthreads();
+
+    // (3) per digit: exclusive offsets over the waves, the digit's start in the sorted tile, and where its run goes
+    {
+        constexpr int C = MAXB / THREADS > 0 ? MAXB / THREADS : 1;      // digits per thread
+        uint32_t tot[C], sum = 0;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int d = threadIdx.x * C + c;
+            tot[c] = 0;
+            if (d < bins) {
+                uint32_t run = 0;
+#pragma unroll
+                for (int w = 0; w < W; w++) { const uint32_t x = s_wcnt[w][d]; s_wcnt[w][d] = (uint16_t)run; run += x; }
+                tot[c] = run;
+            }
+            sum += tot[c];
+        }
+        uint32_t total;
+        uint32_t ex = block_excl<THREADS>(sum, s_scan, &total);
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int d = threadIdx.x * C + c;
+            if (d < bins) {
+                s_dstart[d] = ex;
+                s_toff[d] = a.offs[(int64_t)d * a.n_tiles + tile] - ex;
+                ex += tot[c];
+            }
+        }
+    }
+    __syncthreads();
+
+    // (4) destination slot of every row of the tile
+#pragma unroll
+    for (int r = 0; r < RI; r++) {
+        if (valid[r]) {
+            const int e = wave * SLICE + r * 64 + lane;
+            const uint32_t slot = s_dstart[dig[r]] + s_wcnt[wave][dig[r]] + rank[r];
+            s_dest[e] = (uint16_t)slot;
+            s_keys[slot] = key[r];
+        }
+    }
+    __syncthreads();
+
+    // (5) payload words into their rows' slots
+    if (SRC_COLS) {
+#pragma unroll
+        for (int r = 0; r < RI; r++) {
+            const int e = r * THREADS + threadIdx.x;
+            if (e < n_here) {
+                const int slot = s_dest[e];
+                s_rows[slot * 3 + 0] = w0[r]; s_rows[slot * 3 + 1] = w1[r]; s_rows[slot * 3 + 2] = w2[r];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RI; r++) {
+            const int j0 = r * THREADS + threadIdx.x, j1 = j0 + TILE, j2 = j0 + 2 * TILE;
+            if (j0 < 3 * n_here) s_rows[(int)s_dest[j0 / 3] * 3 + j0 % 3] = w0[r];
+            if (j1 < 3 * n_here) s_rows[(int)s_dest[j1 / 3] * 3 + j1 % 3] = w1[r];
+            if (j2 < 3 * n_here) s_rows[(int)s_dest[j2 / 3] * 3 + j2 % 3] = w2[r];
+        }
+    }
+    __syncthreads();
+
+    // (6) the sorted tile leaves as one contiguous run per digit: consecutive lanes, consecutive words
+#pragma unroll
+    for (int r = 0; r < 3 * RI; r++) {
+        const int j = r * THREADS + threadIdx.x;
+        if (j < 3 * n_here) {
+            const int p = j / 3;
+            const uint32_t d = (s_keys[p] >> a.shift) & mask;
+            const int64_t row = (int64_t)(uint32_t)(s_toff[d] + (uint32_t)p);
+            a.rows_out[row * 3 + (j - p * 3)] = s_rows[j];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RI; r++) {
+        const int p = r * THREADS + threadIdx.x;
+        if (p < n_here) {
+            const uint32_t k = s_keys[p];
+            const uint32_t d = (k >> a.shift) & mask;
+            a.keys_out[(int64_t)(uint32_t)(s_toff[d] + (uint32_t)p)] = k;
+        }
+    }
+}
+
+// First row and one-past-last row of every group (group = key >> L) in the keys sorted by group; arrays zeroed before.
+__global__ __launch_bounds__(256) void k_group_bounds(const uint32_t *__restrict__ keys, int64_t n, int L,
+                                                      uint32_t *__restrict__ gbegin, uint32_t *__restrict__ gend) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t g = keys[i] >> L;
+        if (i == 0 || (keys[i - 1] >> L) != g) gbegin[g] = (uint32_t)i;
+        if (i == n - 1 || (keys[i + 1] >> L) != g) gend[g] = (uint32_t)(i + 1);
+    }
+}
+
+// stats[0] = rows of the largest group, stats[1] = number of groups with more than `cap` rows (their ids -> large[])
+__global__ __launch_bounds__(256) void k_group_scan(const uint32_t *__restrict__ gbegin, const uint32_t *__restrict__ gend,
+                                                    int64_t n_groups, uint32_t cap, unsigned int *__restrict__ stats,
+                                                    uint32_t *__restrict__ large, uint32_t large_cap) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint32_t mx = 0;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += stride) {
+        const uint32_t m = gend[g] - gbegin[g];
+        mx = m > mx ? m : mx;
+        if (m > cap) {
+            const unsigned int at = atomicAdd(&stats[1], 1u);
+            if (at < large_cap) large[at] = (uint32_t)g;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { const uint32_t o = __shfl_down(mx, d, 64); mx = o > mx ? o : mx; }
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(&stats[0], mx);
+}
+
+struct FinishArgs {
+    const uint64_t *rows; const uint32_t *keys;
+    const uint32_t *gbegin, *gend;
+    int64_t n_groups;
+    int L;
+    uint64_t n_buckets;
+    int skip_frequencies;
+    int32_t *h2i; uint32_t *nk;
+    uint64_t *o_kmers; uint32_t *o_nodes; uint64_t *o_refs; uint32_t *o_af; uint16_t *o_freq;
+    uint32_t *o_perm; const uint32_t *af_in;     // rows carry their input index: permutation out, allele frequency fetched by it
+    uint32_t *big_buckets; unsigned int *n_big; uint32_t big_cap;    // buckets of more than SMALL_BUCKET rows (frequencies later)
+    int xcd_groups;
+};
+
+// One workgroup per group of 2^L buckets: everything about the group happens in LDS.
+__global__ __launch_bounds__(GROUP_THREADS) void k_group_finish(FinishArgs a) {
+    constexpr int NB = 1 << GROUP_LMAX, RI = GROUP_CAP / GROUP_THREADS, W = GROUP_THREADS / 64;
+    __shared__ uint64_t s_kmer[GROUP_CAP], s_ref[GROUP_CAP];
+    __shared__ uint32_t s_node[GROUP_CAP], s_af[GROUP_CAP];
+    __shared__ uint32_t s_cnt[NB], s_pos[NB];     // rows of a bucket; next free slot (start + rows once all are placed)
+    __shared__ uint16_t s_lk[GROUP_CAP];        // by slot: the row's bucket within the group
+    __shared__ uint16_t s_src[GROUP_CAP];       // by slot: the row's position in the group (input order)
+    __shared__ uint16_t s_dest[GROUP_CAP];      // by position: the row's final slot
+    __shared__ uint32_t s_scan[W + 1];
+    int64_t g = blockIdx.x;
+    if (a.xcd_groups > 0) { g = (int64_t)(blockIdx.x & 7) * a.xcd_groups + (blockIdx.x >> 3); if (g >= a.n_groups) return; }
+    const uint32_t s = a.gbegin[g], m = a.gend[g] - s;
+    const uint64_t gb = (uint64_t)g << a.L;
+    const uint32_t nbk = (uint32_t)((a.n_buckets - gb) < (1ull << a.L) ? (a.n_buckets - gb) : (1ull << a.L));
+    if (m > GROUP_CAP) return;                                  // k_group_large's
+    const uint32_t lmask = (1u << a.L) - 1u;
+    // rows and keys of the group, issued before anything else
+    uint32_t lk[RI];
+    uint64_t w0[RI], w1[RI], w2[RI];
+    const uint64_t *src = a.rows + (int64_t)s * 3;
+#pragma unroll
+    for (int r = 0; r < RI; r++) {
+        const uint32_t e = r * GROUP_THREADS + threadIdx.x;
+        lk[r] = e < m ? (a.keys[(int64_t)s + e] & lmask) : 0u;
+        const uint32_t j = e;
+        w0[r] = j < 3 * m ? src[j] : 0ull;
+        w1[r] = j + GROUP_CAP < 3 * m ? src[j + GROUP_CAP] : 0ull;
+        w2[r] = j + 2 * GROUP_CAP < 3 * m ? src[j + 2 * GROUP_CAP] : 0ull;
+    }
+    for (uint32_t b = threadIdx.x; b < nbk; b += GROUP_THREADS) s_cnt[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RI; r++)
+        if (r * GROUP_THREADS + threadIdx.x < m) atomicAdd(&s_cnt[lk[r]], 1u);
+    __syncthreads();
+    // bucket starts (exclusive scan over the group's buckets) and the directory of the group, streamed
+    {
+        constexpr int C = NB / GROUP_THREADS;                   // 4 buckets per thread
+        uint32_t c[C], sum = 0;
+#pragma unroll
+        for (int i = 0; i < C; i++) { const uint32_t b = threadIdx.x * C + i; c[i] = b < nbk ? s_cnt[b] : 0u; sum += c[i]; }
+        uint32_t total;
+        uint32_t ex = block_excl<GROUP_THREADS>(sum, s_scan, &total);
+#pragma unroll
+        for (int i = 0; i < C; i++) { const uint32_t b = threadIdx.x * C + i; if (b < nbk) s_pos[b] = ex; ex += c[i]; }
+    }
+    __syncthreads();
+    // a provisional slot inside the bucket (arrival order), then the stable one: rows of a bucket in input order
+#pragma unroll
+    for (int r = 0; r < RI; r++) {
+        const uint32_t e = r * GROUP_THREADS + threadIdx.x;
+        if (e < m) s_src[atomicAdd(&s_pos[lk[r]], 1u)] = (uint16_t)e;
+    }
+    __syncthreads();                                             // from here on: start of bucket b = s_pos[b] - s_cnt[b]
+    for (uint32_t b = threadIdx.x; b < nbk; b += GROUP_THREADS) {
+        const uint32_t c = s_cnt[b];
+        a.h2i[gb + b] = c ? (int32_t)(s + s_pos[b] - c) : 0;     // collision_free_kmer_index.py:453-454
+        a.nk[gb + b] = c;                                        // :456-457
+    }
+#pragma unroll
+    for (int r = 0; r < RI; r++) {
+        const uint32_t e = r * GROUP_THREADS + threadIdx.x;
+        if (e < m) {
+            const uint32_t c = s_cnt[lk[r]], b0 = s_pos[lk[r]] - c;
+            uint32_t before = 0;
+            for (uint32_t j = b0; j < b0 + c; j++) before += s_src[j] < e ? 1u : 0u;
+            s_dest[e] = (uint16_t)(b0 + before);
+            s_lk[b0 + before] = (uint16_t)lk[r];
+        }
+    }
+    __syncthreads();
+    // payload words to their rows' slots, column-wise in LDS
+#pragma unroll
+    for (int r = 0; r < RI; r++) {
+        const uint32_t j0 = r * GROUP_THREADS + threadIdx.x, j1 = j0 + GROUP_CAP, j2 = j0 + 2 * GROUP_CAP;
+        const uint64_t w[3] = {w0[r], w1[r], w2[r]};
+        const uint32_t jj[3] = {j0, j1, j2};
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            if (jj[t] < 3 * m) {
+                const uint32_t row = jj[t] / 3, word = jj[t] - row * 3, slot = s_dest[row];
+                if (word == 0) s_kmer[slot] = w[t];
+                else if (word == 1) s_ref[slot] = w[t];
+                else { s_node[slot] = (uint32_t)w[t]; s_af[slot] = (uint32_t)(w[t] >> 32); }
+            }
+        }
+    }
+    __syncthreads();
+    // the group's slice of the output columns, frequencies computed on the way (set_frequencies :267-293)
+#pragma unroll
+    for (int r = 0; r < RI; r++) {
+        const uint32_t p = r * GROUP_THREADS + threadIdx.x;
+        if (p < m) {
+            const uint64_t km = s_kmer[p], rf = s_ref[p];
+            const int64_t o = (int64_t)s + p;
+            a.o_kmers[o] = km; a.o_refs[o] = rf; a.o_nodes[o] = s_node[p];
+            if (a.o_perm) { const uint32_t idx = s_af[p]; a.o_perm[o] = idx; a.o_af[o] = a.af_in[idx]; }
+            else a.o_af[o] = s_af[p];
+            uint32_t f = 0;
+            if (!a.skip_frequencies) {
+                const uint32_t b = s_lk[p], c = s_cnt[b], b0 = s_pos[b] - c;
+                if (c == 1) f = 1;
+                else if (c <= SMALL_BUCKET) {
+                    for (uint32_t j = b0; j < b0 + c; j++) {
+                        if (s_kmer[j] != km) continue;
+                        const uint64_t rj = s_ref[j];
+                        bool dup = false;
+                        for (uint32_t q = b0; q < j; q++) dup |= (s_kmer[q] == km && s_ref[q] == rj);
+                        f += dup ? 0u : 1u;
+                    }
+                } else if (p == b0) {
+                    const unsigned int at = atomicAdd(a.n_big, 1u);
+                    if (at < a.big_cap) a.big_buckets[at] = (uint32_t)(gb + b);
+                }
+            }
+            a.o_freq[o] = (uint16_t)f;
+        }
+    }
+}
+
+// A group with more rows than k_group_finish keeps in LDS: one workgroup streams it three times (count, then an
+// ordered scatter of its rows straight into the output columns).  Frequencies of its buckets are left to the caller.
+__global__ __launch_bounds__(256) void k_group_large(FinishArgs a, const uint32_t *__restrict__ large, unsigned int n_large) {
+    constexpr int NB = 1 << GROUP_LMAX;
+    __shared__ uint32_t s_cnt[NB], s_start[NB];
+    __shared__ uint32_t s_scan[256 / 64 + 1];
+    const uint32_t lmask = (1u << a.L) - 1u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    for (unsigned int li = blockIdx.x; li < n_large; li += gridDim.x) {
+        const int64_t g = large[li];
+        const uint32_t s = a.gbegin[g], m = a.gend[g] - s;
+        const uint64_t gb = (uint64_t)g << a.L;
+        const uint32_t nbk = (uint32_t)((a.n_buckets - gb) < (1ull << a.L) ? (a.n_buckets - gb) : (1ull << a.L));
+        for (uint32_t b = threadIdx.x; b < NB; b += 256) s_cnt[b] = 0;
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < m; e += 256) atomicAdd(&s_cnt[a.keys[(int64_t)s + e] & lmask], 1u);
+        __syncthreads();
+        {
+            constexpr int C = NB / 256;
+            uint32_t c[C], sum = 0;
+#pragma unroll
+            for (int i = 0; i < C; i++) { c[i] = s_cnt[threadIdx.x * C + i]; sum += c[i]; }
+            uint32_t total;
+            uint32_t ex = block_excl<256>(sum, s_scan, &total);
+#pragma unroll
+            for (int i = 0; i < C; i++) { s_start[threadIdx.x * C + i] = ex; ex += c[i]; }
+        }
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < nbk; b += 256) {
+            const uint32_t c = s_cnt[b];
+            a.h2i[gb + b] = c ? (int32_t)(s + s_start[b]) : 0;
+            a.nk[gb + b] = c;
+        }
+        __syncthreads();
+        // ordered scatter: chunks of 256 rows, the four waves of a chunk one after the other; s_start[b] runs ahead as
+        // the next free slot of bucket b
+        for (uint32_t c0 = 0; c0 < m; c0 += 256) {
+            const uint32_t e = c0 + threadIdx.x;
+            const bool valid = e < m;
+            const uint32_t b = valid ? (a.keys[(int64_t)s + e] & lmask) : 0u;
+            uint64_t w0 = 0, w1 = 0, w2 = 0;
+            if (valid) { const uint64_t *row = a.rows + ((int64_t)s + e) * 3; w0 = row[0]; w1 = row[1]; w2 = row[2]; }
+            uint64_t same = __ballot(valid);
+            for (int t = 0; t < a.L; t++) {
+                const uint64_t bit = __ballot((b >> t) & 1u);
+                same &= ((b >> t) & 1u) ? bit : ~bit;
+            }
+            const uint32_t before = (uint32_t)__popcll(same & lt_mask);
+            for (int w = 0; w < 4; w++) {
+                if (wave == w && valid) {
+                    const uint32_t slot = s_start[b] + before;
+                    __builtin_amdgcn_wave_barrier();
+                    if (before == 0) s_start[b] = slot + (uint32_t)__popcll(same);
+                    const int64_t o = (int64_t)s + slot;
+                    a.o_kmers[o] = w0; a.o_refs[o] = w1; a.o_nodes[o] = (uint32_t)w2;
+                    if (a.o_perm) { const uint32_t idx = (uint32_t)(w2 >> 32); a.o_perm[o] = idx; a.o_af[o] = a.af_in[idx]; }
+                    else a.o_af[o] = (uint32_t)(w2 >> 32);
+                    a.o_freq[o] = 0;
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// row ranges whose frequencies are still open: every large group, every big bucket
+__global__ __launch_bounds__(256) void k_open_ranges(const uint32_t *__restrict__ large, unsigned int n_large,
+                                                     const uint32_t *__restrict__ gbegin, const uint32_t *__restrict__ gend,
+                                                     const uint32_t *__restrict__ big, unsigned int n_big,
+                                                     const int32_t *__restrict__ h2i, const uint32_t *__restrict__ nk,
+                                                     int64_t *__restrict__ rb, int64_t *__restrict__ re) {
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_large + n_big; i += gridDim.x * blockDim.x) {
+        if (i < n_large) { rb[i] = gbegin[large[i]]; re[i] = gend[large[i]]; }
+        else { const uint32_t b = big[i - n_large]; rb[i] = h2i[b]; re[i] = (int64_t)h2i[b] + nk[b]; }
+    }
+}
+
+int key_bits(uint64_t max_key) {
+    int bits = 0;
+    while (bits < 32 && (max_key >> bits) != 0) bits++;
+    return bits;
+}
+
+}  // namespace
+
+__global__ void k_bucket_keys_only(const uint64_t *__restrict__ kmers, int64_t n, uint64_t modulo, uint64_t bucket_begin,
+                                   uint64_t n_buckets, uint32_t *__restrict__ keys, int *__restrict__ out_of_range) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t b = kmers[i] % modulo - bucket_begin;       // collision_free_kmer_index.py:433
+        if (b >= n_buckets) *out_of_range = 1;
+        keys[i] = b < n_buckets ? (uint32_t)b : 0u;
+    }
+}
+
+// Tile shape of the partition passes.  4096-row tiles (one workgroup of 512 threads per CU, 144 KB of LDS) give every
+// digit of a 512-way pass a run of 8 rows = 192 bytes on average; see DESIGN.md 4.3 for the measured alternatives.
+#ifndef GKI_PT_THREADS
+#define GKI_PT_THREADS 512
+#endif
+#ifndef GKI_PT_RI
+#define GKI_PT_RI 8
+#endif
+
+// The row-carrying build.  Returns GKI_OK with *done = 1 when it built the index, *done = 0 when the input is outside
+// its domain (a group too large to stream with one workgroup) and the caller should use the pair-sorting form.
+int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
+                         uint64_t modulo, uint64_t bucket_begin, uint64_t n_buckets, int skip_frequencies,
+                         void *d_hashes_to_index, void *d_n_kmers, void *d_out_kmers, void *d_out_nodes,
+                         void *d_out_ref_offsets, void *d_out_af32, void *d_out_frequencies, void *d_out_permutation, int *done) {
+    constexpr int THREADS = GKI_PT_THREADS, RI = GKI_PT_RI, TILE = THREADS * RI;
+    *done = 0;
+    hipStream_t s = 0;
+    const int kb = key_bits(n_buckets - 1);
+    // L: low key bits resolved inside LDS -- the largest for which an average group (plus a quarter) fits
+    int L = kb < GROUP_LMAX ? kb : GROUP_LMAX;
+    while (L > 0 && ((double)n / (double)n_buckets) * (double)(1ull << L) * 1.25 + 64.0 > (double)GROUP_CAP) L--;
+    const int top = kb - L;                                   // bits the partition passes sort on
+    const int n_pass = top > 0 ? (top + MAXB_BITS - 1) / MAXB_BITS : 1;   // top == 0: one pass of one digit, which only packs the rows
+    if (n_pass > 3) return GKI_OK;
+    const int64_t n_groups = (int64_t)(((n_buckets - 1) >> L) + 1);
+    const int64_t n_tiles = ceil_div(n, TILE);
+    const int64_t hist_n = (int64_t)MAXB * n_tiles;
+    const int64_t tmp_bytes = gki_scan_tmp_bytes(hist_n);
+    uint64_t *rows[2] = {nullptr, nullptr};
+    uint32_t *keys[3] = {nullptr, nullptr, nullptr}, *hist = nullptr, *offs = nullptr, *gbegin = nullptr, *gend = nullptr;
+    uint32_t *large = nullptr, *big = nullptr;
+    unsigned int *stats = nullptr;                            // [0] max group, [1] large groups, [2] big buckets, [3] out of range
+    int64_t *rng = nullptr;
+    void *tmp = nullptr;
+    const uint32_t large_cap = 1u << 16;
+    const uint32_t big_cap = (uint32_t)(n / SMALL_BUCKET + 1);
+    int rc = GKI_OK;
+#define HIP_G(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = gki_set_error(GKI_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); goto done; } } while (0)
+    {
+        HIP_G(gki_dev_malloc((void **)&keys[0], (size_t)n * 4));
+        HIP_G(gki_dev_malloc((void **)&stats, 64));
+        HIP_G(hipMemsetAsync(stats, 0, 64, s));
+        hipLaunchKernelGGL(k_bucket_keys_only, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const uint64_t *)d_kmers, n, modulo,
+                           bucket_begin, n_buckets, keys[0], (int *)(stats + 3));
+        HIP_G(hipGetLastError());
+        for (int i = 0; i < (n_pass > 1 ? 2 : 1); i++) HIP_G(gki_dev_malloc((void **)&rows[i], (size_t)n * 24));
+        for (int i = 1; i < (n_pass > 1 ? 3 : 2); i++) HIP_G(gki_dev_malloc((void **)&keys[i], (size_t)n * 4));
+        HIP_G(gki_dev_malloc((void **)&hist, (size_t)hist_n * 4));
+        HIP_G(gki_dev_malloc((void **)&offs, (size_t)(hist_n + 1) * 4));
+        HIP_G(gki_dev_malloc(&tmp, (size_t)tmp_bytes));
+        HIP_G(gki_dev_malloc((void **)&gbegin, (size_t)n_groups * 4));
+        HIP_G(gki_dev_malloc((void **)&gend, (size_t)n_groups * 4));
+        HIP_G(gki_dev_malloc((void **)&large, (size_t)large_cap * 4));
+        HIP_G(gki_dev_malloc((void **)&big, (size_t)big_cap * 4));
+        HIP_G(hipMemsetAsync(gbegin, 0, (size_t)n_groups * 4, s));
+        HIP_G(hipMemsetAsync(gend, 0, (size_t)n_groups * 4, s));
+        // partition passes on the top bits, least significant digit first, each stable
+        const uint64_t *cur_rows = nullptr;
+        const uint32_t *cur_keys = keys[0];
+        int shift = L;
+        for (int p = 0; p < n_pass; p++) {
+            const int bits = (top - (shift - L) + (n_pass - p) - 1) / (n_pass - p);       // remaining bits spread evenly
+            const int64_t bins_n = ((int64_t)1 << bits) * n_tiles;
+            hipLaunchKernelGGL((k_digit_hist<THREADS, RI>), dim3((unsigned)n_tiles), dim3(THREADS), 0, s, cur_keys, n, shift, bits,
+                               hist, n_tiles);
+            HIP_G(hipGetLastError());
+            rc = gki_scan_u32_to_u32(hist, bins_n, offs, tmp, tmp_bytes, s);
+            if (rc != GKI_OK) goto done;
+            PartArgs a;
+            a.keys_in = cur_keys; a.c_kmers = (const uint64_t *)d_kmers; a.c_nodes = (const uint32_t *)d_nodes;
+            a.c_refs = (const uint64_t *)d_ref_offsets; a.c_af = (const uint32_t *)d_af32; a.rows_in = cur_rows;
+            a.n = n; a.n_tiles = n_tiles; a.shift = shift; a.bits = bits; a.offs = offs; a.carry_index = d_out_permutation != nullptr;
+            a.rows_out = rows[p & 1]; a.keys_out = keys[1 + (p & 1)];
+            a.xcd_tiles = (int)ceil_div(n_tiles, 8);
+            const unsigned grid = (unsigned)(a.xcd_tiles * 8);
+            if (p == 0) hipLaunchKernelGGL((k_partition_rows<THREADS, RI, true>), dim3(grid), dim3(THREADS), 0, s, a);
+            else hipLaunchKernelGGL((k_partition_rows<THREADS, RI, false>), dim3(grid), dim3(THREADS), 0, s, a);
+            HIP_G(hipGetLastError());
+            cur_rows = a.rows_out; cur_keys = a.keys_out;
+            shift += bits;
+        }
+        hipLaunchKernelGGL(k_group_bounds, dim3(stream_grid(n, 256)), dim3(256), 0, s, cur_keys, n, L, gbegin, gend);
+        HIP_G(hipGetLastError());
+        hipLaunchKernelGGL(k_group_scan, dim3(stream_grid(n_groups, 256)), dim3(256), 0, s, gbegin, gend, n_groups,
+                           (uint32_t)GROUP_CAP, stats, large, large_cap);
+        HIP_G(hipGetLastError());
+        unsigned int h_stats[4] = {0, 0, 0, 0};
+        HIP_G(hipMemcpyAsync(h_stats, stats, 16, hipMemcpyDeviceToHost, s));
+        HIP_G(hipStreamSynchronize(s));
+        if (h_stats[3]) { rc = gki_set_error(GKI_ERR_BAD_ARG, "a record's bucket lies outside [%llu, +%llu)", (unsigned long long)bucket_begin, (unsigned long long)n_buckets); goto done; }
+        // one workgroup streams a large group: fine for the repeats of a genome, not for an index that IS one bucket
+        if (h_stats[1] > large_cap || h_stats[0] > (1u << 22)) goto done;           // *done stays 0
+        FinishArgs f;
+        f.rows = cur_rows; f.keys = cur_keys; f.gbegin = gbegin; f.gend = gend; f.n_groups = n_groups; f.L = L;
+        f.n_buckets = n_buckets; f.skip_frequencies = skip_frequencies; f.h2i = (int32_t *)d_hashes_to_index;
+        f.nk = (uint32_t *)d_n_kmers; f.o_kmers = (uint64_t *)d_out_kmers; f.o_nodes = (uint32_t *)d_out_nodes;
+        f.o_refs = (uint64_t *)d_out_ref_offsets; f.o_af = (uint32_t *)d_out_af32; f.o_freq = (uint16_t *)d_out_frequencies;
+        f.o_perm = (uint32_t *)d_out_permutation; f.af_in = (const uint32_t *)d_af32;
+        f.big_buckets = big; f.n_big = stats + 2; f.big_cap = big_cap;
+        f.xcd_groups = (int)ceil_div(n_groups, 8);
+        hipLaunchKernelGGL(k_group_finish, dim3((unsigned)(f.xcd_groups * 8)), dim3(GROUP_THREADS), 0, s, f);
+        HIP_G(hipGetLastError());
+        if (h_stats[1] > 0) {
+            const unsigned n_large = h_stats[1];
+            hipLaunchKernelGGL(k_group_large, dim3(n_large < 1024 ? n_large : 1024), dim3(256), 0, s, f, large, n_large);
+            HIP_G(hipGetLastError());
+        }
+        if (!skip_frequencies) {
+            // frequencies still open: the rows of large groups (all their buckets) and, from k_group_finish, buckets of
+            // more than SMALL_BUCKET rows.  Both go through the first form's kernels over the finished columns.
+            HIP_G(hipMemcpyAsync(h_stats, stats, 16, hipMemcpyDeviceToHost, s));
+            HIP_G(hipStreamSynchronize(s));
+            if (h_stats[1] > 0 || h_stats[2] > 0) {
+                const int n_ranges = (int)h_stats[1] + (int)h_stats[2];
+                HIP_G(gki_dev_malloc((void **)&rng, (size_t)n_ranges * 16));
+                hipLaunchKernelGGL(k_open_ranges, dim3(stream_grid(n_ranges, 256)), dim3(256), 0, s, large, h_stats[1], gbegin, gend,
+                                   big, h_stats[2], (const int32_t *)d_hashes_to_index, (const uint32_t *)d_n_kmers, rng,
+                                   rng + n_ranges);
+                HIP_G(hipGetLastError());
+                rc = gki_frequencies_for_rows(rng, rng + n_ranges, n_ranges, modulo, bucket_begin, d_hashes_to_index, d_n_kmers,
+                                              d_out_kmers, d_out_ref_offsets, d_out_frequencies, n, s);
+                if (rc != GKI_OK) goto done;
+            }
+        }
+        HIP_G(hipStreamSynchronize(s));
+        *done = 1;
+    }
+done:
+    for (int i = 0; i < 2; i++) (void)gki_dev_free(rows[i]);
+    for (int i = 0; i < 3; i++) (void)gki_dev_free(keys[i]);
+    (void)gki_dev_free(hist); (void)gki_dev_free(offs); (void)gki_dev_free(tmp); (void)gki_dev_free(gbegin); (void)gki_dev_free(gend);
+    (void)gki_dev_free(large); (void)gki_dev_free(big); (void)gki_dev_free(stats); (void)gki_dev_free(rng);
+#undef HIP_G
+    return rc;
+}

@@ -498,22 +498,30 @@ extern "C" int gki_measure_random_loads(int64_t table_bytes, int64_t n_loads, do
     *loads_per_s = 0.0;
     if (table_bytes < 4096 || n_loads < 1) return gki_set_error(GKI_ERR_BAD_ARG, "measure_random_loads: bad sizes");
     uint64_t *table = nullptr, *sink = nullptr;
-    HIP_TRY(gki_dev_malloc((void **)&table, (size_t)table_bytes));
-    HIP_TRY(gki_dev_malloc((void **)&sink, 8));
-    HIP_TRY(hipMemset(table, 1, (size_t)table_bytes));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     float ms = 0.f;
+    int rc = GKI_OK;
+    // every early exit passes through `done`: the 2 GB table must not outlive a failed call (bench.py measures with
+    // the whole 3 Gbp output resident)
+#define HIP_G(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = gki_set_error(GKI_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); goto done; } } while (0)
+    HIP_G(gki_dev_malloc((void **)&table, (size_t)table_bytes));
+    HIP_G(gki_dev_malloc((void **)&sink, 8));
+    HIP_G(hipMemset(table, 1, (size_t)table_bytes));
+    HIP_G(hipEventCreate(&e0));
+    HIP_G(hipEventCreate(&e1));
     for (int rep = 0; rep < 2; rep++) {              // the second launch is the measurement
-        HIP_TRY(hipEventRecord(e0, 0));
+        HIP_G(hipEventRecord(e0, 0));
         hipLaunchKernelGGL(k_random_loads, dim3(2048), dim3(256), 0, 0, table, (uint64_t)(table_bytes / 8), n_loads, sink);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(e1, 0));
-        HIP_TRY(hipEventSynchronize(e1));
-        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        HIP_G(hipGetLastError());
+        HIP_G(hipEventRecord(e1, 0));
+        HIP_G(hipEventSynchronize(e1));
+        HIP_G(hipEventElapsedTime(&ms, e0, e1));
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    (void)gki_dev_free(table); (void)gki_dev_free(sink);
     if (ms > 0.f) *loads_per_s = (double)n_loads / ((double)ms * 1e-3);
-    return GKI_OK;
+done:
+#undef HIP_G
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)gki_dev_free(table); (void)gki_dev_free(sink);
+    return rc;
 }

@@ -70,68 +70,119 @@ def _recv_msg(sock):
 
 
 class SocketControlPlane(_GatherControlPlane):
-    """Star over TCP: rank 0 listens on (addr, port), every other rank keeps one connection to it.  A gather is
-    "everyone sends to rank 0, rank 0 sends the list back".  Defaults come from the launcher's environment
-    (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT, as torch.distributed.run and mpirun wrappers export them)."""
+    """Star over TCP: rank 0 listens on ONE port, every other rank keeps one connection to it.  A gather is "everyone
+    sends to rank 0, rank 0 sends the list back".  Defaults come from the launcher's environment (RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT, as torch.distributed.run and mpirun wrappers export them); the port is MASTER_PORT + 1
+    (torch.distributed.run's own rendezvous store listens on MASTER_PORT itself) unless GKI_CONTROL_PORT names another.
 
-    def __init__(self, rank=None, world=None, addr=None, port=None, timeout=120.0):
+    Handshake: a worker sends magic + job token + world + its rank and waits for rank 0's verdict.  The token is
+    derived from MASTER_ADDR:MASTER_PORT and the launcher's run id (TORCHELASTIC_RUN_ID, or GKI_JOB_TOKEN), so a worker
+    of another job on the same host is turned away instead of being adopted.  Rank 0 drops a connection that does not
+    complete the handshake within a few seconds (a port scanner, a health probe), that carries another token or world
+    size, a rank outside 1..world-1 or a rank it already holds, and keeps accepting until every rank has joined or the
+    timeout passes."""
+
+    MAGIC = b"GKI2"
+    HANDSHAKE_SECONDS = 5.0
+
+    @staticmethod
+    def job_token(addr, base_port, world):
+        import hashlib
+        run = os.environ.get("GKI_JOB_TOKEN") or os.environ.get("TORCHELASTIC_RUN_ID") or ""
+        return hashlib.sha256(("%s:%d:%d:%s" % (addr, base_port, world, run)).encode()).digest()[:16]
+
+    def __init__(self, rank=None, world=None, addr=None, port=None, timeout=120.0, token=None):
+        import time
         self.rank = int(os.environ.get("RANK", 0)) if rank is None else int(rank)
         self.world = int(os.environ.get("WORLD_SIZE", 1)) if world is None else int(world)
         addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
-        # one above the launcher's port: torch.distributed.run's own rendezvous store listens on MASTER_PORT itself
-        port = int(port) if port is not None else int(os.environ.get("MASTER_PORT", 29400)) + 1
+        base_port = int(os.environ.get("MASTER_PORT", 29400))
+        if port is None:
+            port = int(os.environ["GKI_CONTROL_PORT"]) if os.environ.get("GKI_CONTROL_PORT") else base_port + 1
+        port = int(port)
         self._peers, self._sock, self._server = [], None, None
         if self.world == 1:
             return
-        # Rank 0 takes the first free port of port .. port+15 and greets every connection with a magic word; the others
-        # try those ports in turn until one answers with it (another service may own a port of the range).
-        magic = b"GKI1" + struct.pack("<q", self.world)
-        ports = range(port, port + 16)
+        if not 0 <= self.rank < self.world:
+            raise ValueError("control plane: rank %d outside 0..%d" % (self.rank, self.world - 1))
+        token = bytes(token) if token is not None else self.job_token(addr, port, self.world)
+        hello = self.MAGIC + token + struct.pack("<qq", self.world, self.rank)
+        deadline = time.time() + timeout
         if self.rank == 0:
-            last = None
-            for cand in ports:
+            # a worker that dials before rank 0 listens can, for an instant, hold the port itself (a TCP self-connection
+            # from an ephemeral source port equal to the target): retry the bind briefly before calling the port taken
+            bind_deadline = time.time() + min(timeout, 3.0)
+            while True:
                 srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
                 srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
                 try:
-                    srv.bind((addr, cand))
-                    self._server = srv
+                    srv.bind((addr, port))
                     break
                 except OSError as e:
-                    last = e
                     srv.close()
-            if self._server is None:
-                raise last
-            self._server.listen(self.world)
-            self._server.settimeout(timeout)
+                    if time.time() > bind_deadline:
+                        raise OSError("control plane: rank 0 cannot listen on %s:%d (%s); set GKI_CONTROL_PORT to a free "
+                                      "port on every rank" % (addr, port, e)) from e
+                    time.sleep(0.1)
+            self._server = srv
+            srv.listen(max(self.world, 8))
             peers = {}
             while len(peers) < self.world - 1:
-                conn, _ = self._server.accept()
-                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                conn.settimeout(timeout)
-                conn.sendall(magic)
-                peers[struct.unpack("<q", _recv_exact(conn, 8))[0]] = conn
+                left = deadline - time.time()
+                if left <= 0:
+                    missing = sorted(set(range(1, self.world)) - set(peers))
+                    self.close()
+                    raise TimeoutError("control plane: ranks %s did not join %s:%d within %.0f s" % (missing, addr, port, timeout))
+                srv.settimeout(min(left, 1.0))
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    continue
+                try:
+                    conn.settimeout(self.HANDSHAKE_SECONDS)
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    got = _recv_exact(conn, len(hello))
+                    w, r = struct.unpack("<qq", got[-16:])
+                    if got[:4] != self.MAGIC or got[4:20] != token or w != self.world or not 1 <= r < self.world or r in peers:
+                        try:
+                            conn.sendall(b"NO")
+                        finally:
+                            conn.close()
+                        continue
+                    conn.sendall(b"OK")
+                    conn.settimeout(timeout)
+                    peers[r] = conn
+                except (OSError, ConnectionError, struct.error):
+                    conn.close()                       # junk or a half-open connection: keep accepting
             self._peers = [peers[r] for r in range(1, self.world)]
         else:
-            import time
-            deadline = time.time() + timeout
+            refused = False
             while self._sock is None:
-                for cand in ports:
-                    try:
-                        sock = socket.create_connection((addr, cand), timeout=2.0)
-                        sock.settimeout(2.0)
-                        if _recv_exact(sock, len(magic)) == magic:
-                            self._sock = sock
-                            break
+                try:
+                    sock = socket.create_connection((addr, port), timeout=2.0)
+                    if sock.getsockname() == sock.getpeername():     # connected to itself: nobody listens yet
                         sock.close()
-                    except (OSError, ConnectionError):
-                        pass
-                if self._sock is None:
-                    if time.time() > deadline:
-                        raise TimeoutError("control plane: rank 0 did not answer on %s:%d..%d" % (addr, port, port + 15))
-                    time.sleep(0.05)
+                        raise ConnectionError("self-connection")
+                    sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    sock.settimeout(max(self.HANDSHAKE_SECONDS, 2.0) + 5.0)
+                    sock.sendall(hello)
+                    verdict = _recv_exact(sock, 2)
+                    if verdict == b"OK":
+                        self._sock = sock
+                        break
+                    sock.close()
+                    refused = verdict == b"NO"
+                    if refused:
+                        break
+                except (OSError, ConnectionError):
+                    pass
+                if time.time() > deadline:
+                    raise TimeoutError("control plane: rank 0 did not answer on %s:%d" % (addr, port))
+                time.sleep(0.05)
+            if refused:
+                raise ConnectionError("control plane: rank 0 at %s:%d turned rank %d away (another job's port, a world-size "
+                                      "mismatch, or a duplicate rank)" % (addr, port, self.rank))
             self._sock.settimeout(timeout)
-            self._sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            self._sock.sendall(struct.pack("<q", self.rank))
 
     def _allgather_bytes(self, payload):
         payload = bytes(payload)
@@ -342,10 +393,137 @@ class Comm:
         _lib.check(_lib.load().gki_comm_allreduce_u32(self.handle, counts.ptr, counts.n))
         return counts
 
+    def info(self):
+        """What RCCL itself reports about the communicator."""
+        w, r = C.c_int(0), C.c_int(-1)
+        _lib.check(_lib.load().gki_comm_info(self.handle, C.byref(w), C.byref(r)))
+        return {"exchange": "rccl", "rccl_ranks": w.value, "rccl_rank": r.value}
+
     def close(self):
         if self.handle is not None:
             _lib.load().gki_comm_destroy(self.handle)
             self.handle = None
+
+
+class SharedDeviceComm:
+    """`Comm`'s interface for ranks (processes) that share ONE device: a multi-rank run rehearsed on a single GPU.
+    RCCL refuses such a communicator (two ranks on one device: ncclInvalidUsage), so the exchanges go through HIP IPC:
+    every rank exports the allocations that hold its columns (gki_ipc_export), the 64-byte handles and the slice tables
+    travel over the control plane, every rank maps its peers' columns (gki_ipc_open) and copies what it is owed
+    device-to-device.  Same results as `Comm`, no xGMI involved; `make_comm` picks it only when ranks share a device."""
+
+    def __init__(self, control):
+        self.control = control
+        self.handle = None
+
+    def _exchange(self, arrays, meta):
+        """Everyone's (handles of `arrays`, meta) -> per rank (list of mapped DeviceArray-like pointers, meta).  Returns
+        (views, metas, close) where views[r][i] is the address of rank r's i-th array in THIS process."""
+        lib = _lib.load()
+        _lib.check(lib.gki_device_synchronize())
+        blob = b""
+        for a in arrays:
+            h, off = C.create_string_buffer(64), C.c_int64(0)
+            _lib.check(lib.gki_ipc_export(a.ptr, h, C.byref(off)))
+            blob += h.raw + struct.pack("<q", off.value)
+        blob += struct.pack("<%dq" % len(meta), *[int(x) for x in meta])
+        everyone = self.control._allgather_bytes(blob)
+        me, opened, views, metas = self.control.rank, [], [], []
+        for r, b in enumerate(everyone):
+            ptrs = []
+            for i in range(len(arrays)):
+                if r == me:
+                    ptrs.append(arrays[i].ptr.value)
+                    continue
+                h, off = b[72 * i:72 * i + 64], struct.unpack_from("<q", b, 72 * i + 64)[0]
+                base = C.c_void_p()
+                _lib.check(lib.gki_ipc_open(h, C.byref(base)))
+                opened.append(base)
+                ptrs.append(base.value + off)
+            views.append(ptrs)
+            metas.append(list(struct.unpack_from("<%dq" % len(meta), b, 72 * len(arrays))))
+
+        def close():
+            _lib.check(lib.gki_device_synchronize())
+            for base in opened:
+                _lib.check(lib.gki_ipc_close(base))
+            self.control.barrier()            # nobody frees a column a peer is still reading
+        return views, metas, close
+
+    @staticmethod
+    def _cols(d):
+        return [d.hashes, d.nodes, d.ref_offsets, d.allele_frequencies]
+
+    def allgather_flat(self, dflat):
+        lib = _lib.load()
+        views, metas, close = self._exchange(self._cols(dflat), [dflat.n])
+        counts = [m[0] for m in metas]
+        out = DeviceFlatKmers.allocate(sum(counts))
+        off = 0
+        for r, n in enumerate(counts):
+            for i, dst in enumerate(self._cols(out)):
+                sz = dst.dtype.itemsize
+                if n > 0:
+                    _lib.check(lib.gki_memcpy_d2d(C.c_void_p(dst.ptr.value + off * sz), C.c_void_p(views[r][i]), n * sz))
+            off += n
+        out.n = off
+        close()
+        return out, counts
+
+    def alltoall_flat(self, dflat, send_start):
+        lib = _lib.load()
+        me = self.control.rank
+        views, metas, close = self._exchange(self._cols(dflat), send_start)
+        recv_counts = [m[me + 1] - m[me] for m in metas]
+        recv_start = np.concatenate([[0], np.cumsum(recv_counts)]).astype(np.int64)
+        out = DeviceFlatKmers.allocate(int(recv_start[-1]))
+        for r, m in enumerate(metas):
+            for i, dst in enumerate(self._cols(out)):
+                sz = dst.dtype.itemsize
+                if recv_counts[r] > 0:
+                    _lib.check(lib.gki_memcpy_d2d(C.c_void_p(dst.ptr.value + int(recv_start[r]) * sz),
+                                                  C.c_void_p(views[r][i] + m[me] * sz), recv_counts[r] * sz))
+        out.n = int(recv_start[-1])
+        close()
+        return out, [int(x) for x in recv_start]
+
+    def allreduce_counts(self, counts):
+        lib = _lib.load()
+        views, _, close = self._exchange([counts], [counts.n])
+        total = np.zeros(counts.n, dtype=np.uint64)
+        tmp = np.empty(counts.n, dtype=np.uint32)
+        for r in range(self.control.world):
+            _lib.check(lib.gki_memcpy_d2h(_lib.hptr(tmp), C.c_void_p(views[r][0]), tmp.nbytes))
+            total += tmp
+        self.control.barrier()                # every rank has read every buffer before anyone overwrites its own
+        total = total.astype(np.uint32)       # uint32 wrap like ncclSum
+        _lib.check(lib.gki_memcpy_h2d(counts.ptr, _lib.hptr(total), total.nbytes))
+        close()
+        return counts
+
+    def info(self):
+        return {"exchange": "hip-ipc", "rccl_ranks": None,
+                "why": "the ranks share one device and RCCL refuses a communicator with duplicate devices"}
+
+    def close(self):
+        pass
+
+
+def device_identity():
+    """(hostname, PCI bus id of the current device): what tells two ranks on one GPU from two ranks on two GPUs."""
+    buf = C.create_string_buffer(64)
+    _lib.check(_lib.load().gki_device_bus_id(buf, 64))
+    return "%s/%s" % (socket.gethostname(), buf.value.decode())
+
+
+def make_comm(control):
+    """The exchange layer for this job: RCCL (`Comm`) when every rank has a device of its own, HIP IPC
+    (`SharedDeviceComm`) when ranks share one."""
+    mine = device_identity().encode()
+    ids = control._allgather_bytes(mine) if hasattr(control, "_allgather_bytes") else [mine]
+    if len(set(ids)) < len(ids):
+        return SharedDeviceComm(control)
+    return Comm(control)
 
 
 def find_sharded(graph_arrays, k, critical_graph_paths, rank, world, **finder_kwargs):

@@ -260,6 +260,16 @@ int gki_index_build_range(const void *d_kmers, const void *d_nodes, const void *
                           void *d_hashes_to_index, void *d_n_kmers,
                           void *d_out_kmers, void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32,
                           void *d_out_frequencies, void *d_out_permutation);
+/* The build has two forms with identical results.  gki_index_build(_range) runs the row-carrying form (the 24-byte
+ * payload travels with its key through stable partition passes, the last bits are sorted inside LDS; no random access)
+ * and hands over to the pair-sorting form (stable LSD sort of (bucket, index) pairs, then one gather of the payload)
+ * when a group of 2^L neighbouring buckets holds more than 2^22 records (an index that is a handful of buckets).
+ * gki_index_build_pairs runs the pair-sorting form directly: same arguments, same outputs. */
+int gki_index_build_pairs(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32,
+                          int64_t n, uint64_t modulo, uint64_t bucket_begin, uint64_t n_buckets, int skip_frequencies,
+                          void *d_hashes_to_index, void *d_n_kmers,
+                          void *d_out_kmers, void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32,
+                          void *d_out_frequencies, void *d_out_permutation);
 
 /* ---------------------------------------------------------------- ReverseKmerIndex
  * Replaces ReverseKmerIndex.from_flat_kmers (reverse_kmer_index.py:47-60): records stably sorted by
@@ -336,6 +346,16 @@ int gki_probe_reads_count_nodes(gki_probe *p, const void *d_reads, const void *d
  * load that misses L2 is one 64-byte request -- the unit the probe kernels are bound by, not bytes).  Runs n_loads loads
  * twice and reports the second launch.  bench.py reports the read-side rate as a fraction of this. */
 int gki_measure_random_loads(int64_t table_bytes, int64_t n_loads, double *loads_per_s);
+/* The store ceiling of THIS device for the FlatKmers column pattern: writes n records of the four columns (8 + 4 + 8 + 4
+ * bytes; the caller's buffers, e.g. the output columns before a run) with nothing else in the kernel, three launches,
+ * best of the last two; bytes_per_s = 24 n / time.  bench.py prints it beside the 8 TB/s spec peak. */
+int gki_measure_store_bw(void *d_hashes, void *d_nodes, void *d_ref_offsets, void *d_af32, int64_t n, double *bytes_per_s);
+/* Read simulator on the device (benchmark input for BASELINE configs[4]): n_reads reads of read_len
+ * letters (ASCII ACGT) sampled from a haplotype (uint8 codes 0..3 in HBM): uniform start, either strand, every base
+ * substituted with p_substitution, a read replaced by uniform random letters with p_random_read.  Counter-based: read
+ * first_read + q is a pure function of (seed, its index), so batches of one run and a NumPy restatement agree. */
+int gki_simulate_reads(const void *d_haplotype, int64_t hap_len, int64_t n_reads, int read_len, uint64_t seed,
+                       double p_substitution, double p_random_read, int64_t first_read, void *d_letters);
 
 /* ---------------------------------------------------------------- multi-GPU exchange (RCCL over xGMI)
  * One process per GPU.  The reference gathers its per-process FlatKmers by pickling them through a
@@ -351,6 +371,18 @@ typedef struct gki_comm gki_comm;
 int gki_comm_get_unique_id(void *h_id);
 int gki_comm_create(gki_comm **out, int world_size, int rank, const void *h_id);
 int gki_comm_destroy(gki_comm *c);
+/* What RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank). */
+int gki_comm_info(gki_comm *c, int *rccl_world, int *rccl_rank);
+/* Ranks that share ONE device.  RCCL refuses a communicator with two ranks on the same device (ncclInvalidUsage), so
+ * a multi-rank run on a single GPU exchanges through HIP IPC instead: gki_device_bus_id tells the ranks apart
+ * (PCI bus id of the current device), gki_ipc_export gives the 64-byte handle of the allocation that holds d_ptr and
+ * d_ptr's offset inside it, gki_ipc_open maps a peer's allocation (returns its base), gki_ipc_close unmaps it.  The
+ * handles travel over the caller's control plane (parallel.SharedDeviceComm). */
+#define GKI_IPC_HANDLE_BYTES 64
+int gki_device_bus_id(char *buf, int len);
+int gki_ipc_export(const void *d_ptr, void *h_handle, int64_t *offset);
+int gki_ipc_open(const void *h_handle, void **d_base);
+int gki_ipc_close(void *d_base);
 /* All-to-all(v) of FlatKmers columns for the bucket-range partitioned build: the send columns hold this rank's records
  * partitioned by destination, slice r = [h_send_start[r], h_send_start[r+1]); what rank r sends to this rank lands at
  * [h_recv_start[r], h_recv_start[r+1]) of the receive columns (both tables host int64[world+1]; the counts travel

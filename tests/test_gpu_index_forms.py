@@ -1,0 +1,126 @@
+"""The two forms of the CollisionFreeKmerIndex build (collision_free_kmer_index.py:423-467, set_frequencies :267-293):
+the row-carrying form (csrc/gki_index_rows.hip: partition passes + in-LDS finish) and the pair-sorting form
+(csrc/gki_index.hip) must agree element by element with the oracle's stable build and with each other, on every shape
+the row-carrying form treats differently: no / one / two / three partition passes, groups finished in LDS, groups too
+large for LDS (streamed by one workgroup), buckets past the per-lane frequency path, a bucket range, a wanted
+permutation, and the hand-over to the pair-sorting form for an index that is one giant bucket."""
+import numpy as np
+import pytest
+
+from graph_kmer_index_amd import _lib
+from graph_kmer_index_amd.flat_kmers import FlatKmers, DeviceFlatKmers
+from graph_kmer_index_amd.collision_free_kmer_index import DeviceIndex, bucket_range
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+COLS = (("_hashes_to_index", "hashes_to_index"), ("_n_kmers", "n_kmers"), ("_kmers", "kmers"), ("_nodes", "nodes"),
+        ("_ref_offsets", "ref_offsets"), ("_allele_frequencies", "allele_frequencies"), ("_frequencies", "frequencies"))
+
+
+def _records(n, n_distinct, seed, heavy=0):
+    """n records over a pool of n_distinct k-mers; `heavy` of them repeat one k-mer (a bucket of that size)."""
+    rng = np.random.default_rng(seed)
+    pool = rng.integers(0, 4 ** 31, size=n_distinct, dtype=np.uint64)
+    kmers = pool[rng.integers(0, n_distinct, size=n)]
+    if heavy:
+        kmers[rng.choice(n, size=heavy, replace=False)] = pool[0]
+    nodes = rng.integers(0, 1 << 24, size=n).astype(np.uint32)
+    refs = (kmers % np.uint64(50)) + rng.integers(0, 30, size=n).astype(np.uint64)
+    af = rng.uniform(0, 1, size=n).astype(np.float32)
+    return kmers, nodes, refs, af
+
+
+def _check(dev, o, n, perm=None):
+    for name, attr in COLS:
+        got = getattr(dev, attr).to_host(len(o[name]) if name in ("_hashes_to_index", "_n_kmers") else n)
+        assert np.array_equal(got, o[name]), name
+    if perm is not None:
+        assert np.array_equal(dev.permutation.to_host(n), perm)
+
+
+@pytest.mark.parametrize("n,modulo,n_distinct,heavy", [
+    (7, 4, 5, 0),                       # one group, no real partition pass
+    (5000, 1009, 3000, 0),              # 10-bit key: all of it inside LDS
+    (300000, 65537, 5000, 0),           # one partition pass; buckets of ~60 records (large-bucket frequencies)
+    (200000, 452930477, 150000, 0),     # default modulo, sparse: two passes of 9 bits, nearly empty groups
+    (400000, 1 << 21, 300000, 0),       # two passes
+    (250000, 4294967291, 200000, 0),    # 32-bit key: three passes
+    (50000, 7, 40, 0),                  # seven buckets of ~7000 records: groups streamed by one workgroup each
+    (600000, 1000003, 400000, 30000),   # a 30 000-record bucket inside an ordinary index: one large group
+    (70000, 1000003, 3, 0),             # three giant buckets
+    (3000, 2, 1, 0),                    # a single k-mer
+])
+@pytest.mark.parametrize("skip_frequencies", [False, True])
+def test_both_forms_equal_the_oracle(n, modulo, n_distinct, heavy, skip_frequencies):
+    kmers, nodes, refs, af = _records(n, n_distinct, seed=n + modulo % 1000, heavy=heavy)
+    o = oracle.index_build(kmers, nodes, refs, af, modulo=modulo, skip_frequencies=skip_frequencies)
+    d = DeviceFlatKmers.from_flat_kmers(FlatKmers(kmers, nodes, refs, af))
+    order = np.argsort(kmers % np.uint64(modulo), kind="stable").astype(np.uint32)
+    for pairs in (False, True):
+        for want_perm in (False, True):
+            dev = DeviceIndex.build(d, modulo, skip_frequencies, want_permutation=want_perm, pairs_form=pairs)
+            _check(dev, o, n, order if want_perm else None)
+            dev.free()
+    d.free()
+
+
+def test_bucket_range_slices_and_out_of_range_record():
+    n, modulo, world = 300000, 999983, 3
+    kmers, nodes, refs, af = _records(n, 200000, seed=5)
+    full = oracle.index_build(kmers, nodes, refs, af, modulo=modulo)
+    buckets = kmers % np.uint64(modulo)
+    for r in range(world):
+        lo, hi = bucket_range(modulo, world, r)
+        sel = (buckets >= lo) & (buckets < hi)
+        d = DeviceFlatKmers.from_flat_kmers(FlatKmers(kmers[sel], nodes[sel], refs[sel], af[sel]))
+        for pairs in (False, True):
+            dev = DeviceIndex.build(d, modulo, bucket_begin=lo, n_buckets=hi - lo, pairs_form=pairs)
+            first = int(np.searchsorted(np.sort(buckets, kind="stable"), lo))
+            m = int(sel.sum())
+            assert np.array_equal(dev.kmers.to_host(m), full["_kmers"][first:first + m])
+            assert np.array_equal(dev.frequencies.to_host(m), full["_frequencies"][first:first + m])
+            nk = dev.n_kmers.to_host()
+            assert np.array_equal(nk, full["_n_kmers"][lo:hi])
+            h2i = dev.hashes_to_index.to_host()
+            assert np.array_equal(h2i[nk > 0], full["_hashes_to_index"][lo:hi][nk > 0] - first)
+            assert not h2i[nk == 0].any()
+            dev.free()
+        d.free()
+    # a record outside the range is refused by both forms
+    lo, hi = bucket_range(modulo, world, 1)
+    d = DeviceFlatKmers.from_flat_kmers(FlatKmers(kmers[:1000], nodes[:1000], refs[:1000], af[:1000]))
+    for pairs in (False, True):
+        with pytest.raises(_lib.GkiError):
+            DeviceIndex.build(d, modulo, bucket_begin=lo, n_buckets=hi - lo, pairs_form=pairs)
+    d.free()
+
+
+def test_giant_bucket_hands_over_to_the_pair_sorting_form():
+    # one k-mer 4.3 million times: a group past what one workgroup should stream; gki_index_build still answers,
+    # through the pair-sorting form, and equals the oracle
+    n = (1 << 22) + 100000
+    rng = np.random.default_rng(3)
+    kmers = np.full(n, 123456789123, dtype=np.uint64)
+    kmers[::1000] = rng.integers(0, 4 ** 31, size=len(kmers[::1000]), dtype=np.uint64)
+    nodes = rng.integers(0, 1 << 20, size=n).astype(np.uint32)
+    refs = rng.integers(0, 40000, size=n).astype(np.uint64)
+    af = np.ones(n, np.float32)
+    o = oracle.index_build(kmers, nodes, refs, af, modulo=1000003)
+    d = DeviceFlatKmers.from_flat_kmers(FlatKmers(kmers, nodes, refs, af))
+    dev = DeviceIndex.build(d, 1000003)
+    _check(dev, o, n)
+    dev.free()
+    d.free()
+
+
+def test_a_million_records_default_modulo_device_resident():
+    # the shape of the bench's index_build record at 1/300 of its size: dense enough that groups hold ~1400 rows
+    n, modulo = 1 << 20, 1530013
+    kmers, nodes, refs, af = _records(n, 900000, seed=11)
+    o = oracle.index_build(kmers, nodes, refs, af, modulo=modulo)
+    d = DeviceFlatKmers.from_flat_kmers(FlatKmers(kmers, nodes, refs, af))
+    dev = DeviceIndex.build(d, modulo)
+    _check(dev, o, n)
+    dev.free()
+    d.free()

@@ -133,23 +133,63 @@ def _socket_worker(rank, world, port, tmpdir):
     plane.close()
 
 
+def _intruders(port, world, stop):
+    """What a shared host throws at rank 0's port while the real ranks join: a connection that says nothing, one that
+    sends junk, a worker of another job (wrong token), a rank outside the world, and a second 'rank 1'."""
+    import socket
+    import struct
+    import time
+    from graph_kmer_index_amd.parallel import SocketControlPlane as P
+    good = P.job_token("127.0.0.1", port, world)
+    hellos = [b"GET / HTTP/1.0\r\n\r\n" + b"x" * 40, P.MAGIC + b"\0" * 16 + struct.pack("<qq", world, 1),
+              P.MAGIC + good + struct.pack("<qq", world, world + 3), None, P.MAGIC + good + struct.pack("<qq", world, 1)]
+    verdicts = []
+    for h in hellos:
+        deadline = time.time() + 20
+        while time.time() < deadline and not stop.is_set():
+            try:
+                c = socket.create_connection(("127.0.0.1", port), timeout=1.0)
+                if c.getsockname() == c.getpeername():       # TCP self-connection: rank 0 is not listening yet
+                    c.close()
+                    raise OSError("self-connection")
+            except OSError:
+                time.sleep(0.05)
+                continue
+            try:
+                if h is not None:
+                    c.sendall(h)
+                c.settimeout(8.0)
+                verdicts.append(c.recv(2))
+            except OSError:
+                verdicts.append(b"")
+            c.close()
+            break
+    return verdicts
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_socket_control_plane_ranks(tmp_path, world):
+    """World 2 and 3 over the product's control plane, with intruders on the port (a junk client, another
+    job's worker, an out-of-range rank, a silent connection must neither be adopted nor stop the job)."""
     import multiprocessing
-    import socket
+    import threading
     port = 31000 + os.getpid() % 2000 + 20 * world
-    # the first port of the range belongs to somebody else: rank 0 moves on, the others find it by its greeting
-    squatter = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-    squatter.bind(("127.0.0.1", port))
-    squatter.listen(8)
     ctx = multiprocessing.get_context("spawn")
     procs = [ctx.Process(target=_socket_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
-    for p in procs:
+    stop, seen = threading.Event(), []
+    intruder = threading.Thread(target=lambda: seen.extend(_intruders(port, world, stop)))
+    procs[0].start()
+    intruder.start()
+    import time
+    time.sleep(1.0)                          # the intruders get there first
+    for p in procs[1:]:
         p.start()
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    squatter.close()
+    stop.set()
+    intruder.join(30)
+    assert len(seen) >= 3 and b"OK" not in seen[:4]       # junk, foreign token, rank out of range, silence: never adopted
     parts = [np.load(str(tmp_path / ("r%d.npz" % r))) for r in range(world)]
     g = synthetic_snp_graph(60000, 700, k=31, seed=21)
     n_full = len(oracle.find(g, 31, None, True, 5)["kmers"])
@@ -158,3 +198,23 @@ def test_socket_control_plane_ranks(tmp_path, world):
         assert p["ident"].tolist() == list(range(128))
         assert np.array_equal(p["matrix"], np.stack([q["send"] for q in parts]))
         assert float(p["slowest"]) == world - 0.5
+
+
+def test_socket_control_plane_reports_a_taken_port():
+    import socket
+    from graph_kmer_index_amd.parallel import SocketControlPlane
+    port = 33500 + os.getpid() % 1000
+    squatter = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    squatter.bind(("127.0.0.1", port))
+    squatter.listen(1)
+    try:
+        with pytest.raises(OSError, match="GKI_CONTROL_PORT"):
+            SocketControlPlane(0, 2, "127.0.0.1", port, timeout=2.0)
+    finally:
+        squatter.close()
+
+
+def test_socket_control_plane_names_the_ranks_that_never_joined():
+    from graph_kmer_index_amd.parallel import SocketControlPlane
+    with pytest.raises(TimeoutError, match=r"ranks \[1, 2\]"):
+        SocketControlPlane(0, 3, "127.0.0.1", 34600 + os.getpid() % 1000, timeout=1.5)
