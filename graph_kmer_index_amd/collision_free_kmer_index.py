@@ -423,6 +423,11 @@ class CollisionFreeKmerIndex:
         flags.free()
         return out
 
+    def has_kmers_parallel(self, kmers, n_threads=1):
+        """collision_free_kmer_index.py:222-232 spreads `has_kmers` over a shared-memory process pool; one batched probe
+        on the device does the whole array, so `n_threads` is accepted and ignored."""
+        return self.has_kmers(kmers)
+
     def map_kmers(self, kmers, n_nodes):
         """kmer_mapper.map_kmers_to_graph_index equivalent (:210-212): node hit counts, probe and histogram fused
         on the device."""

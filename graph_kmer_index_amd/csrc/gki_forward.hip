@@ -70,9 +70,11 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
         if (cur[j] >= end[j]) { L--; continue; }
         int32_t q;
         if (forced[j]) {
-            // :386-388 forced traversal: only the successors in the follow set, and -- the reference iterates a Python
-            // set of small ints there -- in ascending id order whatever the successor list says.  cur[j] counts the
-            // forced successors already taken; last[j] is the latest of them.
+            // :386-388 forced traversal: only the successors in the follow set.  The reference iterates a Python set
+            // there, and CPython orders a set of small ints by hash & table mask, not by value (list({7, 8}) is
+            // [8, 7]): among SEVERAL forced successors of one node the reference's order is an accident of the
+            // interpreter and is not reproduced.  They are taken in ascending id here (deterministic); parity for
+            // such nodes is on the multiset of records.  last[j] is the latest forced successor taken.
             q = INT_MAX;
             for (int32_t e = (int32_t)g.edge_start[nd[j]]; e < end[j]; e++) {
                 const int32_t c = g.edges[e];

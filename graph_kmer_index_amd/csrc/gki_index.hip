@@ -17,6 +17,9 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
                          uint64_t modulo, uint64_t bucket_begin, uint64_t n_buckets, int skip_frequencies,
                          void *d_hashes_to_index, void *d_n_kmers, void *d_out_kmers, void *d_out_nodes,
                          void *d_out_ref_offsets, void *d_out_af32, void *d_out_frequencies, void *d_out_permutation, int *done);
+int gki_partition_columns_by_part(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
+                                  uint64_t modulo, int n_parts, void *d_out_kmers, void *d_out_nodes, void *d_out_ref_offsets,
+                                  void *d_out_af32, int64_t *h_part_start);
 int gki_frequencies_for_rows(const int64_t *d_row_begin, const int64_t *d_row_end, int n_ranges, uint64_t modulo,
                              uint64_t bucket_begin, const void *d_hashes_to_index, const void *d_n_kmers,
                              const void *d_kmers, const void *d_refs, void *d_freq, int64_t n, hipStream_t s);
@@ -37,22 +40,6 @@ __global__ __launch_bounds__(256) void k_bucket_keys(const uint64_t *__restrict_
         const uint64_t b = kmers[i] % modulo - bucket_begin;       // collision_free_kmer_index.py:433
         if (b >= n_buckets) *out_of_range = 1;
         keys[i] = b < n_buckets ? (uint32_t)b : 0u;
-        idx[i] = (uint32_t)i;
-    }
-}
-
-// bucket-range partition: part p owns the buckets [modulo*p/n_parts, modulo*(p+1)/n_parts)
-__device__ __host__ inline uint64_t part_begin(uint64_t modulo, int n_parts, int p) { return modulo * (uint64_t)p / (uint64_t)n_parts; }
-
-__global__ __launch_bounds__(256) void k_part_keys(const uint64_t *__restrict__ kmers, int64_t n, uint64_t modulo, int n_parts,
-                                                   uint32_t *__restrict__ keys, uint32_t *__restrict__ idx) {
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint64_t b = kmers[i] % modulo;
-        int p = (int)(b * (uint64_t)n_parts / modulo);
-        while (p + 1 < n_parts && part_begin(modulo, n_parts, p + 1) <= b) p++;
-        while (p > 0 && part_begin(modulo, n_parts, p) > b) p--;
-        keys[i] = (uint32_t)p;
         idx[i] = (uint32_t)i;
     }
 }
@@ -410,15 +397,6 @@ static int radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], int64_t n, int
     return GKI_OK;
 }
 
-// first position of every part in the sorted part ids (lower bound); start[n_parts] = n
-__global__ void k_part_starts(const uint32_t *__restrict__ keys, int64_t n, int n_parts, int64_t *__restrict__ start) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p > n_parts) return;
-    int64_t lo = 0, hi = n;
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (keys[mid] < (uint32_t)p) lo = mid + 1; else hi = mid; }
-    start[p] = lo;
-}
-
 // FlatKmers.get_new_without_singletons (flat_kmers.py:98-125): a record is kept iff an EARLIER record carries the same
 // hash.  After the stable sort by bucket the records of a bucket are in input order, so "earlier" = an earlier position
 // of the bucket's run; the flag goes back to the record's original position.
@@ -704,47 +682,9 @@ int gki_partition_by_bucket_range(const void *d_kmers, const void *d_nodes, cons
     if (n >= (1ll << 31)) return gki_set_error(GKI_ERR_OVERFLOW, "%lld records: partition at most 2^31-1 at a time", (long long)n);
     for (int p = 0; p <= n_parts; p++) h_part_start[p] = 0;
     if (n <= 0) return GKI_OK;
-    hipStream_t s = 0;
-    const int64_t hist_n = (int64_t)RBINS * ceil_div(n, RTILE);
-    const int64_t tmp_bytes = gki_scan_tmp_bytes(hist_n);
-    uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *hist = nullptr, *offs = nullptr;
-    int64_t *pstart = nullptr;
-    uint4 *rows = nullptr;
-    void *tmp = nullptr;
-    int rc = GKI_OK;
-#define HIP_G(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = gki_set_error(GKI_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); goto done; } } while (0)
-    {
-        for (int i = 0; i < 2; i++) {
-            HIP_G(gki_dev_malloc((void **)&keys[i], (size_t)n * 4));
-            HIP_G(gki_dev_malloc((void **)&vals[i], (size_t)n * 4));
-        }
-        HIP_G(gki_dev_malloc((void **)&hist, (size_t)hist_n * 4));
-        HIP_G(gki_dev_malloc((void **)&offs, (size_t)(hist_n + 1) * 4));
-        HIP_G(gki_dev_malloc(&tmp, (size_t)tmp_bytes));
-        HIP_G(gki_dev_malloc((void **)&rows, (size_t)n * 32));
-        HIP_G(gki_dev_malloc((void **)&pstart, 257 * 8));
-        hipLaunchKernelGGL(k_part_keys, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const uint64_t *)d_kmers, n, modulo, n_parts,
-                           keys[0], vals[0]);
-        HIP_G(hipGetLastError());
-        int cur = 0;
-        rc = radix_sort_pairs(keys, vals, n, key_bits((uint64_t)n_parts - 1), hist, offs, tmp, tmp_bytes, s, &cur);
-        if (rc != GKI_OK) goto done;
-        hipLaunchKernelGGL(k_pack_rows, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const uint64_t *)d_kmers,
-                           (const uint32_t *)d_nodes, (const uint64_t *)d_ref_offsets, (const float *)d_af32, n, rows);
-        HIP_G(hipGetLastError());
-        hipLaunchKernelGGL(k_gather_rows, dim3(stream_grid(n, 256)), dim3(256), 0, s, vals[cur], n, (const uint4 *)rows,
-                           (uint64_t *)d_out_kmers, (uint32_t *)d_out_nodes, (uint64_t *)d_out_ref_offsets, (float *)d_out_af32);
-        HIP_G(hipGetLastError());
-        hipLaunchKernelGGL(k_part_starts, dim3(2), dim3(256), 0, s, keys[cur], n, n_parts, pstart);
-        HIP_G(hipGetLastError());
-        HIP_G(hipMemcpyAsync(h_part_start, pstart, (size_t)(n_parts + 1) * 8, hipMemcpyDeviceToHost, s));
-        HIP_G(hipStreamSynchronize(s));
-    }
-done:
-    for (int i = 0; i < 2; i++) { (void)gki_dev_free(keys[i]); (void)gki_dev_free(vals[i]); }
-    (void)gki_dev_free(hist); (void)gki_dev_free(offs); (void)gki_dev_free(tmp); (void)gki_dev_free(rows); (void)gki_dev_free(pstart);
-#undef HIP_G
-    return rc;
+    // one stable pass of the row-carrying build's partition kernel, columns in, columns out (gki_index_rows.hip)
+    return gki_partition_columns_by_part(d_kmers, d_nodes, d_ref_offsets, d_af32, n, modulo, n_parts, d_out_kmers, d_out_nodes,
+                                         d_out_ref_offsets, d_out_af32, h_part_start);
 }
 
 int gki_flag_repeated_kmers(const void *d_kmers, int64_t n, void *d_flags) {

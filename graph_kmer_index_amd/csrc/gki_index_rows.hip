@@ -42,6 +42,7 @@ struct PartArgs {
     int shift, bits;
     const uint32_t *offs;          // [bins * n_tiles] exclusive scan of the bin-major tile histograms
     uint64_t *rows_out; uint32_t *keys_out;
+    uint64_t *o_kmers; uint32_t *o_nodes; uint64_t *o_refs; uint32_t *o_af;   // DST_COLS: the sorted tile leaves as four columns
     int carry_index;               // the row's input index rides in place of the allele frequency (permutation wanted)
     int xcd_tiles;                 // > 0: block b works on tile (b % 8) * xcd_tiles + b / 8, so that neighbouring tiles
                                    // (whose runs are adjacent in memory) go through the same XCD's L2
@@ -115,7 +116,7 @@ __device__ __forceinline__ void wave_rank(const uint32_t (&dig)[RI], const bool 
 }
 
 // One stable partition pass over a tile of THREADS * RI rows.
-template <int THREADS, int RI, bool SRC_COLS>
+template <int THREADS, int RI, bool SRC_COLS, bool DST_COLS = false>
 __global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
     constexpr int TILE = THREADS * RI, W = THREADS / 64, SLICE = TILE / W;
     __shared__ uint64_t s_rows[TILE * 3];
@@ -237,6 +238,20 @@ __global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
     __syncthreads();
 
     // (6) the sorted tile leaves as one contiguous run per digit: consecutive lanes, consecutive words
+    if (DST_COLS) {
+#pragma unroll
+        for (int r = 0; r < RI; r++) {
+            const int p = r * THREADS + threadIdx.x;
+            if (p < n_here) {
+                const uint32_t d = (s_keys[p] >> a.shift) & mask;
+                const int64_t row = (int64_t)(uint32_t)(s_toff[d] + (uint32_t)p);
+                const uint64_t w2 = s_rows[p * 3 + 2];
+                a.o_kmers[row] = s_rows[p * 3]; a.o_refs[row] = s_rows[p * 3 + 1];
+                a.o_nodes[row] = (uint32_t)w2; a.o_af[row] = (uint32_t)(w2 >> 32);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 3 * RI; r++) {
         const int j = r * THREADS + threadIdx.x;
@@ -594,6 +609,7 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
             a.c_refs = (const uint64_t *)d_ref_offsets; a.c_af = (const uint32_t *)d_af32; a.rows_in = cur_rows;
             a.n = n; a.n_tiles = n_tiles; a.shift = shift; a.bits = bits; a.offs = offs; a.carry_index = d_out_permutation != nullptr;
             a.rows_out = rows[p & 1]; a.keys_out = keys[1 + (p & 1)];
+            a.o_kmers = nullptr; a.o_nodes = nullptr; a.o_refs = nullptr; a.o_af = nullptr;
             a.xcd_tiles = (int)ceil_div(n_tiles, 8);
             const unsigned grid = (unsigned)(a.xcd_tiles * 8);
             if (p == 0) hipLaunchKernelGGL((k_partition_rows<THREADS, RI, true>), dim3(grid), dim3(THREADS), 0, s, a);
@@ -653,6 +669,81 @@ done:
     for (int i = 0; i < 3; i++) (void)gki_dev_free(keys[i]);
     (void)gki_dev_free(hist); (void)gki_dev_free(offs); (void)gki_dev_free(tmp); (void)gki_dev_free(gbegin); (void)gki_dev_free(gend);
     (void)gki_dev_free(large); (void)gki_dev_free(big); (void)gki_dev_free(stats); (void)gki_dev_free(rng);
+#undef HIP_G
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------ bucket-range partition
+// gki_partition_by_bucket_range through ONE pass of the kernel above: key = owning part (<= 256 parts = 8 bits), the four
+// input columns in, the four output columns out, stable.  68 bytes of traffic per record where the pair-sorting route
+// (sort (part, index) pairs, pack 32-byte rows, gather them) moved 148.
+namespace {
+__device__ __host__ inline uint64_t part_begin_of(uint64_t modulo, int n_parts, int p) { return modulo * (uint64_t)p / (uint64_t)n_parts; }
+
+__global__ __launch_bounds__(256) void k_part_ids(const uint64_t *__restrict__ kmers, int64_t n, uint64_t modulo, int n_parts,
+                                                  uint32_t *__restrict__ keys) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t b = kmers[i] % modulo;
+        int p = (int)(b * (uint64_t)n_parts / modulo);
+        while (p + 1 < n_parts && part_begin_of(modulo, n_parts, p + 1) <= b) p++;
+        while (p > 0 && part_begin_of(modulo, n_parts, p) > b) p--;
+        keys[i] = (uint32_t)p;
+    }
+}
+
+__global__ void k_part_first_rows(const uint32_t *__restrict__ offs, int64_t n_tiles, int n_parts, int bins, int64_t n,
+                                  int64_t *__restrict__ start) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > n_parts) return;
+    start[p] = p < bins && p < n_parts ? (int64_t)offs[(int64_t)p * n_tiles] : n;     // first row of part p = its run in tile 0
+}
+}  // namespace
+
+int gki_partition_columns_by_part(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
+                                  uint64_t modulo, int n_parts, void *d_out_kmers, void *d_out_nodes, void *d_out_ref_offsets,
+                                  void *d_out_af32, int64_t *h_part_start) {
+    constexpr int THREADS = GKI_PT_THREADS, RI = GKI_PT_RI, TILE = THREADS * RI;
+    hipStream_t s = 0;
+    int bits = 0;
+    while ((1 << bits) < n_parts) bits++;
+    const int bins = 1 << bits;
+    const int64_t n_tiles = ceil_div(n, TILE);
+    const int64_t hist_n = (int64_t)bins * n_tiles;
+    const int64_t tmp_bytes = gki_scan_tmp_bytes(hist_n);
+    uint32_t *keys = nullptr, *hist = nullptr, *offs = nullptr;
+    int64_t *pstart = nullptr;
+    void *tmp = nullptr;
+    int rc = GKI_OK;
+#define HIP_G(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = gki_set_error(GKI_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); goto done; } } while (0)
+    {
+        HIP_G(gki_dev_malloc((void **)&keys, (size_t)n * 4));
+        HIP_G(gki_dev_malloc((void **)&hist, (size_t)hist_n * 4));
+        HIP_G(gki_dev_malloc((void **)&offs, (size_t)(hist_n + 1) * 4));
+        HIP_G(gki_dev_malloc(&tmp, (size_t)tmp_bytes));
+        HIP_G(gki_dev_malloc((void **)&pstart, 257 * 8));
+        hipLaunchKernelGGL(k_part_ids, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const uint64_t *)d_kmers, n, modulo, n_parts, keys);
+        HIP_G(hipGetLastError());
+        hipLaunchKernelGGL((k_digit_hist<THREADS, RI>), dim3((unsigned)n_tiles), dim3(THREADS), 0, s, keys, n, 0, bits, hist, n_tiles);
+        HIP_G(hipGetLastError());
+        rc = gki_scan_u32_to_u32(hist, hist_n, offs, tmp, tmp_bytes, s);
+        if (rc != GKI_OK) goto done;
+        PartArgs a;
+        a.keys_in = keys; a.c_kmers = (const uint64_t *)d_kmers; a.c_nodes = (const uint32_t *)d_nodes;
+        a.c_refs = (const uint64_t *)d_ref_offsets; a.c_af = (const uint32_t *)d_af32; a.rows_in = nullptr;
+        a.n = n; a.n_tiles = n_tiles; a.shift = 0; a.bits = bits; a.offs = offs; a.rows_out = nullptr; a.keys_out = nullptr;
+        a.o_kmers = (uint64_t *)d_out_kmers; a.o_nodes = (uint32_t *)d_out_nodes; a.o_refs = (uint64_t *)d_out_ref_offsets;
+        a.o_af = (uint32_t *)d_out_af32; a.carry_index = 0;
+        a.xcd_tiles = (int)ceil_div(n_tiles, 8);
+        hipLaunchKernelGGL((k_partition_rows<THREADS, RI, true, true>), dim3((unsigned)(a.xcd_tiles * 8)), dim3(THREADS), 0, s, a);
+        HIP_G(hipGetLastError());
+        hipLaunchKernelGGL(k_part_first_rows, dim3(2), dim3(256), 0, s, offs, n_tiles, n_parts, bins, n, pstart);
+        HIP_G(hipGetLastError());
+        HIP_G(hipMemcpyAsync(h_part_start, pstart, (size_t)(n_parts + 1) * 8, hipMemcpyDeviceToHost, s));
+        HIP_G(hipStreamSynchronize(s));
+    }
+done:
+    (void)gki_dev_free(keys); (void)gki_dev_free(hist); (void)gki_dev_free(offs); (void)gki_dev_free(tmp); (void)gki_dev_free(pstart);
 #undef HIP_G
     return rc;
 }

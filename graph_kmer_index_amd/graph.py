@@ -94,7 +94,7 @@ class GraphArrays:
 
     # ------------------------------------------------------------------ builders
     @classmethod
-    def from_dicts(cls, node_sequences, edges, linear_ref_nodes, allele_frequencies=None):
+    def from_dicts(cls, node_sequences, edges, linear_ref_nodes, allele_frequencies=None, chromosome_start_nodes=None):
         """Same call shape as obgraph's `Graph.from_dicts` (tests/test_kmer_finder.py:12-16).
 
         An empty node counts as linear-ref dummy iff none of its siblings is a
@@ -142,6 +142,8 @@ class GraphArrays:
         indeg0 = [n for n in range(n_nodes) if exists[n] and len(rev[n]) == 0]
         first = min(indeg0)
         chrom = [linear_list[0]] if linear_list else [first]
+        if chromosome_start_nodes is not None:
+            chrom = [int(n) for n in chromosome_start_nodes]
         return cls(node_size, seq, edge_start, flat_edges, is_ref, af, exists, first, chrom, ntro)
 
     @classmethod
@@ -198,6 +200,37 @@ class GraphArrays:
         ntro = d["node_to_ref_offset"]
         return cls(d["node_size"], d["seq"], d["edge_start"], d["edges"], d["is_ref"], d["allele_freq"], d["exists"],
                    int(d["first_node"]), d["chromosome_start_nodes"].tolist(), ntro if len(ntro) else None)
+
+    _DIR_KEYS = ("node_size", "seq", "edge_start", "edges", "rev_start", "rev_edges", "is_ref", "allele_freq", "exists")
+
+    def to_dir(self, path):
+        """One .npy per array under `path` (e.g. a /dev/shm directory): the other processes of a node map the graph with
+        `from_dir` instead of generating or unpickling a copy each -- what the reference does with
+        shared_memory_wrapper.object_to_shared_memory before its process pool (command_line_interface.py:585)."""
+        import json
+        import os
+        os.makedirs(path, exist_ok=True)
+        for k in self._DIR_KEYS:
+            np.save(os.path.join(path, k + ".npy"), getattr(self, k))
+        meta = {"first_node": self.first_node, "chromosome_start_nodes": self._chromosome_start_nodes,
+                "has_node_to_ref_offset": self.node_to_ref_offset is not None}
+        if self.node_to_ref_offset is not None:
+            np.save(os.path.join(path, "node_to_ref_offset.npy"), np.asarray(self.node_to_ref_offset))
+        with open(os.path.join(path, "meta.json.tmp"), "w") as fh:
+            json.dump(meta, fh)
+        os.replace(os.path.join(path, "meta.json.tmp"), os.path.join(path, "meta.json"))    # written last: "complete"
+
+    @classmethod
+    def from_dir(cls, path, mmap=True):
+        import json
+        import os
+        with open(os.path.join(path, "meta.json")) as fh:
+            meta = json.load(fh)
+        d = {k: np.load(os.path.join(path, k + ".npy"), mmap_mode="r" if mmap else None) for k in cls._DIR_KEYS}
+        ntro = np.load(os.path.join(path, "node_to_ref_offset.npy"), mmap_mode="r" if mmap else None) \
+            if meta["has_node_to_ref_offset"] else None
+        return cls(d["node_size"], d["seq"], d["edge_start"], d["edges"], d["is_ref"], d["allele_freq"], d["exists"],
+                   meta["first_node"], meta["chromosome_start_nodes"], ntro, d["rev_start"], d["rev_edges"])
 
     # ------------------------------------------- obgraph-compatible accessor surface
     @property

@@ -37,12 +37,14 @@ def update_hash(current_base, current_hash, first_base, k, only_add=False):
     return (current_hash - first_base) // 4 + current_base * 4 ** (k - 1)
 
 
-def check_supported_graph(g, k):
-    """Raises for the one graph shape the kernels do not cover: a second chromosome that starts with a node shorter
-    than k (its first windows would need the reference's extra start point :208-211 per chromosome)."""
-    for s in g.chromosome_start_nodes.values():
-        if s != g.first_node and g.node_size[s] < k:
-            raise NotImplementedError("chromosome start node %d is shorter than k" % s)
+def search_roots(g, k):
+    """Nodes at which the reference starts a search with no history, besides the critical nodes: the graph's first node
+    (kmer_finder.py:208-211 prepends (first_node, 0) when it is not longer than k; longer, it is critical itself).  The
+    start node of a LATER chromosome gets no such extra start point: if it is shorter than k it is not critical either
+    (critical_graph_paths.py:76-82), no search ever enters it, and every window that touches the nodes before that
+    chromosome's first critical point is never emitted -- the classification marks those nodes DEAD (no alive
+    predecessor, not a root) and the general kernels drop their windows."""
+    return [int(g.first_node)] + [int(s) for s in g.chromosome_start_nodes.values() if g.node_size[s] >= k]
 
 
 def classify_nodes(g, k, max_variant_nodes, only_follow_nodes=None, critical_nodes=None):
@@ -63,8 +65,7 @@ def classify_nodes(g, k, max_variant_nodes, only_follow_nodes=None, critical_nod
             cache.clear()
         # search roots: chromosome starts and every critical node (each critical point starts a search with no history,
         # kmer_finder.py:190-232)
-        roots = np.ascontiguousarray(np.concatenate([np.asarray(list(g.chromosome_start_nodes.values()) + [g.first_node],
-                                                                dtype=np.int32), crit]))
+        roots = np.ascontiguousarray(np.concatenate([np.asarray(search_roots(g, k), dtype=np.int32), crit]))
         flags = np.zeros(g.n_nodes, dtype=np.uint16)
         general = C.c_int32(0)
         _lib.check(_lib.load().gki_classify_nodes(
@@ -168,7 +169,6 @@ class DenseKmerFinder:
 
     def _make_params(self):
         g, k = self._arrays, self._k
-        check_supported_graph(g, k)
         if self._critical_graph_paths is None:
             logging.info("Making critical graph paths since it's not specified.")
             self._critical_graph_paths = CriticalGraphPaths.from_graph(g, k)

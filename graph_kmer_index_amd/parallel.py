@@ -40,7 +40,7 @@ class _GatherControlPlane:
 
     def allgather_ints(self, xs):
         """Every rank's list of integers -> the matrix (row r = rank r's list)."""
-        xs = [int(x) for x in xs]
+        xs = [((int(x) + (1 << 63)) % (1 << 64)) - (1 << 63) for x in xs]       # uint64 values (checksums) wrap to int64
         rows = self._allgather_bytes(struct.pack("<%dq" % len(xs), *xs))
         return [list(struct.unpack("<%dq" % (len(p) // 8), p)) for p in rows]
 

@@ -263,3 +263,37 @@ def index_get(index, kmer, max_hits=10):
     hit = hit[:c]
     return (index["_nodes"][hit], index["_ref_offsets"][hit], index["_frequencies"][hit],
             index["_allele_frequencies"][hit])
+
+
+# ------------------------------------------------------------------ batch loops (bench.py's CPU baselines, test checker)
+def map_reads(index, letters, read_start, k, n_nodes, strands=3, max_hits=10):
+    """Node counts of all k-mers of the reads (both strands by default): a loop of read_kmers + index_get in C.
+    Returns (counts uint32[n_nodes], n_kmers, n_hits)."""
+    letters = np.ascontiguousarray(letters, dtype=np.uint8)
+    read_start = np.ascontiguousarray(read_start, dtype=np.int64)
+    counts = np.zeros(n_nodes, dtype=np.uint32)
+    nk, nh = C.c_int64(0), C.c_int64(0)
+    ks = np.ascontiguousarray(index["_kmers"]).astype(np.int64, copy=False).view(np.uint64)
+    fr = index["_frequencies"]
+    fr = None if not isinstance(fr, np.ndarray) or len(fr) != len(ks) else np.ascontiguousarray(fr, dtype=np.uint16)
+    nodes = np.ascontiguousarray(index["_nodes"]).astype(np.uint32, copy=False)
+    err = lib().orc_map_reads(_p(letters), _p(read_start), C.c_int64(len(read_start) - 1), C.c_int(k), C.c_int(strands),
+                              _p(index["_hashes_to_index"]), _p(index["_n_kmers"]), _p(ks), _p(nodes), _p(fr),
+                              C.c_uint64(index["_modulo"]), C.c_int64(min(max_hits, 2 ** 62)), _p(counts),
+                              C.c_int64(n_nodes), C.byref(nk), C.byref(nh))
+    if err:
+        raise OracleError(-err)
+    return counts, nk.value, nh.value
+
+
+def find_from_positions(g, k, nodes, offsets, only_save_one_node_per_kmer=False, max_variant_nodes=4):
+    """Number of records of a loop of find_only_kmers_starting_at_position over the start positions."""
+    nodes = np.ascontiguousarray(nodes, dtype=np.int32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    gs = _graph_struct(g)
+    n = C.c_int64(0)
+    err = lib().orc_find_from_positions(C.byref(gs), C.c_int(k), _p(nodes), _p(offsets), C.c_int64(len(nodes)),
+                                        C.c_int(bool(only_save_one_node_per_kmer)), C.c_int(max_variant_nodes), C.byref(n))
+    if err:
+        raise OracleError(err)
+    return n.value

@@ -289,7 +289,83 @@ def index_cases():
     return out
 
 
+def two_chromosome_cases():
+    """Graphs with two chromosomes (two components, `chromosome_start_nodes` lists both starts).  The reference walks
+    every chromosome for critical points (critical_graph_paths.py:52-53) but prepends the extra start point only for
+    the graph's first node (kmer_finder.py:208-211): a later chromosome whose start node is shorter than k begins to
+    emit at its first critical point."""
+    cases = []
+    rng = np.random.default_rng(20261004)
+
+    def shifted(part, shift):
+        seqs, edges, lin, af = part
+        return ({n + shift: s for n, s in seqs.items()}, {n + shift: [m + shift for m in e] for n, e in edges.items()},
+                [n + shift for n in lin], {n + shift: f for n, f in (af or {m: 1.0 for m in seqs}).items()})
+
+    def add(name, parts, k, **kw):
+        seqs, edges, lin, af, starts = {}, {}, [], {}, []
+        for part in parts:
+            s2, e2, l2, a2 = shifted(part, len(seqs))
+            starts.append(min(s2))
+            seqs.update(s2); edges.update(e2); lin += l2; af.update(a2)
+        g = Graph.from_dicts(seqs, edges, lin, af, chromosome_start_nodes=starts)
+        base = dict(name=name, seqs={str(a): b for a, b in seqs.items()}, edges={str(a): b for a, b in edges.items()},
+                    linear=lin, k=k, af={str(a): b for a, b in af.items()}, kw=kw, chromosome_start_nodes=starts)
+        try:
+            fl, crit = run_finder(g, k, **kw)
+        except OverflowError:
+            cases.append(dict(base, raises="E2"))
+            return
+        cases.append(dict(base, crit_nodes=crit[0], crit_offsets=crit[1], kmers=fl._hashes.tolist(), nodes=fl._nodes.tolist(),
+                          start_nodes=fl._start_nodes.tolist(), start_offsets=fl._start_offsets.tolist(),
+                          allele_frequencies=fl._allele_frequencies.tolist()))
+
+    i = 0
+    for k in (3, 4, 5, 7):
+        for first2 in (1, 2, k - 1, k, k + 4):             # start node of chromosome 2: shorter than k, exactly k, longer
+            if first2 < 1:
+                continue
+            for variant in range(2):
+                c1 = random_bubble_graph(rng, n_var=int(rng.integers(1, 4)), min_ref=k, max_ref=2 * k + 2, p_indel=0.3,
+                                         first_ref=k + 2, with_af=True)
+                chain = None if variant == 0 else {-1: int(rng.integers(1, max(2, first2)))}
+                c2 = random_bubble_graph(rng, n_var=int(rng.integers(1, 5)), min_ref=1, max_ref=2 * k + 2, p_indel=0.4,
+                                         first_ref=first2, with_af=True, chain_after=chain)
+                for one in (True, False):
+                    add("two_chrom_%d_k%d_f%d_v%d_%d" % (i, k, first2, variant, int(one)), [c1, c2], k,
+                        only_save_one_node_per_kmer=one, max_variant_nodes=int(rng.integers(1, 6)))
+                i += 1
+    # three chromosomes, the middle one a single short node (never emits), and chunked runs over a two-chromosome graph
+    for j in range(4):
+        k = int(rng.integers(3, 6))
+        c1 = random_bubble_graph(rng, n_var=2, min_ref=k, max_ref=2 * k, first_ref=k + 1)
+        mid = ({0: "ACGT"[:k - 1][:max(1, k - 2)]}, {}, [0], {0: 1.0})
+        c3 = random_bubble_graph(rng, n_var=3, min_ref=1, max_ref=2 * k, first_ref=int(rng.integers(1, k)))
+        add("three_chrom_%d" % j, [c1, mid, c3], k, only_save_one_node_per_kmer=bool(j % 2), max_variant_nodes=4)
+        seqs = {}
+        parts = [c1, c3]
+        g_parts = []
+        for part in parts:
+            g_parts.append(shifted(part, sum(len(p[0]) for p in g_parts)))
+        all_seqs = {}
+        all_edges, all_lin = {}, []
+        for sq, ed, li, _ in g_parts:
+            all_seqs.update(sq); all_edges.update(ed); all_lin += li
+        n_crit = len(CriticalGraphPaths.from_graph(Graph.from_dicts(all_seqs, all_edges, all_lin,
+                                                                    chromosome_start_nodes=[min(p[0]) for p in g_parts]), k))
+        for a, b in ((0, n_crit // 2), (n_crit // 2, n_crit)):
+            add("two_chrom_chunk_%d_%d_%d" % (j, a, b), parts, k, start_at_critical_path_number=a,
+                stop_at_critical_path_number=b, only_save_one_node_per_kmer=True, max_variant_nodes=5)
+    return cases
+
+
 def main():
+    if sys.argv[1:] == ["two_chrom"]:
+        two = two_chromosome_cases()
+        with open(os.path.join(HERE, "finder_two_chrom.json"), "w") as f:
+            json.dump(two, f, separators=(",", ":"))
+        print("two-chromosome cases:", len(two), "raising:", sum("raises" in c for c in two))
+        return
     nested = nested_cases()
     with open(os.path.join(HERE, "finder_nested.json"), "w") as f:
         json.dump(nested, f, separators=(",", ":"))

@@ -3,7 +3,8 @@
 Semantics assumed (SURVEY.md section 8c): numeric base codes a=0 c=1 g=2 t=3;
 an empty node is a "linear-ref dummy" iff none of its siblings (the other
 successors of any of its predecessors) is a linear-ref node; allele
-frequencies default to 1.0; one chromosome starting at the first linear node.
+frequencies default to 1.0; one chromosome starting at the first linear node unless
+`chromosome_start_nodes` lists the start node of every chromosome.
 """
 import numpy as np
 
@@ -16,7 +17,7 @@ _CODE = {"a": 0, "c": 1, "g": 2, "t": 3, "n": 0, "m": 0}
 
 
 class Graph:
-    def __init__(self, node_sequences, edges, linear_ref_nodes, allele_frequencies=None):
+    def __init__(self, node_sequences, edges, linear_ref_nodes, allele_frequencies=None, chromosome_start_nodes=None):
         self._seq = {int(n): np.array([_CODE[c] for c in s.lower()], dtype=np.uint8)
                      for n, s in node_sequences.items()}
         self._edges = {int(n): [int(x) for x in e] for n, e in edges.items()}
@@ -36,7 +37,8 @@ class Graph:
         self._ref_or_dummy = None
         self.make_linear_ref_node_and_ref_dummy_node_index()
         first = self._linear_list[0] if self._linear_list else min(self._seq)
-        self.chromosome_start_nodes = {1: first}
+        self.chromosome_start_nodes = {1: first} if chromosome_start_nodes is None else \
+            {i + 1: int(n) for i, n in enumerate(chromosome_start_nodes)}
         # linear-ref offset of every linear node (cumulative along the linear path)
         self.node_to_ref_offset = np.zeros(max(self._seq) + 2, dtype=np.int64)
         off = 0
@@ -45,8 +47,8 @@ class Graph:
             off += len(self._seq[n])
 
     @classmethod
-    def from_dicts(cls, node_sequences, edges, linear_ref_nodes, allele_frequencies=None):
-        return cls(node_sequences, edges, linear_ref_nodes, allele_frequencies)
+    def from_dicts(cls, node_sequences, edges, linear_ref_nodes, allele_frequencies=None, chromosome_start_nodes=None):
+        return cls(node_sequences, edges, linear_ref_nodes, allele_frequencies, chromosome_start_nodes)
 
     def make_linear_ref_node_and_ref_dummy_node_index(self):
         flag = {}

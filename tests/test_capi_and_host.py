@@ -10,7 +10,7 @@ from conftest import ROOT
 from graph_kmer_index_amd import _lib, GraphArrays, FlatKmers, CriticalGraphPaths
 from graph_kmer_index_amd import letter_sequence_to_numeric, sequence_to_kmer_hash, kmer_hash_to_sequence, NpList
 from graph_kmer_index_amd.kmer_hashing import power_array, reverse_power_array, kmer_hashes_to_bases, kmer_to_hash_fast
-from graph_kmer_index_amd.kmer_finder import check_supported_graph, lossy_table, update_hash, DenseKmerFinder
+from graph_kmer_index_amd.kmer_finder import search_roots, lossy_table, update_hash, DenseKmerFinder
 from graph_kmer_index_amd.graph import synthetic_snp_graph, synthetic_linear_graph
 from golden_cases import CRITICAL_KATS, REFERENCE_TEST_GRAPHS
 from oracle import oracle
@@ -165,16 +165,17 @@ def test_supported_graph_checks():
     from graph_kmer_index_amd.kmer_finder import classify_nodes
     g = GraphArrays.from_dicts({0: "ACGTACGT", 1: "A", 2: "C", 3: "G", 4: "TTTTTTTT"},
                                {0: [1, 2], 2: [3], 1: [4], 3: [4]}, [0, 1, 4])
-    check_supported_graph(g, 4)
     flags, general = classify_nodes(g, 4, 4)
     assert general and flags[3] & 16 and flags[2] & 8 and all(flags[n] & 4 for n in (0, 1, 4))
     assert flags.dtype == np.uint16 and (flags[4] >> 8) == 2            # up to two variant nodes (2, 3) right before node 4
-    check_supported_graph(synthetic_snp_graph(20000, 300, k=31, seed=3), 31)
     assert not classify_nodes(synthetic_snp_graph(20000, 300, k=31, seed=3), 31, 4)[1]
-    two = GraphArrays.from_dicts({0: "ACGTACGT", 1: "AC", 2: "GGGG"}, {1: [2]}, [0, 1, 2])
-    two._chromosome_start_nodes = [0, 1]
-    with pytest.raises(NotImplementedError):
-        check_supported_graph(two, 4)
+    # a second chromosome that starts with a node shorter than k gets no search root of its own (the reference prepends
+    # its extra start point for the graph's first node only, kmer_finder.py:208-211): the node is never entered (DEAD)
+    # and the run takes the general kernels; tests/test_two_chromosomes.py holds the reference's records for such graphs
+    two = GraphArrays.from_dicts({0: "ACGTACGT", 1: "AC", 2: "GGGG"}, {1: [2]}, [0, 1, 2], chromosome_start_nodes=[0, 1])
+    assert search_roots(two, 4) == [0, 0] and search_roots(two, 2) == [0, 0, 1]
+    flags, general = classify_nodes(two, 4, 4, critical_nodes=[0, 2])
+    assert general and flags[1] & 128 and not flags[2] & 128 and not flags[0] & 128
     # lossy restart table: critical (N, c) with 0 < c < k-1
     g = GraphArrays.from_dicts({0: "A", 1: "CTTT", 2: "TAAGGGG", 3: "AA", 4: ""}, {0: [1], 1: [2, 4], 2: [3], 4: [3]},
                                [0, 1, 2, 3])

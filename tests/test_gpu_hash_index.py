@@ -148,6 +148,9 @@ def test_reference_known_answer_fixture():
     assert index.get_nodes_from_multiple_kmers(np.array([9, 9])).tolist() == []
     assert index.has_kmers(np.array([1, 2, 3, 10, 10, 12, 100, 101, 102, 5], dtype=np.uint64)).tolist() == \
         [True, True, True, False, False, False, False, False, False, True]     # :30-34
+    # tests/test_collision_free_kmer_index.py:30-34 of the reference calls the process-pool form
+    assert index.has_kmers_parallel(np.array([1, 2, 3, 10, 10, 12, 100, 101, 102, 5], dtype=np.uint64), 4).tolist() == \
+        [True, True, True, False, False, False, False, False, False, True]
 
 
 @pytest.mark.parametrize("n,modulo,n_distinct", [(200000, 452930477, 150000), (300000, 65537, 5000), (50000, 7, 40),

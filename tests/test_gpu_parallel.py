@@ -322,13 +322,44 @@ def test_bench_line_has_the_contract_fields(tmp_path):
     es = d["early_stop_search"]            # seven starts per SNP site (fewer where the segment in front is short)
     assert 5 * 30000 < es["start_positions"] <= 7 * 30000 and es["records"] >= es["start_positions"]
     assert es["every_start_has_a_record"] and es["start_positions_per_s"] > 0
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline"] + small,
+    for key in ("index_build", "read_mapping", "early_stop_search"):         # the oracle's rate beside every record
+        cb = d[key]["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["sample"]
+    fi = d["full_index"]                                                      # every record of the step, in slices
+    assert fi["records"] == d["config"]["records_per_step"] and sum(fi["records_per_slice"]) == fi["records"]
+    assert fi["payload_equals_flat_multiset"] and fi["slices"] == 8
+    assert d["roofline"]["ceiling_measured"] > 0 and 0 < d["roofline"]["frac_of_ceiling"] < 1.5
+    # (1) the driver's form: `python bench.py --gpus 2` with NO launcher environment -- bench.py starts its own two rank
+    # processes (fresh children, before any GPU call), generates the graph once, and times exchange + build with ranks
+    clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline"] + small, env=clean,
+                         capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = run.stdout.strip().splitlines()
+    assert len(lines) == 1                                                     # rank 0 alone prints the line
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["config"]["records_per_step"] == d["config"]["records_per_step"]
+    assert sum(d2["config"]["records_per_rank"]) == d["config"]["records_per_step"] and min(d2["config"]["records_per_rank"]) > 0
+    sb = d2["sharded_build"]
+    n_dev = _lib.device_count()
+    if n_dev >= 2:                                   # ranks on devices of their own: RCCL, as it reports itself
+        assert sb["exchange"] == "rccl" and sb["rccl_ranks"] == 2
+    else:                                            # one device: RCCL refuses duplicate devices, the ranks use HIP IPC
+        assert sb["exchange"] == "hip-ipc" and sb["rccl_ranks"] is None and d2["config"]["ranks_sharing_rank0_device"] == 2
+    va, fp = sb["variant_index_allgather"], sb["full_index_partitioned"]
+    assert va["records_total"] == d["index_build"]["records"] and va["index_holds_every_record"]
+    assert va["allgather_ms"] > 0 and va["build_ms"] > 0 and va["bytes_per_link"] == max(va["records_per_rank"]) * 24
+    assert fp["records_total"] == d["config"]["records_per_step"] and fp["slices_hold_every_record"]
+    assert fp["payload_equals_flat_multiset"] and sum(fp["records_per_slice"]) == fp["records_total"]
+    assert fp["partition_ms"] > 0 and fp["alltoall_ms"] > 0 and fp["slice_build_ms"] > 0
+    # (2) under a launcher's environment (what torch.distributed.run exports) every process is a rank
+    env = dict(clean, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline", "--no-sharded-build"] + small,
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                               text=True) for r in range(2)]
     outs = [p.communicate(timeout=600) for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     lines = [o[0].strip() for o in outs]
-    assert lines[1] == "" and lines[0].count("\\n") == 0                 # rank 0 alone prints the line
-    d2 = json.loads(lines[0])
-    assert d2["n_gpus"] == 2 and d2["config"]["records_per_step"] == d["config"]["records_per_step"]
+    assert lines[1] == "" and lines[0].count("\n") == 0                 # rank 0 alone prints the line
+    d3 = json.loads(lines[0])
+    assert d3["n_gpus"] == 2 and d3["config"]["records_per_step"] == d["config"]["records_per_step"]
