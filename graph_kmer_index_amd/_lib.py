@@ -76,6 +76,7 @@ SYMBOLS = {
     "gki_classify_nodes": (_I32, [_I64, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, C.POINTER(C.c_int32)]),
     "gki_find_params_size": (_I64, []),
     "gki_critical_paths": (_I32, [_I64, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, C.POINTER(_I64)]),
+    "gki_graph_critical_paths": (_I32, [_P, _P, _I32, _I32, _P, _P, C.POINTER(_I64)]),
     "gki_finder_create": (_I32, [_P, C.POINTER(_P)]),
     "gki_finder_destroy": (_I32, [_P]),
     "gki_finder_count": (_I32, [_P, C.POINTER(FindParams), C.POINTER(_I64)]),

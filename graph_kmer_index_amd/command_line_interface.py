@@ -6,8 +6,9 @@ collision_free_kmer_index.py:393-402).
     python -m graph_kmer_index_amd.command_line_interface index -g graph.npz -k 31 -o flat
     python -m graph_kmer_index_amd.command_line_interface make_from_flat -f flat -o index
 
-`-g` takes an obgraph file when obgraph is installed, else a GraphArrays .npz (GraphArrays.to_file).  `-t/--n-threads`
-is accepted and ignored: the enumeration runs on the GPU (use parallel.build_index_sharded for several GPUs).
+`-g` takes an obgraph file when obgraph is installed, else a GraphArrays .npz (GraphArrays.to_file).  `index -t N` runs
+one process per GPU (at most N, at most the visible devices), each on its own range of critical-path numbers, and
+concatenates the shards in rank order -- the reference's process pool over chunks (:575-614) with GPUs for workers.
 """
 import argparse
 import logging
@@ -45,17 +46,30 @@ def _bool(x):
 
 
 def index(args):
+    if args.shard is None and max(1, args.n_threads) > 1:
+        ranks = args.ranks or min(args.n_threads, max(1, _visible_devices()))
+        if ranks > 1:
+            return index_on_ranks(args, ranks)
+        logging.info("-t %d: one device visible, one process" % args.n_threads)
     graph = load_graph(args.graph)
     k = args.kmer_size
     cp = load_critical_paths(args.critical_graph_paths) or CriticalGraphPaths.from_graph(graph, k)
     whitelist = None
     if args.whitelist is not None:
         whitelist = CollisionFreeKmerIndex.from_file(args.whitelist)                      # :634 (`kmer in whitelist`)
+    chunk = {}
+    if args.shard is not None:                       # one rank of `index -t N`: its range of critical-path numbers
+        from . import _lib
+        from .sharding import shard_range
+        r, w = (int(x) for x in args.shard.split("/"))
+        _lib.check(_lib.load().gki_set_device(r % max(1, _lib.device_count())))
+        a, b = shard_range(GraphArrays.from_obgraph(graph), cp, r, w)
+        chunk = dict(start_at_critical_path_number=a, stop_at_critical_path_number=b)
     finder = DenseKmerFinder(graph, k, critical_graph_paths=cp, max_variant_nodes=args.max_variant_nodes,
-                             only_save_one_node_per_kmer=True, whitelist=whitelist)      # :559-565
+                             only_save_one_node_per_kmer=True, whitelist=whitelist, **chunk)      # :559-565
     dflat = finder.find_flat_on_device(split_layout=False)      # with a whitelist: membership probe + compaction in HBM
     finder.synchronize()
-    if args.include_reverse_complement:                                                    # :616-620, still in HBM
+    if args.include_reverse_complement and args.shard is None:                            # :616-620, still in HBM
         from .flat_kmers import DeviceFlatKmers
         both = DeviceFlatKmers.from_multiple_flat_kmers([dflat, dflat.get_reverse_complement_flat_kmers(k)])
         dflat.free()
@@ -63,6 +77,44 @@ def index(args):
     flat = dflat.to_flat_kmers()
     dflat.free()
     logging.info("N kmers in flat kmers: %d" % len(flat._hashes))
+    flat.to_file(args.out_file_name)
+
+
+def _visible_devices():
+    from . import _lib
+    return _lib.device_count()
+
+
+def index_on_ranks(args, ranks):
+    """`index -t N` (command_line_interface.py:575-614 spreads n_threads * 20 chunks of critical-path numbers over a
+    process pool and concatenates the results in chunk order): here one process per GPU, each taking one contiguous
+    range of critical-path numbers balanced by bases (sharding.shard_range -- no k-window crosses a critical point, so
+    the ranges need no halo), writing its FlatKmers shard; this process concatenates the shards in rank order
+    (flat_kmers.py:71-90) and adds the reverse complements afterwards like the reference (:616-620)."""
+    import os
+    import subprocess
+    import tempfile
+    k = args.kmer_size
+    with tempfile.TemporaryDirectory(prefix="gki_index_") as tmp:
+        procs = []
+        for r in range(ranks):
+            cmd = [sys.executable, "-m", "graph_kmer_index_amd.command_line_interface", "index", "-g", args.graph, "-k", str(k),
+                   "-o", os.path.join(tmp, "shard_%d" % r), "-v", str(args.max_variant_nodes), "--shard", "%d/%d" % (r, ranks)]
+            if args.critical_graph_paths:
+                cmd += ["-c", args.critical_graph_paths]
+            if args.whitelist:
+                cmd += ["-w", args.whitelist]
+            env = dict(os.environ)
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+            procs.append(subprocess.Popen(cmd, env=env))
+        codes = [p.wait() for p in procs]
+        if any(codes):
+            raise RuntimeError("index: rank exit codes %s" % codes)
+        flat = FlatKmers.from_multiple_flat_kmers([FlatKmers.from_file(os.path.join(tmp, "shard_%d" % r)) for r in range(ranks)])
+    if args.include_reverse_complement:
+        flat = FlatKmers.from_multiple_flat_kmers([flat, flat.get_reverse_complement_flat_kmers(k=k)])
+    logging.info("N kmers in flat kmers: %d (from %d ranks)" % (len(flat._hashes), ranks))
     flat.to_file(args.out_file_name)
 
 
@@ -103,6 +155,9 @@ def build_parser():
     p.add_argument("-r", "--include-reverse-complement", type=_bool, default=False)
     p.add_argument("-O", "--only-save-one-node-per-kmer", type=_bool, default=False)
     p.add_argument("-v", "--max-variant-nodes", type=int, default=5)
+    p.add_argument("--ranks", type=int, default=0, help="processes of `-t N` (default: min(N, visible devices); more ranks "
+                   "than devices share them round-robin)")
+    p.add_argument("--shard", default=None, help=argparse.SUPPRESS)       # R/W: this process is rank R of `index -t`
     p.set_defaults(func=index)
     p = sub.add_parser("make_from_flat")
     p.add_argument("-o", "--out_file_name", required=True)

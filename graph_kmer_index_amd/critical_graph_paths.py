@@ -1,7 +1,8 @@
 """CriticalGraphPaths with the reference's interface (critical_graph_paths.py:5-104).
 
-`from_graph` runs the walk in libgki_hip.so's host-side `gki_critical_paths` on the flat graph
-arrays (O(#linear nodes), sequential -- a graph-preparation step, not a per-base one)."""
+`from_graph` runs the walk on the device over the resident graph (`gki_graph_critical_paths`: jump tables + prefix
+sums, csrc/gki_critical.hip); the sequential host walk of the library (`gki_critical_paths`) serves hosts without a
+device, e.g. a machine that only prepares the chunk table."""
 import ctypes as C
 import numpy as np
 
@@ -47,16 +48,27 @@ class CriticalGraphPaths:
         return len(self.nodes)
 
     @classmethod
-    def from_graph(cls, graph, k):
+    def from_graph(cls, graph, k, on_device=None):
+        """critical_graph_paths.py:42-104.  on_device=None: the data-parallel walk over the graph resident in HBM
+        (gki_graph_critical_paths; the graph handle is created on first use and cached on the graph, the finder needs
+        it anyway) when an MI355X is visible and the graph has at most 64 chromosomes, else the sequential host walk
+        of the library (gki_critical_paths).  Both give the reference's points in its order and raise where it does."""
         g = GraphArrays.from_obgraph(graph)
         lib = _lib.load()
         chrom = np.ascontiguousarray(list(g.chromosome_start_nodes.values()), dtype=np.int32)
         nodes = np.zeros(g.n_nodes, dtype=np.uint32)
         offsets = np.zeros(g.n_nodes, dtype=np.uint16)
         n = C.c_int64(0)
-        rc = lib.gki_critical_paths(g.n_nodes, _lib.hptr(g.node_size), _lib.hptr(g.edge_start), _lib.hptr(g.edges),
-                                    _lib.hptr(g.rev_start), _lib.hptr(g.is_ref), _lib.hptr(chrom), len(chrom), int(k),
-                                    _lib.hptr(nodes), _lib.hptr(offsets), C.byref(n))
+        if on_device is None:
+            on_device = len(chrom) <= 64 and _lib.device_count() > 0
+        if on_device:
+            from .device_graph import DeviceGraph
+            rc = lib.gki_graph_critical_paths(DeviceGraph.of(g).handle, _lib.hptr(chrom), len(chrom), int(k), _lib.hptr(nodes),
+                                              _lib.hptr(offsets), C.byref(n))
+        else:
+            rc = lib.gki_critical_paths(g.n_nodes, _lib.hptr(g.node_size), _lib.hptr(g.edge_start), _lib.hptr(g.edges),
+                                        _lib.hptr(g.rev_start), _lib.hptr(g.is_ref), _lib.hptr(chrom), len(chrom), int(k),
+                                        _lib.hptr(nodes), _lib.hptr(offsets), C.byref(n))
         if rc != 0:
             # the reference raises here too (critical_graph_paths.py:96-100 Exception, :104 OverflowError)
             raise Exception(lib.gki_last_error().decode())

@@ -113,6 +113,19 @@ struct gki_graph {
     hipEvent_t ev_prep0, ev_prep1;
 };
 
+// ---------------------------------------------------------------------------------- device error word
+// Kernels report the two conditions a run can end on through ONE word, as bits, so that the outcome does not depend on
+// which lane stored last (plain stores of different codes raced): bit 0 = the reference's assertion
+// (kmer_finder.py:402, GKI_ERR_NOT_ONE_REF_SUCC), bit 1 = a window or history deeper than the kernels' stacks
+// (GKI_ERR_WINDOW_TOO_DEEP).  Too-deep wins on the host: a run that could not look at every window cannot vouch for
+// the assertion either way.
+__device__ __forceinline__ void gki_raise(int *err, int code) {
+    atomicOr((unsigned int *)err, code == GKI_ERR_WINDOW_TOO_DEEP ? 2u : 1u);
+}
+static inline int gki_error_of_word(int64_t word) {
+    return (word & 2) ? GKI_ERR_WINDOW_TOO_DEEP : (word & 1) ? GKI_ERR_NOT_ONE_REF_SUCC : GKI_OK;
+}
+
 // ---------------------------------------------------------------------------------- exclusive scan
 // out[0..n] (n+1 entries), out[n] = total.  Three launches: block sums, scan of block sums, rescan.
 int gki_scan_u32_to_i64(const uint32_t *d_in, int64_t n, int64_t *d_out, void *d_tmp, int64_t tmp_bytes,

@@ -290,7 +290,7 @@ __device__ __noinline__ bool history_ok(const WalkSrc gs, const WalkCache &wc, c
     for (int budget = 1 << 16;; budget--) {
         // every lane's enumeration ends: a graph with more than 65 536 history steps behind one window is refused
         // (GKI_ERR_WINDOW_TOO_DEEP) rather than walked for minutes
-        if (budget == 0) { *err = GKI_ERR_WINDOW_TOO_DEEP; return false; }
+        if (budget == 0) { gki_raise(err, GKI_ERR_WINDOW_TOO_DEEP); return false; }
         if (hcur[h] >= hend[h]) { if (h == 0) return false; h--; continue; }
         const int32_t p = cached_preds_next(g, wc, wv, &hcur[h]);
         const uint8_t fp = (uint8_t)cached_flag(nf, nullptr, wc, wv, p);
@@ -327,7 +327,7 @@ __device__ __noinline__ bool history_ok(const WalkSrc gs, const WalkCache &wc, c
             if (closed) return true;                              // p is not DEAD: some admissible history enters it
         }
         if (!(fp & GKI_NODE_NESTED)) continue;
-        if (h + 1 >= HMAX) { *err = GKI_ERR_WINDOW_TOO_DEEP; return false; }
+        if (h + 1 >= HMAX) { gki_raise(err, GKI_ERR_WINDOW_TOO_DEEP); return false; }
         h++;
         preds_begin(g, wp, p, &hcur[h], &hend[h]);
     }
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256, GEN ? 8 : 1) void k_count_boundary(DevGraph g,
         // at the limit.  The windows in question end at the node's last base (oc), for an empty node "before offset 0".
         bool chk = GEN && (fn & GKI_NODE_CHECK) && reach_n && in_run(a, n);
         const int oc = size - 1;
-        if (chk && size >= k) { if (v0 >= a.M) *err = GKI_ERR_NOT_ONE_REF_SUCC; chk = false; }
+        if (chk && size >= k) { if (v0 >= a.M) gki_raise(err, GKI_ERR_NOT_ONE_REF_SUCC); chk = false; }
         const bool chk_empty = chk && size == 0;
         if (reach_n && ((bl > 0 && o_lo < o_hi) || chk_empty) && !(nonfree0 && a.M < 1)) {
             const int cn = HAS_LOSSY ? lossy_of(lossy, (int32_t)n) : -1;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256, GEN ? 8 : 1) void k_count_boundary(DevGraph g,
             if (HAS_LOSSY && cn >= 0 && cn < hi) hi = cn;
             const int w_lo = chk_empty ? -1 : o_lo;       // offset -1: the k bases before the node
             if (chk_empty) hi = 0;
-            if (GEN && chk && wn.rev_cnt == 0 && v0 >= a.M) *err = GKI_ERR_NOT_ONE_REF_SUCC;   // a root shorter than k
+            if (GEN && chk && wn.rev_cnt == 0 && v0 >= a.M) gki_raise(err, GKI_ERR_NOT_ONE_REF_SUCC);   // a root shorter than k
             if (w_lo < hi) {
                 int32_t t_cur, t_end;
                 preds_begin(g, wn, n, &t_cur, &t_end);
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256, GEN ? 8 : 1) void k_count_boundary(DevGraph g,
                         aq = t_a ? t_a : ((fq & (GKI_NODE_REF | GKI_NODE_FORCED)) ? 0 : vq);
                         if (aq && vq - aq >= a.M) continue;
                     }
-                    if (L >= MAXN - 1) { *err = GKI_ERR_WINDOW_TOO_DEEP; continue; }
+                    if (L >= MAXN - 1) { gki_raise(err, GKI_ERR_WINDOW_TOO_DEEP); continue; }
                     if (GEN) { if (L == 1) pr1 = q; else if (L == 2) pr2 = q; else path[L] = q; }
                     const int s = wq.size, c = t_cum;
                     bool deeper;
@@ -441,13 +441,13 @@ __global__ __launch_bounds__(256, GEN ? 8 : 1) void k_count_boundary(DevGraph g,
                             const int min_ok = k - 1 - c - s + cq; if (from < min_ok) from = min_ok;
                             // the search restarted at (q, cq) with no history: at an end position whose window would
                             // reach before that point it holds the shorter window, which still decides :402
-                            if (GEN && chk && oc >= w_lo && oc < min_ok && vq >= a.M) *err = GKI_ERR_NOT_ONE_REF_SUCC;
+                            if (GEN && chk && oc >= w_lo && oc < min_ok && vq >= a.M) gki_raise(err, GKI_ERR_NOT_ONE_REF_SUCC);
                         }
                         if (GEN && from < to) {
                             bool ok = true;                          // a history before the window's first node?
                             if (!(fq & (GKI_NODE_T | GKI_NODE_SIMPLE)))
                                 ok = (fq & GKI_NODE_NESTED) ? (vq + (int)(fq >> 8) < a.M || (path[1] = pr1, path[2] = pr2, history_ok(WalkSrc{g.walk, g.rev_edges, g.rev_start}, wc, wv, a.nflags, k, a.M, path, L, err))) : false;
-                            if (ok && chk && from <= oc && oc < to && vq >= a.M) *err = GKI_ERR_NOT_ONE_REF_SUCC;
+                            if (ok && chk && from <= oc && oc < to && vq >= a.M) gki_raise(err, GKI_ERR_NOT_ONE_REF_SUCC);
                             if (!ok) to = from;
                         }
                         if (GEN && from < 0 && from < to) from = 0;      // offset -1 has no record
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256, GEN ? 8 : 1) void k_count_boundary(DevGraph g,
                             count += (uint32_t)(to - from) * per_window;
                         }
                         // the graph ends before the window of oc is complete (graph start): the search saw what there is
-                        if (GEN && chk && wq.rev_cnt == 0 && c + s < k - 1 - oc && vq >= a.M) *err = GKI_ERR_NOT_ONE_REF_SUCC;
+                        if (GEN && chk && wq.rev_cnt == 0 && c + s < k - 1 - oc && vq >= a.M) gki_raise(err, GKI_ERR_NOT_ONE_REF_SUCC);
                         deeper = (k - 1 - c - s > w_lo) && !(HAS_LOSSY && cq >= 0);
                         new_cum = c + s;
                     }
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(256, (GEN && !ALL && FMT != 1) ? 4 : 1) void k_emit
                     }
                     if (take) {
                         if (L >= MAXN - 1) {
-                            *err = GKI_ERR_WINDOW_TOO_DEEP;
+                            gki_raise(err, GKI_ERR_WINDOW_TOO_DEEP);
                         } else {
                             const int s = wq.size, c = t_cum;
                             if (LAZY) { if (L == 1) pr1 = qn; else if (L == 2) pr2 = qn; else path[L] = qn; }
@@ -1353,11 +1353,12 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
     HIP_TRY(hipMemcpyAsync(tot + 4, f->d_bsum, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     unsigned long long bsum = (unsigned long long)tot[4];
-    if (tot[1] == GKI_ERR_NOT_ONE_REF_SUCC)
+    const int run_err = gki_error_of_word(tot[1]);
+    if (run_err == GKI_ERR_NOT_ONE_REF_SUCC)
         return gki_set_error(GKI_ERR_NOT_ONE_REF_SUCC, "a window at the variant limit ends a node that does not have exactly one "
                              "linear-ref successor: the reference asserts here (kmer_finder.py:402); raise max_variant_nodes");
-    if (tot[1] != 0)
-        return gki_set_error((int)tot[1], "a k-window (or the history that decides it) crosses more than %d nodes", MAXN - 2);
+    if (run_err != GKI_OK)
+        return gki_set_error(run_err, "a k-window (or the history that decides it) crosses more than %d nodes", MAXN - 2);
     if (a.split) bsum = (unsigned long long)tot[2];
     f->n_records = tot[0];
     f->n_boundary_records = (int64_t)bsum;

@@ -29,7 +29,7 @@ __device__ __forceinline__ void check_one_ref_successor(const DevGraph &g, int32
     if (e1 == e0) return;
     int n_ref = 0;
     for (int64_t e = e0; e < e1; e++) n_ref += g.is_ref[g.edges[e]] ? 1 : 0;
-    if (n_ref != 1) *err = GKI_ERR_NOT_ONE_REF_SUCC;
+    if (n_ref != 1) gki_raise(err, GKI_ERR_NOT_ONE_REF_SUCC);
 }
 
 template <bool EMIT>
@@ -90,7 +90,7 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
         } else if (vc[j] >= M && !wq.is_ref) {
             continue;                                                   // :397-403 only the linear-ref successor
         }
-        if (L >= FMAX - 1) { *err = GKI_ERR_WINDOW_TOO_DEEP; continue; }
+        if (L >= FMAX - 1) { gki_raise(err, GKI_ERR_WINDOW_TOO_DEEP); continue; }
         const int hv = have[j];
         const int t = wq.size < k - hv ? wq.size : k - hv;
         nd[L] = q; vc[L] = (uint8_t)(vc[j] + (wq.is_ref ? 0 : 1));
@@ -186,6 +186,7 @@ int gki_forward_count(gki_graph *gr, int k, int max_variant_nodes, int one_node,
     (void)gki_dev_free(cnt); (void)gki_dev_free(tmp); (void)gki_dev_free(d_err);
     if (rc != GKI_OK) return rc;
     HIP_TRY(e1); HIP_TRY(e2);
+    herr = gki_error_of_word(herr);
     if (herr == GKI_ERR_NOT_ONE_REF_SUCC)
         return gki_set_error(herr, "a path at the variant limit ends a node that does not have exactly one linear-ref "
                              "successor: the reference asserts here (kmer_finder.py:402)");

@@ -57,8 +57,9 @@ def classify_nodes(g, k, max_variant_nodes, only_follow_nodes=None, critical_nod
         follow = np.zeros(g.n_nodes, dtype=np.uint8)
         ids = np.fromiter((int(x) for x in only_follow_nodes), dtype=np.int64)
         follow[ids[(ids >= 0) & (ids < g.n_nodes)]] = 1
+    # the same clamp as gki_finder_count / gki_forward_* (250): classification and kernels decide on one limit
     crit = np.zeros(0, dtype=np.int32) if critical_nodes is None else np.ascontiguousarray(critical_nodes, dtype=np.int32)
-    key = (int(k), min(int(max_variant_nodes), 64), None if follow is None else follow.tobytes(), crit.tobytes())
+    key = (int(k), min(int(max_variant_nodes), 250), None if follow is None else follow.tobytes(), crit.tobytes())
     cache = g.__dict__.setdefault("_node_classes", {})
     if key not in cache:
         if len(cache) > 8:
@@ -71,7 +72,7 @@ def classify_nodes(g, k, max_variant_nodes, only_follow_nodes=None, critical_nod
         _lib.check(_lib.load().gki_classify_nodes(
             g.n_nodes, _lib.hptr(g.node_size), _lib.hptr(g.edge_start), _lib.hptr(g.edges), _lib.hptr(g.rev_start),
             _lib.hptr(g.rev_edges), _lib.hptr(g.is_ref), _lib.hptr(follow), _lib.hptr(roots), len(roots), int(k),
-            min(int(max_variant_nodes), 64), _lib.hptr(flags), C.byref(general)))
+            min(int(max_variant_nodes), 250), _lib.hptr(flags), C.byref(general)))
         cache[key] = (flags, bool(general.value))
     return cache[key]
 

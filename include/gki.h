@@ -124,6 +124,12 @@ int gki_critical_paths(int64_t n_nodes, const int32_t *h_node_size,
                        const int64_t *h_rev_start, const uint8_t *h_is_ref,
                        const int32_t *h_chrom_start, int n_chrom, int k,
                        uint32_t *h_out_nodes, uint16_t *h_out_offsets, int64_t *n_out);
+/* The same walk on the device, over a resident graph: next-node table -> pointer-doubling jump tables -> the path of
+ * every chromosome -> depth / bp_since_last_join as prefix sums over the path -> the test, compacted in walk order
+ * (csrc/gki_critical.hip).  Same outputs (host arrays sized n_nodes by the caller) and same errors as
+ * gki_critical_paths; at most 64 chromosomes. */
+int gki_graph_critical_paths(gki_graph *g, const int32_t *h_chrom_start, int n_chrom, int k, uint32_t *h_out_nodes,
+                             uint16_t *h_out_offsets, int64_t *n_out);
 
 /* ---------------------------------------------------------------- DenseKmerFinder (A3-A5)
  * Replaces DenseKmerFinder.find() (kmer_finder.py:179-244: search_from :254-347,

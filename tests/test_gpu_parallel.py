@@ -88,6 +88,16 @@ def test_command_line_drivers_write_the_reference_formats(tmp_path):
     assert np.array_equal(flat._hashes[og], exp["kmers"].astype(np.uint64)[oe])
     assert np.array_equal(flat._nodes[og], exp["nodes"].astype(np.uint32)[oe])
     assert np.array_equal(flat._ref_offsets[og], pos.astype(np.uint64)[oe])
+    # `index -t 3` over three rank processes (on however many devices there are): the shards concatenated in rank order
+    # are the one-process output record for record, and the reverse complements follow all forward records (:616-620)
+    flat3_file = str(tmp_path / "flat3")
+    assert main(["index", "-g", gfile + ".npz", "-k", "31", "-o", flat3_file, "-t", "3", "--ranks", "3", "-r", "1"]) == 0
+    flat3 = FlatKmers.from_file(flat3_file)
+    n1 = len(flat._hashes)
+    assert len(flat3._hashes) == 2 * n1
+    for name in ("_hashes", "_nodes", "_ref_offsets", "_allele_frequencies"):
+        assert np.array_equal(getattr(flat3, name)[:n1], getattr(flat, name)), name
+    assert np.array_equal(flat3._hashes[n1:], oracle.reverse_complement(flat._hashes, 31))
     assert main(["make_from_flat", "-f", flat_file, "-o", idx_file, "-m", "200003"]) == 0
     idx = CollisionFreeKmerIndex.from_file(idx_file)
     ref = oracle.index_build(flat._hashes, flat._nodes, flat._ref_offsets, flat._allele_frequencies, modulo=200003)
