@@ -388,8 +388,6 @@ def full_index_record(lib, _lib, g, k, cp, out, max_variant_nodes, modulo, n_sli
     released first (their checksums are kept: the slices' payload must be the same multiset)."""
     from graph_kmer_index_amd.flat_kmers import DeviceFlatKmers
     from graph_kmer_index_amd.collision_free_kmer_index import DeviceIndex, bucket_range, partition_by_bucket_range
-    from graph_kmer_index_amd.parallel import find_sharded
-
     def sync():
         _lib.check(lib.gki_device_synchronize())
     n = out.n
@@ -405,10 +403,17 @@ def full_index_record(lib, _lib, g, k, cp, out, max_variant_nodes, modulo, n_sli
     t_all = time.perf_counter()
     t_find = t_part = t_copy = t_build = 0.0
     shards, starts = [], []
+    from graph_kmer_index_amd import DenseKmerFinder
+    from graph_kmer_index_amd.sharding import shard_range
+    finder = DenseKmerFinder(g, k, critical_graph_paths=cp, **kw)     # one finder, one device handle, eight chunks
     for r in range(W):
-        t = time.perf_counter()
-        mine = find_sharded(g, k, cp, r, W, **kw)
+        a, b = shard_range(g, cp, r, W)
+        finder.set_critical_path_range(a, b)
+        finder._params()                              # (host-side validation of the chunk: not device work)
         sync()
+        t = time.perf_counter()
+        mine = finder.find_flat_on_device()
+        finder.synchronize()
         t_find += time.perf_counter() - t
         t = time.perf_counter()
         by_dest, send_start = partition_by_bucket_range(mine, modulo, W)

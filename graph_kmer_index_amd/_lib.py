@@ -74,6 +74,7 @@ SYMBOLS = {
     "gki_graph_n_bases": (_I64, [_P]),
     "gki_topological_rank": (_I32, [_I64, _P, _P, _P]),
     "gki_classify_nodes": (_I32, [_I64, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, C.POINTER(C.c_int32)]),
+    "gki_graph_classify_nodes": (_I32, [_P, _P, _P, _I32, _I32, _I32, _P, _I32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gki_find_params_size": (_I64, []),
     "gki_critical_paths": (_I32, [_I64, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, C.POINTER(_I64)]),
     "gki_graph_critical_paths": (_I32, [_P, _P, _I32, _I32, _P, _P, C.POINTER(_I64)]),

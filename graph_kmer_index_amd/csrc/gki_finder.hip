@@ -114,16 +114,19 @@ __device__ __forceinline__ int32_t bnd_len_of(const DevGraph &g, const FindArgs 
 // coalesced loads, and the walk reads them there; a node or list entry outside falls back to global memory.
 constexpr int WC_HALO = 32;
 constexpr int WC_REV = 192;
-struct WalkCache {
+template <bool FLG>
+struct WalkCacheT {
     uint4 rec[2 * (WC_HALO + 64)];
     int32_t rev[WC_REV];
-    uint32_t flg[WC_HALO + 64];      // per staged node: flag word (general graphs) | lossy-restart offset << 16 (runs with such points)
+    uint32_t flg[FLG ? WC_HALO + 64 : 1];   // per staged node: flag word (general graphs) | lossy-restart offset << 16 (runs with such points)
 };
+typedef WalkCacheT<true> WalkCache;         // WalkCacheT<false>: a kernel variant that reads neither (all-nodes mode, 384 B per wave)
 struct WalkView {                // wave-uniform bounds of what the cache holds
     int64_t lo, hi;              // nodes
     int64_t r0, r1;              // rev_edges entries
 };
-__device__ __forceinline__ WalkView stage_walk(const DevGraph &g, WalkCache &wc, int64_t base, int lane,
+template <class WC>
+__device__ __forceinline__ WalkView stage_walk(const DevGraph &g, WC &wc, int64_t base, int lane,
                                                const uint16_t *__restrict__ nflags = nullptr,
                                                const uint16_t *__restrict__ lossy = nullptr) {
     WalkView v;
@@ -158,7 +161,7 @@ __device__ __forceinline__ WalkView stage_walk(const DevGraph &g, WalkCache &wc,
     for (int u = 0; u < RC; u++) wc.rec[u * 64 + lane] = t[u];
 #pragma unroll
     for (int u = 0; u < VC; u++) wc.rev[u * 64 + lane] = r[u];
-    if (nflags || lossy) {
+    if (sizeof(wc.flg) > 4 && (nflags || lossy)) {
         wc.flg[lane] = fl[0];
         if (lane < WC_HALO) wc.flg[64 + lane] = fl[1];
     }
@@ -170,7 +173,8 @@ __device__ __forceinline__ WalkView stage_walk(const DevGraph &g, WalkCache &wc,
 __device__ __forceinline__ void opaque(uint4 &x) { asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w)); }
 __device__ __forceinline__ void opaque(int32_t &x) { asm volatile("" : "+v"(x)); }
 
-__device__ __forceinline__ NodeWalk cached_walk(const DevGraph &g, const WalkCache &wc, const WalkView &v, int64_t q) {
+template <class WC>
+__device__ __forceinline__ NodeWalk cached_walk(const DevGraph &g, const WC &wc, const WalkView &v, int64_t q) {
     const bool in = q >= v.lo && q < v.hi;
     const int64_t slot = in ? q - v.lo : 0;
     uint4 lo16 = wc.rec[2 * slot], hi16 = wc.rec[2 * slot + 1];
@@ -191,8 +195,9 @@ __device__ __forceinline__ NodeWalk cached_walk(const DevGraph &g, const WalkCac
     return w;
 }
 // flag word (low 16 bits, 0 without nflags) and lossy-restart offset (high 16 bits, 0xFFFF = none) of node q
+template <class WC>
 __device__ __forceinline__ uint32_t cached_flag(const uint16_t *__restrict__ nflags, const uint16_t *__restrict__ lossy,
-                                                const WalkCache &wc, const WalkView &v, int64_t q) {
+                                                const WC &wc, const WalkView &v, int64_t q) {
     const bool in = q >= v.lo && q < v.hi;
     int32_t f = (int32_t)wc.flg[in ? q - v.lo : 0];
     opaque(f);
@@ -200,7 +205,8 @@ __device__ __forceinline__ uint32_t cached_flag(const uint16_t *__restrict__ nfl
     return (uint32_t)f;
 }
 __device__ __forceinline__ int lossy_in(uint32_t fw) { const int c = (int)(fw >> 16); return c == 0xFFFF ? -1 : c; }
-__device__ __forceinline__ int32_t cached_preds_next(const DevGraph &g, const WalkCache &wc, const WalkView &v, int32_t *cur) {
+template <class WC>
+__device__ __forceinline__ int32_t cached_preds_next(const DevGraph &g, const WC &wc, const WalkView &v, int32_t *cur) {
     if (*cur < 0) { const int32_t q = ~*cur; *cur = 0; return q; }
     const int32_t i = (*cur)++;
     const bool in = i >= v.r0 && i < v.r1;
@@ -255,6 +261,10 @@ constexpr int HMAX = 40;         // nodes of one enumerated history (k-1 one-bas
 // this out-of-line call and every load through its pointers in the kernel itself became a FLAT load (address space
 // lost) -- which waits on the LDS counter as well as on the memory counter, in kernels full of LDS traffic.
 struct WalkSrc { const NodeWalk *walk; const int32_t *rev_edges; const int64_t *rev_start; };
+// (kernel variants without the flag words never run the general branch that calls history_ok; this overload only
+// lets that branch compile)
+__device__ __forceinline__ bool history_ok(const WalkSrc, const WalkCacheT<false> &, const WalkView &, const uint16_t *, int, int,
+                                           const int32_t *, int, int *) { return false; }
 __device__ __noinline__ bool history_ok(const WalkSrc gs, const WalkCache &wc, const WalkView &wv,
                                         const uint16_t *__restrict__ nf, int k, int M, const int32_t *path, int L, int *err) {
     DevGraph g = {};                       // only these three members are read below (helpers are inlined)
@@ -502,22 +512,28 @@ constexpr int EVQ = GKI_EVQ;        // step descriptors per wave queue (a walk r
 constexpr int MW = EVQ * 32 / 64;   // words of the window bitmap (a step holds at most 31 windows)
 static_assert(EVQ > 64 && EVQ <= 128 && EVQ % 2 == 0 && MW <= 64, "two steps per lane, one bitmap word per lane");
 
-constexpr int NLQ = 6;              // all-nodes mode: node lists of up to NLQ nodes travel through the queue
+constexpr int NLQ = 5;              // all-nodes mode: node lists of up to NLQ nodes travel through the queue (two SNPs inside
+                                    // one window: segment, allele, segment, allele, segment); longer lists are written by the wave
 
 template <int FMT> struct MafOf { typedef float T; };        // float32 rounding is monotonic: min, then round == round, then min
 template <> struct MafOf<1> { typedef double T; };           // get_flat_kmers(v="2") keeps float64 (kmer_finder.py:58)
 
+template <bool ALL> struct IdxOf { typedef int64_t T; };
+template <> struct IdxOf<true> { typedef uint32_t T; };
+
 template <int FMT, bool ALL>
 struct EvQueue {
-    // per node of the group in progress (lane l walks node base + l)
-    uint64_t own[64];            // the node's first k-1 bases
-    int64_t pos0[64];            // position id of (node, 0)
-    int32_t n[64];
+    // per node of the group in progress (lane l walks node base + l).  All-nodes mode leaves these three in the
+    // walking lane's registers and shuffles them at expansion time; with the 32-bit record slots, the node lists cut to
+    // five and no `mn` that is 3.2 KB per wave less LDS: 40.7 KB per workgroup, a fourth workgroup per CU.
+    uint64_t own[ALL ? 1 : 64];  // the node's first k-1 bases
+    int64_t pos0[ALL ? 1 : 64];  // position id of (node, 0)
+    int32_t n[ALL ? 1 : 64];
     // per queued step
     uint64_t ctx[EVQ];
-    int64_t idx[EVQ];
+    typename IdxOf<ALL>::T idx[EVQ];   // first record slot of the step (all-nodes mode: relative to the node group's first)
     typename MafOf<FMT>::T maf[EVQ];
-    int32_t mn[EVQ];
+    int32_t mn[ALL ? 1 : EVQ];
     uint8_t order[EVQ];          // slot of the step at position p of the output order
     uint8_t ln[EVQ], seq[EVQ];   // the lane (node) that queued the step, and its number among that lane's queued steps
     uint8_t lbase[64];           // output position of a lane's first queued step
@@ -548,7 +564,8 @@ __device__ int g_dbg_skip_expand = 0;     // tools/exp builds only (make tuning)
 // lane: one wave scan and a scatter -- the first version sorted packed keys with a 28-stage bitonic network.
 template <int FMT, bool ALL>
 __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int my_cnt, typename OutSel<FMT>::T out, int k,
-                                             uint64_t kmask, int lane) {
+                                             uint64_t kmask, int lane, uint64_t own_reg = 0, int64_t pos0_reg = 0,
+                                             int32_t n_reg = 0, int64_t idx_base = 0) {
     if (GKI_DBG_SKIP_EXPAND_IS(1) || GKI_DBG_SKIP_EXPAND_IS(3) || GKI_DBG_SKIP_EXPAND_IS(4)) return;
     {
         int ps = my_cnt;
@@ -562,18 +579,19 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
             if (e < n_ev) q.order[(int)q.lbase[q.ln[e]] + (int)q.seq[e]] = (uint8_t)e;
             if (ALL && e < n_ev) {
                 // the step's nodes ascending (records of a window are written per distinct node, ascending): a fixed
-                // 12-comparator network on registers, every lane the same instructions; slots >= nl count as +inf
-                static_assert(NLQ == 6, "sorting network for six");
+                // 9-comparator network on registers, every lane the same instructions; slots >= nl count as +inf
+                static_assert(NLQ == 5, "sorting network for five");
                 const int nl = (int)q.nl[e];
                 int32_t v[NLQ];
 #pragma unroll
                 for (int t = 0; t < NLQ; t++) v[t] = t < nl ? q.nodes[e][t] : INT_MAX;
 #define GKI_CSWAP(i, j) { const int32_t lo_ = v[i] < v[j] ? v[i] : v[j], hi_ = v[i] < v[j] ? v[j] : v[i]; v[i] = lo_; v[j] = hi_; }
-                GKI_CSWAP(0, 5) GKI_CSWAP(1, 3) GKI_CSWAP(2, 4)
-                GKI_CSWAP(1, 2) GKI_CSWAP(3, 4)
-                GKI_CSWAP(0, 3) GKI_CSWAP(2, 5)
-                GKI_CSWAP(0, 1) GKI_CSWAP(2, 3) GKI_CSWAP(4, 5)
-                GKI_CSWAP(1, 2) GKI_CSWAP(3, 4)
+                GKI_CSWAP(0, 1) GKI_CSWAP(3, 4)
+                GKI_CSWAP(2, 4)
+                GKI_CSWAP(2, 3) GKI_CSWAP(1, 4)
+                GKI_CSWAP(0, 3)
+                GKI_CSWAP(0, 2) GKI_CSWAP(1, 3)
+                GKI_CSWAP(1, 2)
 #undef GKI_CSWAP
 #pragma unroll
                 for (int t = 0; t < NLQ; t++) q.nodes[e][t] = v[t];
@@ -581,7 +599,7 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
         }
         __builtin_amdgcn_wave_barrier();
     }
-    const int64_t mn_idx = q.idx[q.order[0]];        // smallest record slot of the queue
+    const int64_t mn_idx = (int64_t)q.idx[q.order[0]];   // smallest record slot of the queue
     // One lane per WINDOW (= per record in one-node mode).  Half of the steps of a SNP graph hold a single window, so
     // "one step per half-wave" left two thirds of the lanes idle and the address unit paid for 6.4e7 store
     // instructions on the 3 Gbp graph (SQ_INSTS_VMEM_WR).  Here the T windows of the queue are numbered in output
@@ -616,22 +634,43 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
     if (lane < MW) q.wrank[lane] = (uint16_t)(ps - pc);
     __builtin_amdgcn_wave_barrier();
     const int shift = ALL ? 0 : (int)(mn_idx & 15);
-    for (int r0 = -shift; r0 < T; r0 += 64) {
-        const int r = r0 + lane;
-        if (r >= 0 && r < T) {
-            const int w = r >> 6;
-            const int sp = (int)q.wrank[w] + __popcll(q.marks[w] & ((2ull << (r & 63)) - 1ull)) - 1;
-            const int e = (int)q.order[sp];
-            const int j = r - (int)q.pre[sp];
-            const int o = q.from[e] + j, ln = q.ln[e];
-            const uint64_t h = ((q.ctx[e] >> (2 * o)) | (q.own[ln] << (2 * (k - 1 - o)))) & kmask;
-            if (!ALL) {
-                put(out, q.idx[e] + j, h, q.mn[e], q.n[ln], o, q.pos0[ln] + o, (double)q.maf[e]);
-            } else {                                   // one record per distinct node of the window, nodes ascending
+    if (!ALL) {
+        for (int r0 = -shift; r0 < T; r0 += 64) {
+            const int r = r0 + lane;
+            if (r >= 0 && r < T) {
+                const int w = r >> 6;
+                const int sp = (int)q.wrank[w] + __popcll(q.marks[w] & ((2ull << (r & 63)) - 1ull)) - 1;
+                const int e = (int)q.order[sp];
+                const int j = r - (int)q.pre[sp];
+                const int o = q.from[e] + j, ln = q.ln[e];
+                const uint64_t h = ((q.ctx[e] >> (2 * o)) | (q.own[ln] << (2 * (k - 1 - o)))) & kmask;
+                put(out, (int64_t)q.idx[e] + j, h, q.mn[e], q.n[ln], o, q.pos0[ln] + o, (double)q.maf[e]);
+            }
+        }
+    } else {
+        // all-nodes mode: one record per distinct node of the window, nodes ascending.  What belongs to the walking lane
+        // (its node's own bases, position id, node id) stays in that lane's registers and is fetched by shuffle -- with
+        // every lane taking part, a lane outside the trip asks for lane 0.
+        for (int r0 = 0; r0 < T; r0 += 64) {
+            const int r = r0 + lane;
+            const bool valid = r < T;
+            int e = 0, j = 0, o = 0, ln = 0;
+            if (valid) {
+                const int w = r >> 6;
+                const int sp = (int)q.wrank[w] + __popcll(q.marks[w] & ((2ull << (r & 63)) - 1ull)) - 1;
+                e = (int)q.order[sp];
+                j = r - (int)q.pre[sp];
+                o = q.from[e] + j; ln = q.ln[e];
+            }
+            const uint64_t own_v = (uint64_t)__shfl((unsigned long long)own_reg, ln, 64);
+            const int64_t pos0_v = (int64_t)__shfl((long long)pos0_reg, ln, 64);
+            const int32_t n_v = __shfl(n_reg, ln, 64);
+            if (valid) {
+                const uint64_t h = ((q.ctx[e] >> (2 * o)) | (own_v << (2 * (k - 1 - o)))) & kmask;
                 const int nl = (int)q.nl[e];
-                const int64_t first = q.idx[e] + (int64_t)j * nl;
+                const int64_t first = idx_base + (int64_t)q.idx[e] + (int64_t)j * nl;
                 for (int t = 0; t < nl; t++)
-                    put(out, first + t, h, q.nodes[e][t], q.n[ln], o, q.pos0[ln] + o, (double)q.maf[e]);
+                    put(out, first + t, h, q.nodes[e][t], n_v, o, pos0_v + o, (double)q.maf[e]);
             }
         }
     }
@@ -651,8 +690,9 @@ __global__ __launch_bounds__(256, (GEN && !ALL && FMT != 1) ? 4 : 1) void k_emit
                                                            const int64_t *__restrict__ rec_base,
                                                            const int64_t *__restrict__ bnd_shift,
                                                            typename OutSel<FMT>::T out, int *__restrict__ err) {
+    typedef WalkCacheT<!ALL || GEN || HAS_LOSSY> WCache;      // the flag words only where they are read (or LDS is not the limit)
     __shared__ EvQueue<FMT, ALL> s_q[4];
-    __shared__ WalkCache s_wc[4];
+    __shared__ WCache s_wc[4];
     LevelEmit below[MAXN];
     LevelEmit below0;                  // the first suspended level stays in registers
     below0.ctx = 0; below0.maf = 0.0; below0.cur = below0.end = below0.mn = 0; below0.cum = below0.vc = below0.evf = below0.evt = 0;
@@ -664,13 +704,19 @@ __global__ __launch_bounds__(256, (GEN && !ALL && FMT != 1) ? 4 : 1) void k_emit
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     EvQueue<FMT, ALL> &q = s_q[wib];
-    WalkCache &wc = s_wc[wib];
+    WCache &wc = s_wc[wib];
     const int k = a.k;
     const uint64_t kmask = (1ull << (2 * k)) - 1ull;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const int64_t n_threads = (int64_t)gridDim.x * blockDim.x;
     int n_ev = 0, my_cnt = 0;              // steps in the queue; of them, queued by this lane
     for (int64_t base = a.n0 + (int64_t)blockIdx.x * blockDim.x + wib * 64; base < a.n1; base += n_threads) {
+        int64_t idx_base = 0;              // all-nodes mode: queued record slots are 32-bit offsets from the group's first
+        if (ALL) {
+            const int64_t last = base + 64 < a.n1 ? base + 64 : a.n1;
+            idx_base = rec_base[base] + *bnd_shift;
+            if (rec_base[last] - rec_base[base] > 0xFFFFFFFFll) { gki_raise(err, GKI_ERR_WINDOW_TOO_DEEP); continue; }
+        }
         const WalkView wv = stage_walk(g, wc, base, lane, GEN ? a.nflags : nullptr, HAS_LOSSY ? lossy : nullptr);
         const int64_t n = base + lane;
         int L = 0, o_lo = 0, hi = 0;
@@ -709,7 +755,7 @@ __global__ __launch_bounds__(256, (GEN && !ALL && FMT != 1) ? 4 : 1) void k_emit
                     t_mn = (int32_t)n; t_maf = FMT == 1 ? g.allele_freq[n] : (double)wn.af;   // float32 rounding is monotonic:
                     // the minimum of the rounded values is the rounded minimum (flat layout), v2 keeps float64
                     own = gki_extract(g.seq2, wn.seq_start, hi);
-                    q.own[lane] = own; q.pos0[lane] = pos0; q.n[lane] = (int32_t)n;
+                    if (!ALL) { q.own[lane] = own; q.pos0[lane] = pos0; q.n[lane] = (int32_t)n; }
                     if (ALL || GEN) path[0] = (int32_t)n;
                     t_a = nonfree0 ? v0 : 0;
                     L = 1;
@@ -851,14 +897,15 @@ __global__ __launch_bounds__(256, (GEN && !ALL && FMT != 1) ? 4 : 1) void k_emit
             if (pending) {
                 const int n_new = __popcll(pending);
                 if (n_ev + n_new > EVQ) {                    // wave-uniform: make room first
-                    expand_queue<FMT, ALL>(q, n_ev, my_cnt, out, k, kmask, lane);
+                    expand_queue<FMT, ALL>(q, n_ev, my_cnt, out, k, kmask, lane, own, pos0, (int32_t)n, idx_base);
                     n_ev = 0; my_cnt = 0;
                 }
                 if (ev) {
                     const int slot = n_ev + __popcll(pending & lt_mask);
                     q.ln[slot] = (uint8_t)lane; q.seq[slot] = (uint8_t)my_cnt++;
-                    q.ctx[slot] = e_ctx; q.idx[slot] = idx;
-                    q.maf[slot] = (typename MafOf<FMT>::T)e_maf; q.mn[slot] = e_mn;
+                    q.ctx[slot] = e_ctx; q.idx[slot] = (typename IdxOf<ALL>::T)(idx - idx_base);
+                    q.maf[slot] = (typename MafOf<FMT>::T)e_maf;
+                    if (!ALL) q.mn[slot] = e_mn;
                     q.from[slot] = (uint8_t)e_from; q.cnt[slot] = (uint8_t)(e_to - e_from);
                     if (ALL) {
                         q.nl[slot] = (uint8_t)e_nls;
@@ -881,7 +928,7 @@ __global__ __launch_bounds__(256, (GEN && !ALL && FMT != 1) ? 4 : 1) void k_emit
             }
         }
         if (n_ev > 0) {                                      // the queue never mixes node groups (see expand_queue)
-            expand_queue<FMT, ALL>(q, n_ev, my_cnt, out, k, kmask, lane);
+            expand_queue<FMT, ALL>(q, n_ev, my_cnt, out, k, kmask, lane, own, pos0, (int32_t)n, idx_base);
             n_ev = 0; my_cnt = 0;
         }
     }

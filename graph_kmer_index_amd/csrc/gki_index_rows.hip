@@ -274,13 +274,21 @@ __global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
 }
 
 // First row and one-past-last row of every group (group = key >> L) in the keys sorted by group; arrays zeroed before.
+// One coalesced load per key, the neighbours' keys by shuffle (the two edge lanes of a wave load theirs).
 __global__ __launch_bounds__(256) void k_group_bounds(const uint32_t *__restrict__ keys, int64_t n, int L,
                                                       uint32_t *__restrict__ gbegin, uint32_t *__restrict__ gend) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t g = keys[i] >> L;
-        if (i == 0 || (keys[i - 1] >> L) != g) gbegin[g] = (uint32_t)i;
-        if (i == n - 1 || (keys[i + 1] >> L) != g) gend[g] = (uint32_t)(i + 1);
+    const int lane = threadIdx.x & 63;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); i0 < n; i0 += stride) {
+        const int64_t i = i0 + lane;
+        const bool valid = i < n;
+        const uint32_t g = valid ? keys[i] >> L : 0u;
+        uint32_t before = __shfl_up(g, 1, 64), after = __shfl_down(g, 1, 64);
+        if (lane == 0 && i > 0) before = keys[i - 1] >> L;
+        if (lane == 63 && i + 1 < n) after = keys[i + 1] >> L;
+        if (!valid) continue;
+        if (i == 0 || before != g) gbegin[g] = (uint32_t)i;
+        if (i == n - 1 || after != g || (lane < 63 && i + 1 >= n)) gend[g] = (uint32_t)(i + 1);
     }
 }
 
@@ -525,14 +533,32 @@ int key_bits(uint64_t max_key) {
 
 }  // namespace
 
-__global__ void k_bucket_keys_only(const uint64_t *__restrict__ kmers, int64_t n, uint64_t modulo, uint64_t bucket_begin,
-                                   uint64_t n_buckets, uint32_t *__restrict__ keys, int *__restrict__ out_of_range) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint64_t b = kmers[i] % modulo - bucket_begin;       // collision_free_kmer_index.py:433
-        if (b >= n_buckets) *out_of_range = 1;
-        keys[i] = b < n_buckets ? (uint32_t)b : 0u;
+// key = kmer % modulo - bucket_begin for the tile's records, and the tile's histogram of the first pass's digit in the
+// same sweep (the keys are not read back for it)
+template <int THREADS, int RI>
+__global__ __launch_bounds__(THREADS) void k_bucket_keys_hist(const uint64_t *__restrict__ kmers, int64_t n, uint64_t modulo,
+                                                              uint64_t bucket_begin, uint64_t n_buckets, int shift, int bits,
+                                                              uint32_t *__restrict__ keys, uint32_t *__restrict__ hist, int64_t n_tiles,
+                                                              int *__restrict__ out_of_range) {
+    __shared__ uint32_t h[MAXB];
+    const int bins = 1 << bits;
+    for (int d = threadIdx.x; d < bins; d += THREADS) h[d] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * (THREADS * RI);
+    const uint32_t mask = (uint32_t)bins - 1u;
+#pragma unroll
+    for (int r = 0; r < RI; r++) {
+        const int64_t i = base + r * THREADS + threadIdx.x;
+        if (i < n) {
+            const uint64_t b = kmers[i] % modulo - bucket_begin;       // collision_free_kmer_index.py:433
+            if (b >= n_buckets) *out_of_range = 1;
+            const uint32_t key = b < n_buckets ? (uint32_t)b : 0u;
+            keys[i] = key;
+            atomicAdd(&h[(key >> shift) & mask], 1u);
+        }
     }
+    __syncthreads();
+    for (int d = threadIdx.x; d < bins; d += THREADS) hist[(int64_t)d * n_tiles + blockIdx.x] = h[d];
 }
 
 // Tile shape of the partition passes.  4096-row tiles (one workgroup of 512 threads per CU, 144 KB of LDS) give every
@@ -578,9 +604,6 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
         HIP_G(gki_dev_malloc((void **)&keys[0], (size_t)n * 4));
         HIP_G(gki_dev_malloc((void **)&stats, 64));
         HIP_G(hipMemsetAsync(stats, 0, 64, s));
-        hipLaunchKernelGGL(k_bucket_keys_only, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const uint64_t *)d_kmers, n, modulo,
-                           bucket_begin, n_buckets, keys[0], (int *)(stats + 3));
-        HIP_G(hipGetLastError());
         for (int i = 0; i < (n_pass > 1 ? 2 : 1); i++) HIP_G(gki_dev_malloc((void **)&rows[i], (size_t)n * 24));
         for (int i = 1; i < (n_pass > 1 ? 3 : 2); i++) HIP_G(gki_dev_malloc((void **)&keys[i], (size_t)n * 4));
         HIP_G(gki_dev_malloc((void **)&hist, (size_t)hist_n * 4));
@@ -599,8 +622,12 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
         for (int p = 0; p < n_pass; p++) {
             const int bits = (top - (shift - L) + (n_pass - p) - 1) / (n_pass - p);       // remaining bits spread evenly
             const int64_t bins_n = ((int64_t)1 << bits) * n_tiles;
-            hipLaunchKernelGGL((k_digit_hist<THREADS, RI>), dim3((unsigned)n_tiles), dim3(THREADS), 0, s, cur_keys, n, shift, bits,
-                               hist, n_tiles);
+            if (p == 0)
+                hipLaunchKernelGGL((k_bucket_keys_hist<THREADS, RI>), dim3((unsigned)n_tiles), dim3(THREADS), 0, s, (const uint64_t *)d_kmers,
+                                   n, modulo, bucket_begin, n_buckets, shift, bits, keys[0], hist, n_tiles, (int *)(stats + 3));
+            else
+                hipLaunchKernelGGL((k_digit_hist<THREADS, RI>), dim3((unsigned)n_tiles), dim3(THREADS), 0, s, cur_keys, n, shift, bits,
+                                   hist, n_tiles);
             HIP_G(hipGetLastError());
             rc = gki_scan_u32_to_u32(hist, bins_n, offs, tmp, tmp_bytes, s);
             if (rc != GKI_OK) goto done;

@@ -47,9 +47,10 @@ def search_roots(g, k):
     return [int(g.first_node)] + [int(s) for s in g.chromosome_start_nodes.values() if g.node_size[s] >= k]
 
 
-def classify_nodes(g, k, max_variant_nodes, only_follow_nodes=None, critical_nodes=None):
+def classify_nodes(g, k, max_variant_nodes, only_follow_nodes=None, critical_nodes=None, on_device=None, always_flags=True):
     """(uint16[n_nodes] GKI_NODE_* flags | history bound << 8, general) -- gki_classify_nodes (include/gki.h): which nodes the order-free
-    form of the variant limit (kmer_finder.py:383-417) can stop at when it looks for a history.  `general` False
+    form of the variant limit (kmer_finder.py:383-417) can stop at when it looks for a history (on the device by
+    relaxation sweeps, gki_graph_classify_nodes; the host pass takes over without a device and for nested non-free nodes).  `general` False
     means "at most max_variant_nodes variant nodes in the window" is the whole rule for this graph and the kernels run
     without the flags.  Host pass in topological order; kept on the graph object per (k, limit, follow set)."""
     follow = None
@@ -59,7 +60,7 @@ def classify_nodes(g, k, max_variant_nodes, only_follow_nodes=None, critical_nod
         follow[ids[(ids >= 0) & (ids < g.n_nodes)]] = 1
     # the same clamp as gki_finder_count / gki_forward_* (250): classification and kernels decide on one limit
     crit = np.zeros(0, dtype=np.int32) if critical_nodes is None else np.ascontiguousarray(critical_nodes, dtype=np.int32)
-    key = (int(k), min(int(max_variant_nodes), 250), None if follow is None else follow.tobytes(), crit.tobytes())
+    key = (int(k), min(int(max_variant_nodes), 250), None if follow is None else follow.tobytes(), crit.tobytes(), bool(always_flags), on_device)
     cache = g.__dict__.setdefault("_node_classes", {})
     if key not in cache:
         if len(cache) > 8:
@@ -68,11 +69,19 @@ def classify_nodes(g, k, max_variant_nodes, only_follow_nodes=None, critical_nod
         # kmer_finder.py:190-232)
         roots = np.ascontiguousarray(np.concatenate([np.asarray(search_roots(g, k), dtype=np.int32), crit]))
         flags = np.zeros(g.n_nodes, dtype=np.uint16)
-        general = C.c_int32(0)
-        _lib.check(_lib.load().gki_classify_nodes(
-            g.n_nodes, _lib.hptr(g.node_size), _lib.hptr(g.edge_start), _lib.hptr(g.edges), _lib.hptr(g.rev_start),
-            _lib.hptr(g.rev_edges), _lib.hptr(g.is_ref), _lib.hptr(follow), _lib.hptr(roots), len(roots), int(k),
-            min(int(max_variant_nodes), 250), _lib.hptr(flags), C.byref(general)))
+        general, needs_host = C.c_int32(0), C.c_int32(1)
+        M = min(int(max_variant_nodes), 250)
+        if on_device is None:
+            on_device = _lib.device_count() > 0
+        if on_device:                                # relaxation sweeps over the resident graph (csrc/gki_classify.hip)
+            _lib.check(_lib.load().gki_graph_classify_nodes(
+                DeviceGraph.of(g).handle, _lib.hptr(follow), _lib.hptr(roots), len(roots), int(k), M, _lib.hptr(flags),
+                int(bool(always_flags)), C.byref(general), C.byref(needs_host)))
+        if needs_host.value:                         # no device, or a nested non-free node: the host pass decides its history
+            _lib.check(_lib.load().gki_classify_nodes(
+                g.n_nodes, _lib.hptr(g.node_size), _lib.hptr(g.edge_start), _lib.hptr(g.edges), _lib.hptr(g.rev_start),
+                _lib.hptr(g.rev_edges), _lib.hptr(g.is_ref), _lib.hptr(follow), _lib.hptr(roots), len(roots), int(k),
+                M, _lib.hptr(flags), C.byref(general)))
         cache[key] = (flags, bool(general.value))
     return cache[key]
 
@@ -240,6 +249,15 @@ class DenseKmerFinder:
         if node_begin >= g.n_nodes:
             return None
         return p
+
+    def set_critical_path_range(self, start_at_critical_path_number, stop_at_critical_path_number):
+        """Point this finder at another chunk [start, stop) of critical-path numbers (kmer_finder.py:192-205) -- what the
+        reference does with one DenseKmerFinder per chunk (command_line_interface.py:559-565).  The device handle and its
+        per-graph arrays are kept, only the run parameters are rebuilt."""
+        self._start_at_critical_path_number = start_at_critical_path_number
+        self._stop_at_critical_path_number = stop_at_critical_path_number
+        self._params_cache = None
+        self._cols = None
 
     def _count(self, layout=0):
         p = self._params()

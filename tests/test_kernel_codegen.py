@@ -74,13 +74,16 @@ def test_occupancy_footprints_of_the_walk_kernels(finder_asm):
               "k_count_boundary<false, true>"):
         assert waves_by_regs(r[v]["vgpr"]) == 8, (v, r[v])
         assert blocks_by_lds(r[v]["lds"]) >= 8, (v, r[v])
-    # emit pass, flat layouts (FMT 0 / 2): 4 workgroups per CU in one-node mode, 3 in all-nodes mode; registers never the limit
+    # emit pass, flat layouts (FMT 0 / 2): 4 workgroups per CU in one-node mode, and since round 3 in all-nodes mode too
+    # (per-lane facts shuffled instead of staged, 32-bit record slots, node lists of five, no flag words: 40.9 KB); the
+    # all-nodes variant of runs with lossy restart points keeps the flag words and stays at 3; registers never the limit
     for lossy in ("false", "true"):
         for fmt in ("0", "2"):
             one = r["k_emit_boundary_one<%s, %s, false, false>" % (lossy, fmt)]
             allm = r["k_emit_boundary_one<%s, %s, true, false>" % (lossy, fmt)]
             assert blocks_by_lds(one["lds"]) == 4 and waves_by_regs(one["vgpr"]) >= 4, (lossy, fmt, one)
-            assert blocks_by_lds(allm["lds"]) == 3 and waves_by_regs(allm["vgpr"]) >= 3, (lossy, fmt, allm)
+            want = 4 if lossy == "false" else 3
+            assert blocks_by_lds(allm["lds"]) == want and waves_by_regs(allm["vgpr"]) >= want, (lossy, fmt, allm)
     for lossy in ("false", "true"):            # general variants, with and without the lossy-restart logic
         gen = r["k_emit_boundary_one<%s, 2, false, true>" % lossy]
         assert blocks_by_lds(gen["lds"]) == 4 and waves_by_regs(gen["vgpr"]) >= 4, (lossy, gen)
