@@ -291,10 +291,12 @@ def secondary_records(lib, _lib, g, k, cp, finder, out, n_reads, cpu2, max_varia
         if idx is not None:
             idx.free()
         sync()
+        pool0 = _lib.pool_stats()
         t = time.perf_counter()
         idx = DeviceIndex.build(bnd, modulo)
         sync()
         dt = time.perf_counter() - t
+        pool1 = _lib.pool_stats()
     kb = int(modulo - 1).bit_length()
     # algorithmic bytes of the build as implemented (csrc/gki_index_rows.hip), per record: bucket keys 8 R + 4 W; two
     # partition passes on the top 18 bits, each 4 R (histogram) + 28 R + 28 W (24-byte row + key); group bounds 4 R;
@@ -306,6 +308,7 @@ def secondary_records(lib, _lib, g, k, cp, finder, out, n_reads, cpu2, max_varia
                    "frequencies": True, "bytes_moved_model": int(moved), "bytes_per_record_model": per_record,
                    "achieved_GBps": moved / dt / 1e9, "frac_of_hbm_peak": moved / dt / 1e9 / HBM_PEAK_GBS,
                    "timed": "wall clock around DeviceIndex.build incl. its allocations, device synchronised",
+                   "ms_in_device_allocator": (pool1[2] - pool0[2]) + (pool1[3] - pool0[3]),
                    "cpu_baseline": cpu2.get("index_build")}
     # scalar CollisionFreeKmerIndex.get (:303-315): one launch + one synchronisation per call (gki_index_get_small)
     some = bnd.hashes.view(0, min(nb, 4096)).to_host()
@@ -384,8 +387,8 @@ def full_index_record(lib, _lib, g, k, cp, out, max_variant_nodes, modulo, n_sli
     (collision_free_kmer_index.py:453), so the index is built in bucket-range slices -- BASELINE
     configs[3]'s data flow with the 8 ranks taken in turn: every rank's critical-path shard is enumerated and
     partitioned by owning slice, the all-to-all is stood in for by device copies in rank order (exactly what
-    gki_comm_alltoall_flat delivers), every slice is built with frequencies.  The step's own output columns are
-    released first (their checksums are kept: the slices' payload must be the same multiset)."""
+    gki_comm_alltoall_flat delivers), every slice is built with frequencies.  The step's own output columns become the
+    storage of the partitioned shards (their checksums are kept: the slices' payload must be the same multiset)."""
     from graph_kmer_index_amd.flat_kmers import DeviceFlatKmers
     from graph_kmer_index_amd.collision_free_kmer_index import DeviceIndex, bucket_range, partition_by_bucket_range
     def sync():
@@ -394,40 +397,58 @@ def full_index_record(lib, _lib, g, k, cp, out, max_variant_nodes, modulo, n_sli
     MASK = (1 << 64) - 1
     cols = ("hashes", "nodes", "ref_offsets", "allele_frequencies")
     want = [getattr(out, c).checksum(n) for c in cols]
-    for c in cols:
-        getattr(out, c).free()
-    _lib.check(lib.gki_trim())                       # parked blocks of the earlier records go back to the device
+    # The step's columns are dead from here on (their checksums are kept) and become the storage of the partitioned
+    # shards: no allocation or release of tens of GB inside this record -- hipMalloc / hipFree at that size cost seconds
+    # on this stack (§6 "Device memory pool"), which an earlier version of this record measured instead of the build.
     W = n_slices
     kw = dict(only_save_one_node_per_kmer=True, max_variant_nodes=max_variant_nodes)
-    sync()
-    t_all = time.perf_counter()
-    t_find = t_part = t_copy = t_build = 0.0
-    shards, starts = [], []
     from graph_kmer_index_amd import DenseKmerFinder
     from graph_kmer_index_amd.sharding import shard_range
     finder = DenseKmerFinder(g, k, critical_graph_paths=cp, **kw)     # one finder, one device handle, eight chunks
+    ranges, sizes_in = [], []
     for r in range(W):
         a, b = shard_range(g, cp, r, W)
         finder.set_critical_path_range(a, b)
+        ranges.append((a, b))
+        sizes_in.append(finder._count(layout=1))
+    if sum(sizes_in) != n:
+        raise _lib.GkiError(2, "full_index: the shards hold %d records, the step %d" % (sum(sizes_in), n))
+    mine = DeviceFlatKmers.allocate(max(sizes_in))                    # one shard's columns, reused
+    sync()
+    pool0 = _lib.pool_stats()
+    t_all = time.perf_counter()
+    t_find = t_part = t_copy = t_build = 0.0
+    find_ms = []
+    shards, starts = [], []
+    at = 0
+    for r in range(W):
+        finder.set_critical_path_range(*ranges[r])
         finder._params()                              # (host-side validation of the chunk: not device work)
         sync()
         t = time.perf_counter()
-        mine = finder.find_flat_on_device()
+        mine = finder.find_flat_on_device(mine)
         finder.synchronize()
+        find_ms.append(1e3 * (time.perf_counter() - t))
         t_find += time.perf_counter() - t
         t = time.perf_counter()
-        by_dest, send_start = partition_by_bucket_range(mine, modulo, W)
+        dest = DeviceFlatKmers(mine.n, *[getattr(out, c).view(at, mine.n) for c in cols])
+        by_dest, send_start = partition_by_bucket_range(mine, modulo, W, out=dest)
         sync()
         t_part += time.perf_counter() - t
-        mine.free()
+        at += mine.n
         shards.append(by_dest)
         starts.append(send_start)
+    mine.free()
     got = [(0, 0)] * 4
     sizes = []
-    for p in range(W):
+    recv = DeviceFlatKmers.allocate(max(sum(st[p + 1] - st[p] for st in starts) for p in range(W)))      # one slice's records, reused
+    for p in [-1] + list(range(W)):                # p = -1: slice 0 once untimed, it sizes the library's memory pool (the
+        warm = p < 0                               # index_build record measures its third build for the same reason)
+        p = max(p, 0)
+        t_copy0, t_build0 = t_copy, t_build
         t = time.perf_counter()
         n_p = sum(st[p + 1] - st[p] for st in starts)
-        recv = DeviceFlatKmers.allocate(n_p)
+        recv.n = n_p
         at = 0
         for part, st in zip(shards, starts):
             m = st[p + 1] - st[p]
@@ -443,19 +464,28 @@ def full_index_record(lib, _lib, g, k, cp, out, max_variant_nodes, modulo, n_sli
         sl = DeviceIndex.build(recv, modulo, bucket_begin=lo, n_buckets=hi - lo)
         sync()
         t_build += time.perf_counter() - t
-        recv.free()
+        if warm:
+            t_copy, t_build = t_copy0, t_build0
+            pool0 = _lib.pool_stats()
+            sl.free()
+            continue
         for i, colname in enumerate(("kmers", "nodes", "ref_offsets", "allele_frequencies")):
             s, x = getattr(sl, colname).checksum(sl.n)
             got[i] = ((got[i][0] + s) & MASK, got[i][1] ^ x)
         sizes.append(sl.n)
         sl.free()                    # checksummed and released before the next slice is built
+    recv.free()
     dt_all = time.perf_counter() - t_all
-    for c in shards:
-        c.free()
+    pool1 = _lib.pool_stats()
     total = sum(sizes)
     rec = {"records": int(total), "slices": W, "records_per_slice": sizes, "exceeds_int32_directory": bool(total >= 2 ** 31),
-           "find_shards_ms": 1e3 * t_find, "partition_ms": 1e3 * t_part, "exchange_standin_copy_ms": 1e3 * t_copy,
-           "build_slices_ms": 1e3 * t_build, "ms": 1e3 * dt_all, "records_per_s": total / dt_all,
+           "find_shards_ms": 1e3 * t_find, "find_ms_per_shard": [round(x, 2) for x in find_ms], "partition_ms": 1e3 * t_part, "exchange_standin_copy_ms": 1e3 * t_copy,
+           "build_slices_ms": 1e3 * t_build, "ms": 1e3 * (t_find + t_part + t_copy + t_build),
+           "records_per_s": total / (t_find + t_part + t_copy + t_build),
+           "device_allocator": {"hipMalloc_calls": pool1[0] - pool0[0], "hipFree_calls": pool1[1] - pool0[1],
+                                "ms_in_hipMalloc": pool1[2] - pool0[2], "ms_in_hipFree": pool1[3] - pool0[3],
+                                "note": "inside the slice builds above, after slice 0 was built once untimed to size the library's "
+                                        "pool: what still reaches hipMalloc / hipFree"},
            "equals_step_output": bool(total == n),
            "payload_equals_flat_multiset": [tuple(w) for w in want] == [tuple(x) for x in got],
            "timed": "wall clock, device synchronised per phase: %d critical-path shards enumerated (gki_finder_count + "
@@ -685,15 +715,14 @@ def main():
 
     G, S, k = int(args.bases), int(args.sites), args.k
     t0 = time.perf_counter()
-    cp = CriticalGraphPaths.from_graph(g, k)
-    t_crit = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    dg = DeviceGraph(g)
+    dg = DeviceGraph.of(g)                           # upload + device-side preparation; cached on the graph object
     t_up = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cp = CriticalGraphPaths.from_graph(g, k)         # on the device, over the resident graph (csrc/gki_critical.hip)
+    t_crit = time.perf_counter() - t0
     if rank == 0:
         log("graph: %d nodes, %d bases (+%d alt), %d critical points; generate %.1fs (once per node), critical paths %.2fs, "
             "upload+prepare %.2fs" % (g.n_nodes, G, len(g.seq) - G, len(cp), t_gen, t_crit, t_up))
-    g._device = dg
     shard_r, shard_w = rank, world
     if args.pretend_shard:
         shard_r, shard_w = (int(x) for x in args.pretend_shard.split("/"))
@@ -704,6 +733,9 @@ def main():
                              stop_at_critical_path_number=b if shard_w > 1 else None)
 
     finder._force_general_kernels = args.general
+    t0 = time.perf_counter()
+    finder._params()                                 # node classification (device) + run parameters, once per finder
+    t_cls = time.perf_counter() - t0
 
     def barrier():
         _lib.check(lib.gki_device_synchronize())
@@ -778,7 +810,7 @@ def main():
                                          "store pattern alone in a kernel, 24 B per record, best of two launches"
                                          + ("; per rank: %s" % ["%.0f" % c for c in ceilings] if world > 1 else "")},
             "kernels_ms_rank0_last_step": kern,
-            "setup_s": {"generate_graph_host_once_per_node": t_gen, "map_shared_graph": t_map, "critical_paths": t_crit,
+            "setup_s": {"generate_graph_host_once_per_node": t_gen, "map_shared_graph": t_map, "critical_paths_device": t_crit, "classify_nodes_and_run_parameters": t_cls,
                         "upload_and_prepare": t_up},
         }
         if checks is not None:

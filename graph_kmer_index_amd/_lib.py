@@ -54,6 +54,7 @@ SYMBOLS = {
     "gki_malloc": (_I32, [C.POINTER(_P), _I64]),
     "gki_free": (_I32, [_P]),
     "gki_trim": (_I32, []),
+    "gki_pool_stats": (_I32, [C.POINTER(_I64), C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_I64)]),
     "gki_memcpy_h2d": (_I32, [_P, _P, _I64]),
     "gki_memcpy_d2h": (_I32, [_P, _P, _I64]),
     "gki_memcpy_d2d": (_I32, [_P, _P, _I64]),
@@ -161,6 +162,13 @@ def device_count():
 def require_device():
     if device_count() < 1:
         raise GkiError(3, "no HIP device visible: graph_kmer_index_amd needs an MI355X (no CPU fallback)")
+
+
+def pool_stats():
+    """(device mallocs, device frees, ms in hipMalloc, ms in hipFree, bytes parked) of this process so far."""
+    a, b, c, d, e = _I64(0), _I64(0), C.c_double(0), C.c_double(0), _I64(0)
+    check(load().gki_pool_stats(C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e)))
+    return a.value, b.value, c.value, d.value, e.value
 
 
 def hptr(a):

@@ -191,10 +191,15 @@ def bucket_range(modulo, n_parts, part):
     return modulo * part // n_parts, modulo * (part + 1) // n_parts
 
 
-def partition_by_bucket_range(dflat, modulo, n_parts):
-    """Stable partition of device FlatKmers columns by owning part.  Returns (DeviceFlatKmers, part_start[n_parts+1])."""
+def partition_by_bucket_range(dflat, modulo, n_parts, out=None):
+    """Stable partition of device FlatKmers columns by owning part.  Returns (DeviceFlatKmers, part_start[n_parts+1]).
+    `out`: columns to write into (at least dflat.n records, not overlapping dflat) instead of a fresh allocation."""
     _lib.require_device()
-    out = DeviceFlatKmers.allocate(dflat.n)
+    if out is None:
+        out = DeviceFlatKmers.allocate(dflat.n)
+    else:
+        assert out.hashes.n >= dflat.n
+        out.n = dflat.n
     start = (C.c_int64 * (n_parts + 1))()
     _lib.check(_lib.load().gki_partition_by_bucket_range(
         dflat.hashes.ptr, dflat.nodes.ptr, dflat.ref_offsets.ptr, dflat.allele_frequencies.ptr, dflat.n, int(modulo),

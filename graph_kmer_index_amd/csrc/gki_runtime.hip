@@ -1,6 +1,7 @@
 // Runtime plumbing of libgki_hip.so: errors, memory, and the exclusive-scan primitive.
 #include "gki_common.h"
 #include <stdarg.h>
+#include <time.h>
 
 thread_local char gki_err_buf[512] = "";
 
@@ -28,6 +29,22 @@ std::mutex g_pool_mu;
 std::multimap<size_t, void *> g_pool_free;          // parked blocks by size
 std::unordered_map<void *, size_t> g_pool_live;     // size of every block handed out
 size_t g_pool_cached = 0;                           // bytes parked
+// what the device allocator itself cost this process (gki_pool_stats): calls that reached hipMalloc / hipFree, their time
+int64_t g_n_malloc = 0, g_n_free = 0;
+double g_ms_malloc = 0.0, g_ms_free = 0.0;
+double now_ms() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 1e3 * (double)t.tv_sec + 1e-6 * (double)t.tv_nsec; }
+hipError_t timed_malloc(void **p, size_t bytes) {
+    const double t0 = now_ms();
+    hipError_t e = hipMalloc(p, bytes);
+    g_ms_malloc += now_ms() - t0; g_n_malloc++;
+    return e;
+}
+hipError_t timed_free(void *p) {
+    const double t0 = now_ms();
+    hipError_t e = hipFree(p);
+    g_ms_free += now_ms() - t0; g_n_free++;
+    return e;
+}
 size_t pool_cap() {                                 // park at most half of the device's memory (other libraries allocate too)
     static size_t cap = 0;
     if (!cap) { size_t f = 0, t = 0; cap = hipMemGetInfo(&f, &t) == hipSuccess ? t / 2 : (size_t)64 << 30; }
@@ -36,7 +53,7 @@ size_t pool_cap() {                                 // park at most half of the 
 bool pool_enabled() { static const bool on = !(getenv("GKI_POOL") && atoi(getenv("GKI_POOL")) == 0); return on; }
 void pool_trim() {
     std::lock_guard<std::mutex> lock(g_pool_mu);
-    for (auto &kv : g_pool_free) (void)hipFree(kv.second);
+    for (auto &kv : g_pool_free) (void)timed_free(kv.second);
     g_pool_free.clear();
     g_pool_cached = 0;
 }
@@ -65,11 +82,11 @@ hipError_t gki_dev_malloc(void **ptr, size_t bytes) {
             return hipSuccess;
         }
     }
-    hipError_t e = hipMalloc(ptr, bytes);
+    hipError_t e = timed_malloc(ptr, bytes);
     if (e != hipSuccess) {                               // out of memory: give the cache back and retry once
         (void)hipGetLastError();
         pool_trim();
-        e = hipMalloc(ptr, bytes);
+        e = timed_malloc(ptr, bytes);
     }
     if (e == hipSuccess && pool_enabled()) {
         std::lock_guard<std::mutex> lock(g_pool_mu);
@@ -89,13 +106,13 @@ hipError_t gki_dev_free(void *ptr) {
         if (it != g_pool_live.end()) {
             const size_t bytes = it->second;
             g_pool_live.erase(it);
-            if (g_pool_cached + bytes > pool_cap()) return hipFree(ptr);
+            if (g_pool_cached + bytes > pool_cap()) return timed_free(ptr);
             g_pool_free.emplace(bytes, ptr);
             g_pool_cached += bytes;
             return hipSuccess;
         }
     }
-    return hipFree(ptr);
+    return timed_free(ptr);
 }
 
 namespace {
@@ -155,6 +172,13 @@ int gki_malloc(void **d_ptr, int64_t bytes) {
 int gki_free(void *d_ptr) { if (d_ptr) HIP_TRY(gki_dev_free(d_ptr)); return GKI_OK; }
 
 int gki_trim(void) { pool_trim(); return GKI_OK; }
+
+int gki_pool_stats(int64_t *n_device_mallocs, int64_t *n_device_frees, double *ms_in_malloc, double *ms_in_free, int64_t *bytes_parked) {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    *n_device_mallocs = g_n_malloc; *n_device_frees = g_n_free; *ms_in_malloc = g_ms_malloc; *ms_in_free = g_ms_free;
+    *bytes_parked = (int64_t)g_pool_cached;
+    return GKI_OK;
+}
 
 int gki_memcpy_h2d(void *d_dst, const void *h_src, int64_t bytes) {
     if (bytes > 0) HIP_TRY(hipMemcpy(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice));

@@ -45,6 +45,12 @@ int gki_free(void *d_ptr);
 /* gki_malloc / gki_free and the library's own temporaries go through a cache of freed blocks (a fresh hipMalloc of
  * tens of GB costs up to seconds on this stack); gki_trim returns the cache to the device.  GKI_POOL=0 disables it. */
 int gki_trim(void);
+/* What the device allocator itself cost this process so far: the calls that reached hipMalloc / hipFree (the pool
+ * answers the others), the wall time spent inside them, and the bytes parked now.  hipMalloc / hipFree of tens of GB take
+ * from tenths of a second to seconds on this stack; a benchmark that allocates inside its timed phases reports the
+ * difference of two calls beside them. */
+int gki_pool_stats(int64_t *n_device_mallocs, int64_t *n_device_frees, double *ms_in_malloc, double *ms_in_free,
+                   int64_t *bytes_parked);
 int gki_memcpy_h2d(void *d_dst, const void *h_src, int64_t bytes);
 int gki_memcpy_d2h(void *h_dst, const void *d_src, int64_t bytes);
 int gki_memcpy_d2d(void *d_dst, const void *d_src, int64_t bytes);

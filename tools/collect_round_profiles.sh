@@ -15,10 +15,10 @@ python3 - "$O" <<'PY'
 import csv, json, sys
 o = sys.argv[1]
 d = json.loads(open(o + "/bench.json").readline())
-print("bench: %.2f ms/step, %.3g k-mers/s, roofline frac %.3f, index_build %.1f ms (reverse %.1f), read_mapping %.3g k-mers/s, early_stop %.3g starts/s" % (
-    d["ms_per_step"], d["value"], d["roofline"]["frac"], d["index_build"]["ms"], d["index_build"]["reverse_index"]["ms"], d["read_mapping"]["kmers_per_s"], d["early_stop_search"]["start_positions_per_s"]))
+print("bench: %.2f ms/step, %.3g k-mers/s, roofline frac %.3f (of measured ceiling %.3f), index_build %.1f ms (reverse %.1f), full_index %.0f ms, read_mapping %.3g k-mers/s (%d reads), early_stop %.3g starts/s" % (
+    d["ms_per_step"], d["value"], d["roofline"]["frac"], d["roofline"]["frac_of_ceiling"], d["index_build"]["ms"], d["index_build"]["reverse_index"]["ms"], d["full_index"]["ms"], d["read_mapping"]["kmers_per_s"], d["read_mapping"]["reads"], d["early_stop_search"]["start_positions_per_s"]))
 rows = list(csv.DictReader(open(o + "/kernel_stats.csv")))
-keep = [r for r in rows if any(x in r["Name"] for x in ("k_radix", "k_gather_rows", "k_pack_rows", "k_frequencies", "k_directory", "k_bucket_keys", "k_probe", "k_get_small", "k_random_loads", "k_reverse", "k_forward"))]
+keep = [r for r in rows if any(x in r["Name"] for x in ("k_radix", "k_gather_rows", "k_pack_rows", "k_frequencies", "k_directory", "k_bucket_keys", "k_probe", "k_get_small", "k_random_loads", "k_reverse", "k_forward", "k_partition_rows", "k_group_", "k_digit_hist", "k_part_ids", "k_simulate_reads", "k_store_columns", "k_walk_", "k_cls_"))]
 with open(o + "/index_kernel_stats.csv", "w", newline="") as fh:
     w = csv.DictWriter(fh, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(keep)
 for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:8]:

@@ -4,6 +4,7 @@ passes).  usage: python tools/make_pmc_profile.py <collect_pmc outdir> <out.json
 Applies the gfx950 correction of MI355X_MICROARCH.md (section HBM): FETCH_SIZE reports wide coalesced streaming reads at
 half their bytes, so it is doubled; WRITE_SIZE is taken as is."""
 import json
+import os
 import re
 import sys
 
@@ -25,6 +26,7 @@ def bytes_of(k):
 
 
 out = {
+    "commit": os.environ.get("GKI_COMMIT", "unknown"),      # the source tree the counters were taken from (set by the caller)
     "command": "tools/collect_pmc.sh %s --steps 2 --warmup 1 --reads 0   (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in "
                "separate passes, python3 bench.py default 3 Gbp workload)" % src,
     "units": "per_launch_avg_KB: counter value per launch in KiB as rocprofv3 reports it",
