@@ -675,6 +675,8 @@ def main():
                     "(0: skip the secondary records)")
     ap.add_argument("--no-full-index", action="store_true", help="skip the full_index record (N=1)")
     ap.add_argument("--no-sharded-build", action="store_true", help="skip the sharded_build record (N>1)")
+    ap.add_argument("--sharded-build-budget", type=float, default=600.0, help="seconds the sharded_build record may take before "
+                    "rank 0 prints the line without it")
     ap.add_argument("--modulo", type=int, default=452930477)
     args = ap.parse_args()
     if args.nested > 0:
@@ -778,10 +780,7 @@ def main():
     if world == 1 and args.reads > 0 and plain and out.n - n_interior > 0:
         secondary = secondary_records(lib, _lib, g, k, cp, finder, out, int(args.reads), cpu2, args.max_variant_nodes,
                                       not args.no_full_index, args.modulo)
-    sharded = None
-    if world > 1 and plain and not args.no_sharded_build:
-        sharded = sharded_build_record(lib, _lib, plane, finder, out, args.modulo, same_device_ranks)
-
+    res = None
     if rank == 0:
         ms_step = 1000.0 * elapsed / args.steps
         value = n_total * args.steps / elapsed
@@ -817,11 +816,34 @@ def main():
             res["verify"] = checks
         if secondary is not None:
             res["index_build"], res["read_mapping"], res["early_stop_search"], res["full_index"] = secondary
-        if sharded is not None:
-            res["sharded_build"] = sharded
         res["cpu_baseline"] = cpu
+    if world > 1 and plain and not args.no_sharded_build:
+        # The exchange has never run between real GPUs (one GPU per builder box): if a rank fails or a collective never
+        # returns, the headline line must still come out.  A watchdog prints it (rank 0) and ends the rank.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                res["sharded_build"] = {"timed_out_after_s": args.sharded_build_budget}
+                print(json.dumps(res), flush=True)
+            os._exit(0 if rank == 0 else 3)
+        dog = threading.Timer(args.sharded_build_budget, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            sharded = sharded_build_record(lib, _lib, plane, finder, out, args.modulo, same_device_ranks)
+        except Exception as e:                        # noqa: BLE001 -- reported in the line, the step's numbers stand
+            sharded = {"failed": "%s: %s" % (type(e).__name__, e)}
+            log("rank %d: sharded_build failed: %s" % (rank, sharded["failed"]))
+        dog.cancel()
+        if rank == 0:
+            res["sharded_build"] = sharded
+    if rank == 0:
         print(json.dumps(res), flush=True)
-    plane.barrier()
+    try:
+        plane.barrier()
+    except (OSError, ConnectionError):                # a rank that gave up above: the line is out, nothing left to agree on
+        pass
     plane.close()
     if cleanup_dir:
         shutil.rmtree(cleanup_dir, ignore_errors=True)

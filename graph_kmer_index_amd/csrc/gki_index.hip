@@ -882,7 +882,9 @@ __global__ __launch_bounds__(64) void k_get_small(IndexDev ix, SmallStage *st, i
     if (lane == 0) st->n_hits[qi] = total;
 }
 std::mutex g_small_mu;
-SmallStage *g_small_host = nullptr, *g_small_dev = nullptr;
+SmallStage *g_small_host = nullptr;         // pinned + portable: every device maps it; its device address is asked for per call.
+                                            // 0.5 MB for the life of the process: freeing it from a static destructor would call
+                                            // into a HIP runtime that may already be gone
 }  // namespace
 
 extern "C" int gki_index_get_small(const gki_index_view *ix, const uint64_t *h_queries, int q, int64_t max_hits,
@@ -891,10 +893,9 @@ extern "C" int gki_index_get_small(const gki_index_view *ix, const uint64_t *h_q
     if (capacity_per_query < 0) return gki_set_error(GKI_ERR_BAD_ARG, "get_small: negative capacity");
     if (q == 0) return GKI_OK;
     std::lock_guard<std::mutex> lock(g_small_mu);
-    if (!g_small_host) {
-        HIP_TRY(hipHostMalloc((void **)&g_small_host, sizeof(SmallStage), hipHostMallocMapped));
-        HIP_TRY(hipHostGetDevicePointer((void **)&g_small_dev, g_small_host, 0));
-    }
+    if (!g_small_host) HIP_TRY(hipHostMalloc((void **)&g_small_host, sizeof(SmallStage), hipHostMallocMapped | hipHostMallocPortable));
+    SmallStage *g_small_dev = nullptr;              // the mapping of the device that is current NOW (a process may switch devices)
+    HIP_TRY(hipHostGetDevicePointer((void **)&g_small_dev, g_small_host, 0));
     for (int i = 0; i < q; i++) g_small_host->query[i] = h_queries[i];
     hipLaunchKernelGGL(k_get_small, dim3((unsigned)q), dim3(64), 0, 0, view_of(ix), g_small_dev, max_hits);
     HIP_TRY(hipGetLastError());
