@@ -299,12 +299,12 @@ def secondary_records(lib, _lib, g, k, cp, finder, out, n_reads, cpu2, max_varia
         pool1 = _lib.pool_stats()
     kb = int(modulo - 1).bit_length()
     # algorithmic bytes of the build as implemented (csrc/gki_index_rows.hip), per record: bucket keys 8 R + 4 W; two
-    # partition passes on the top 18 bits, each 4 R (histogram) + 28 R + 28 W (24-byte row + key); group bounds 4 R;
+    # partition passes on the top 19 bits, each 4 R (histogram) + 28 R + 28 W (24-byte row + key); group bounds 4 R;
     # finish 28 R + 26 W (four columns + frequency); plus the directory itself, 2 x 4 B x modulo, streamed once
     per_record = 12 + 2 * 60 + 4 + 54
     moved = per_record * nb + 8 * modulo
     index_build = {"records": int(nb), "ms": 1e3 * dt, "records_per_s": nb / dt, "modulo": modulo, "key_bits": kb,
-                   "form": "row-carrying: 2 stable partition passes (9 + 9 bits) + in-LDS finish on 11 bits",
+                   "form": "row-carrying: 2 stable partition passes (10 + 9 bits) + in-LDS finish on 10 bits",
                    "frequencies": True, "bytes_moved_model": int(moved), "bytes_per_record_model": per_record,
                    "achieved_GBps": moved / dt / 1e9, "frac_of_hbm_peak": moved / dt / 1e9 / HBM_PEAK_GBS,
                    "timed": "wall clock around DeviceIndex.build incl. its allocations, device synchronised",

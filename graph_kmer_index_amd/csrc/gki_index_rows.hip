@@ -10,8 +10,8 @@
 //     k_digit_hist                  per-tile digit histogram                                  4 R
 //     scan                          bin-major exclusive scan -> first row of every (digit, tile) run
 //     k_partition_rows              rows (or the four input columns) + keys -> rows + keys    28 R + 28 W
-//   k_group_bounds / k_group_scan   first row / row count of every group (= key >> L)         4 R
-//   k_group_finish                  one workgroup per group: counting sort on the low L bits in LDS, the directory of
+//   k_group_bounds / k_group_scan   first row / row count of every group (= key >> L, L <= 10) 4 R
+//   k_group_finish                  one workgroup per group: counting sort on the low L (<= 10) bits in LDS, the directory of
 //                                   the group's 2^L buckets (streamed, no memset + scatter), frequencies, and the
 //                                   four output columns + frequency column, all coalesced      28 R + 26 W + 8 B/bucket
 //   k_group_large                   a group with more rows than LDS holds: one workgroup streams it (count, scan,
@@ -29,9 +29,22 @@ namespace {
 
 constexpr int MAXB_BITS = 10;
 constexpr int MAXB = 1 << MAXB_BITS;          // digits of one partition pass
-constexpr int GROUP_CAP = 2048;               // rows a group may hold to be finished in LDS
-constexpr int GROUP_LMAX = 11;                // low key bits resolved in LDS
-constexpr int GROUP_THREADS = 512;
+// Shape of the finish: 1024 rows and 2^10 buckets per group, 512 threads -- 38 KB of LDS, four workgroups (32 waves) per CU.
+// Measured against 2048 rows / 2^11 buckets (two workgroups per CU) on 3.1e8 records, same box: the finish 6.13 -> 4.49 ms,
+// the first partition pass (10 bits instead of 9: runs of 4 rows) 5.03 -> 5.75 ms, the build 19.05 -> 18.5 ms
+// (profiles/r03_index_group_shape_ab.txt).
+#ifndef GKI_GROUP_CAP
+#define GKI_GROUP_CAP 1024
+#endif
+#ifndef GKI_GROUP_LMAX
+#define GKI_GROUP_LMAX 10
+#endif
+#ifndef GKI_GROUP_THREADS
+#define GKI_GROUP_THREADS 512
+#endif
+constexpr int GROUP_CAP = GKI_GROUP_CAP;          // rows a group may hold to be finished in LDS
+constexpr int GROUP_LMAX = GKI_GROUP_LMAX;        // low key bits resolved in LDS
+constexpr int GROUP_THREADS = GKI_GROUP_THREADS;
 constexpr int SMALL_BUCKET = 24;              // as in gki_index.hip: buckets up to this size count frequencies per lane
 
 struct PartArgs {
@@ -620,7 +633,8 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
         const uint32_t *cur_keys = keys[0];
         int shift = L;
         for (int p = 0; p < n_pass; p++) {
-            const int bits = (top - (shift - L) + (n_pass - p) - 1) / (n_pass - p);       // remaining bits spread evenly
+            const int bits = (top - (shift - L) + (n_pass - p) - 1) / (n_pass - p);       // remaining bits spread evenly (an odd bit
+                                                                                           // first or last: no difference measured)
             const int64_t bins_n = ((int64_t)1 << bits) * n_tiles;
             if (p == 0)
                 hipLaunchKernelGGL((k_bucket_keys_hist<THREADS, RI>), dim3((unsigned)n_tiles), dim3(THREADS), 0, s, (const uint64_t *)d_kmers,
