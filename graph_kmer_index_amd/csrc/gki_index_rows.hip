@@ -27,7 +27,10 @@ int gki_frequencies_for_rows(const int64_t *d_row_begin, const int64_t *d_row_en
 
 namespace {
 
-constexpr int MAXB_BITS = 10;
+#ifndef GKI_MAXB_BITS
+#define GKI_MAXB_BITS 10
+#endif
+constexpr int MAXB_BITS = GKI_MAXB_BITS;
 constexpr int MAXB = 1 << MAXB_BITS;          // digits of one partition pass
 // Shape of the finish: 1024 rows and 2^10 buckets per group, 512 threads -- 38 KB of LDS, four workgroups (32 waves) per CU.
 // Measured against 2048 rows / 2^11 buckets (two workgroups per CU) on 3.1e8 records, same box: the finish 6.13 -> 4.49 ms,
