@@ -520,18 +520,23 @@ template <> struct MafOf<1> { typedef double T; };           // get_flat_kmers(v
 
 template <bool ALL> struct IdxOf { typedef int64_t T; };
 template <> struct IdxOf<true> { typedef uint32_t T; };
+#ifdef GKI_EMIT_SLIM
+constexpr bool EMIT_SLIM = true;     // one-node mode too: per-lane facts shuffled, 32-bit slots, no flag words -> 32 KB, 5 workgroups per CU
+#else
+constexpr bool EMIT_SLIM = false;
+#endif
 
 template <int FMT, bool ALL>
 struct EvQueue {
     // per node of the group in progress (lane l walks node base + l).  All-nodes mode leaves these three in the
     // walking lane's registers and shuffles them at expansion time; with the 32-bit record slots, the node lists cut to
     // five and no `mn` that is 3.2 KB per wave less LDS: 40.7 KB per workgroup, a fourth workgroup per CU.
-    uint64_t own[ALL ? 1 : 64];  // the node's first k-1 bases
-    int64_t pos0[ALL ? 1 : 64];  // position id of (node, 0)
-    int32_t n[ALL ? 1 : 64];
+    uint64_t own[(ALL || EMIT_SLIM) ? 1 : 64];  // the node's first k-1 bases
+    int64_t pos0[(ALL || EMIT_SLIM) ? 1 : 64];  // position id of (node, 0)
+    int32_t n[(ALL || EMIT_SLIM) ? 1 : 64];
     // per queued step
     uint64_t ctx[EVQ];
-    typename IdxOf<ALL>::T idx[EVQ];   // first record slot of the step (all-nodes mode: relative to the node group's first)
+    typename IdxOf<ALL || EMIT_SLIM>::T idx[EVQ];   // first record slot of the step (all-nodes mode: relative to the node group's first)
     typename MafOf<FMT>::T maf[EVQ];
     int32_t mn[ALL ? 1 : EVQ];
     uint8_t order[EVQ];          // slot of the step at position p of the output order
@@ -633,8 +638,28 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
     for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(ps, d, 64); if (lane >= d) ps += t; }
     if (lane < MW) q.wrank[lane] = (uint16_t)(ps - pc);
     __builtin_amdgcn_wave_barrier();
-    const int shift = ALL ? 0 : (int)(mn_idx & 15);
-    if (!ALL) {
+    const int shift = ALL ? 0 : (int)((mn_idx + idx_base) & 15);
+    if (!ALL && EMIT_SLIM) {
+        for (int r0 = -shift; r0 < T; r0 += 64) {
+            const int r = r0 + lane;
+            const bool valid = r >= 0 && r < T;
+            int e = 0, j = 0, o = 0, ln = 0;
+            if (valid) {
+                const int w = r >> 6;
+                const int sp = (int)q.wrank[w] + __popcll(q.marks[w] & ((2ull << (r & 63)) - 1ull)) - 1;
+                e = (int)q.order[sp];
+                j = r - (int)q.pre[sp];
+                o = q.from[e] + j; ln = q.ln[e];
+            }
+            const uint64_t own_v = (uint64_t)__shfl((unsigned long long)own_reg, ln, 64);
+            const int64_t pos0_v = (int64_t)__shfl((long long)pos0_reg, ln, 64);
+            const int32_t n_v = __shfl(n_reg, ln, 64);
+            if (valid) {
+                const uint64_t h = ((q.ctx[e] >> (2 * o)) | (own_v << (2 * (k - 1 - o)))) & kmask;
+                put(out, idx_base + (int64_t)q.idx[e] + j, h, q.mn[e], n_v, o, pos0_v + o, (double)q.maf[e]);
+            }
+        }
+    } else if (!ALL) {
         for (int r0 = -shift; r0 < T; r0 += 64) {
             const int r = r0 + lane;
             if (r >= 0 && r < T) {
@@ -685,12 +710,12 @@ struct LevelEmit {               // a suspended level of the emit walk
 
 template <bool HAS_LOSSY, int FMT, bool ALL, bool GEN>
 // (general one-node variants in the flat layouts: LDS allows 4 workgroups per CU; without the request they take 129 VGPRs)
-__global__ __launch_bounds__(256, (GEN && !ALL && FMT != 1) ? 4 : 1) void k_emit_boundary_one(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
+__global__ __launch_bounds__(256, (EMIT_SLIM && !GEN && !ALL && !HAS_LOSSY && FMT != 1) ? 5 : (GEN && !ALL && FMT != 1) ? 4 : 1) void k_emit_boundary_one(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
                                                            const uint32_t *__restrict__ bcount,
                                                            const int64_t *__restrict__ rec_base,
                                                            const int64_t *__restrict__ bnd_shift,
                                                            typename OutSel<FMT>::T out, int *__restrict__ err) {
-    typedef WalkCacheT<!ALL || GEN || HAS_LOSSY> WCache;      // the flag words only where they are read (or LDS is not the limit)
+    typedef WalkCacheT<(!ALL && !EMIT_SLIM) || GEN || HAS_LOSSY> WCache;      // the flag words only where they are read (or LDS is not the limit)
     __shared__ EvQueue<FMT, ALL> s_q[4];
     __shared__ WCache s_wc[4];
     LevelEmit below[MAXN];
@@ -712,7 +737,7 @@ __global__ __launch_bounds__(256, (GEN && !ALL && FMT != 1) ? 4 : 1) void k_emit
     int n_ev = 0, my_cnt = 0;              // steps in the queue; of them, queued by this lane
     for (int64_t base = a.n0 + (int64_t)blockIdx.x * blockDim.x + wib * 64; base < a.n1; base += n_threads) {
         int64_t idx_base = 0;              // all-nodes mode: queued record slots are 32-bit offsets from the group's first
-        if (ALL) {
+        if (ALL || EMIT_SLIM) {
             const int64_t last = base + 64 < a.n1 ? base + 64 : a.n1;
             idx_base = rec_base[base] + *bnd_shift;
             if (rec_base[last] - rec_base[base] > 0xFFFFFFFFll) { gki_raise(err, GKI_ERR_WINDOW_TOO_DEEP); continue; }
@@ -755,7 +780,7 @@ __global__ __launch_bounds__(256, (GEN && !ALL && FMT != 1) ? 4 : 1) void k_emit
                     t_mn = (int32_t)n; t_maf = FMT == 1 ? g.allele_freq[n] : (double)wn.af;   // float32 rounding is monotonic:
                     // the minimum of the rounded values is the rounded minimum (flat layout), v2 keeps float64
                     own = gki_extract(g.seq2, wn.seq_start, hi);
-                    if (!ALL) { q.own[lane] = own; q.pos0[lane] = pos0; q.n[lane] = (int32_t)n; }
+                    if (!ALL && !EMIT_SLIM) { q.own[lane] = own; q.pos0[lane] = pos0; q.n[lane] = (int32_t)n; }
                     if (ALL || GEN) path[0] = (int32_t)n;
                     t_a = nonfree0 ? v0 : 0;
                     L = 1;
@@ -903,7 +928,7 @@ __global__ __launch_bounds__(256, (GEN && !ALL && FMT != 1) ? 4 : 1) void k_emit
                 if (ev) {
                     const int slot = n_ev + __popcll(pending & lt_mask);
                     q.ln[slot] = (uint8_t)lane; q.seq[slot] = (uint8_t)my_cnt++;
-                    q.ctx[slot] = e_ctx; q.idx[slot] = (typename IdxOf<ALL>::T)(idx - idx_base);
+                    q.ctx[slot] = e_ctx; q.idx[slot] = (typename IdxOf<ALL || EMIT_SLIM>::T)(idx - idx_base);
                     q.maf[slot] = (typename MafOf<FMT>::T)e_maf;
                     if (!ALL) q.mn[slot] = e_mn;
                     q.from[slot] = (uint8_t)e_from; q.cnt[slot] = (uint8_t)(e_to - e_from);
