@@ -541,7 +541,8 @@ struct EvQueue {
     int32_t mn[ALL ? 1 : EVQ];
     uint8_t order[EVQ];          // slot of the step at position p of the output order
     uint8_t ln[EVQ], seq[EVQ];   // the lane (node) that queued the step, and its number among that lane's queued steps
-    uint8_t lbase[64];           // output position of a lane's first queued step
+    alignas(8) uint8_t lbase[64];   // output position of a lane's first queued step (all-nodes mode: reused by the expansion as
+                                    // eight 64-bit words of record-start marks once the output order is known)
     uint8_t from[EVQ], cnt[EVQ];
     uint8_t nl[ALL ? EVQ : 1];                 // all-nodes mode: number of distinct window nodes of the step ...
     int32_t nodes[ALL ? EVQ : 1][NLQ];         // ... and the nodes, ascending (np.unique, kmer_finder.py:134)
@@ -690,6 +691,52 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
             const uint64_t own_v = (uint64_t)__shfl((unsigned long long)own_reg, ln, 64);
             const int64_t pos0_v = (int64_t)__shfl((long long)pos0_reg, ln, 64);
             const int32_t n_v = __shfl(n_reg, ln, 64);
+#ifndef GKI_ALL_LANE_PER_WINDOW
+            // One lane per RECORD: the trip's windows hold nl records each (1 .. NLQ); written by their window's lane in
+            // turn, neighbouring lanes store nl records apart and every line is touched by up to five store instructions
+            // (the expansion ran at 3.75 TB/s where one-node mode's, coalesced, reaches 5.7).  Here the trip's records are
+            // renumbered 0 .. R-1 (a wave scan of nl), a small bitmap marks where each window's records start, and in
+            // sub-trips of 64 every lane takes one record: its window by popcount, the window's facts by shuffle from the
+            // lane that decoded it, its node from the queued list -- consecutive lanes, consecutive records.
+            uint64_t h = 0;
+            int nl = 0;
+            int64_t first = 0;
+            float maf32 = 0.f;
+            double maf64 = 0.0;
+            if (valid) {
+                h = ((q.ctx[e] >> (2 * o)) | (own_v << (2 * (k - 1 - o)))) & kmask;
+                nl = (int)q.nl[e];
+                first = idx_base + (int64_t)q.idx[e] + (int64_t)j * nl;
+                if (FMT == 1) maf64 = (double)q.maf[e]; else maf32 = (float)q.maf[e];
+            }
+            int incl = nl;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+            const int excl = incl - nl, R = __shfl(incl, 63, 64);
+            uint64_t *rmarks = reinterpret_cast<uint64_t *>(q.lbase);           // 8 words >= (64 * NLQ) / 64 = 5
+            static_assert(NLQ * 64 <= 8 * 64, "record marks of one trip fit the reused lbase words");
+            if (lane < 8) rmarks[lane] = 0ull;
+            __builtin_amdgcn_wave_barrier();
+            if (nl > 0) atomicOr(reinterpret_cast<unsigned int *>(rmarks) + (excl >> 5), 1u << (excl & 31));
+            __builtin_amdgcn_wave_barrier();
+            int before = 0;                                                     // windows that start in earlier sub-trips
+            for (int rr0 = 0; rr0 < R; rr0 += 64) {
+                const int rr = rr0 + lane;
+                const bool live = rr < R;
+                const uint64_t mw = rmarks[rr0 >> 6];                           // one word per sub-trip, the same for all lanes
+                const int owner = live ? before + __popcll(mw & ((2ull << lane) - 1ull)) - 1 : 0;
+                before += __popcll(mw);
+                const int t = rr - __shfl(excl, owner, 64);
+                const int e_o = __shfl(e, owner, 64), o_o = __shfl(o, owner, 64);
+                const uint64_t h_o = (uint64_t)__shfl((unsigned long long)h, owner, 64);
+                const int64_t first_o = (int64_t)__shfl((long long)first, owner, 64);
+                const int64_t pos0_o = (int64_t)__shfl((long long)pos0_v, owner, 64);
+                const int32_t n_o = __shfl(n_v, owner, 64);
+                const double maf_o = FMT == 1 ? __shfl(maf64, owner, 64) : (double)__shfl(maf32, owner, 64);
+                if (live) put(out, first_o + t, h_o, q.nodes[e_o][t], n_o, o_o, pos0_o + o_o, maf_o);
+            }
+            __builtin_amdgcn_wave_barrier();
+#else
             if (valid) {
                 const uint64_t h = ((q.ctx[e] >> (2 * o)) | (own_v << (2 * (k - 1 - o)))) & kmask;
                 const int nl = (int)q.nl[e];
@@ -697,6 +744,7 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
                 for (int t = 0; t < nl; t++)
                     put(out, first + t, h, q.nodes[e][t], n_v, o, pos0_v + o, (double)q.maf[e]);
             }
+#endif
         }
     }
 }
