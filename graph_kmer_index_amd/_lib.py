@@ -107,6 +107,7 @@ SYMBOLS = {
     "gki_probe_reads_count_nodes": (_I32, [_P, _P, _P, _I64, _I32, _I32, _I64, _P, _I64, C.POINTER(_I64), C.POINTER(_I64)]),
     "gki_measure_random_loads": (_I32, [_I64, _I64, C.POINTER(C.c_double)]),
     "gki_measure_store_bw": (_I32, [_P, _P, _P, _P, _I64, C.POINTER(C.c_double)]),
+    "gki_selftest_wave_scan": (_I32, [C.POINTER(_I64)]),
     "gki_simulate_reads": (_I32, [_P, _I64, _I64, _I32, _U64, C.c_double, C.c_double, _I64, _P]),
     "gki_comm_get_unique_id": (_I32, [_P]),
     "gki_comm_create": (_I32, [C.POINTER(_P), _I32, _I32, _P]),

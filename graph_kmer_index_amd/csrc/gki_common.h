@@ -126,6 +126,36 @@ static inline int gki_error_of_word(int64_t word) {
     return (word & 2) ? GKI_ERR_WINDOW_TOO_DEEP : (word & 1) ? GKI_ERR_NOT_ONE_REF_SUCC : GKI_OK;
 }
 
+// ---------------------------------------------------------------------------------- wave prefix sums (DPP)
+// Inclusive prefix sum over the 64 lanes of a wave on the data-parallel-primitive path: row shifts by 1, 2, 4, 8 inside
+// the four rows of 16 lanes (out-of-row sources read as zero), then lane 15 of a row broadcast into the next row and
+// lane 31 into the upper half -- six VALU additions.  The shuffle form (__shfl_up in a loop) compiles to six dependent
+// ds_bpermute_b32, i.e. six LDS round trips of ~100 cycles; the finder's expansion runs five such scans per queue and
+// one per trip in all-nodes mode -- 40 % of that kernel's LDS instructions.  Every lane of the wave must be active.
+// gki_selftest_wave_scan (gki_measure.hip) checks it against the shuffle form on the device.
+__device__ __forceinline__ int gki_wave_incl_sum(int x) {
+#ifdef GKI_SCAN_SHUFFLE                                                 // A/B builds: the shuffle form
+    const int lane_ = (int)(threadIdx.x & 63);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(x, d, 64); if (lane_ >= d) x += t; }
+    return x;
+#endif
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);     // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);     // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);     // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);     // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);    // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);    // row_bcast:31 into rows 2 and 3
+    return x;
+}
+__device__ __forceinline__ uint32_t gki_wave_incl_sum(uint32_t x) { return (uint32_t)gki_wave_incl_sum((int)x); }
+// the value lane `l` (a constant) holds, in a scalar register
+#ifdef GKI_TOTAL_SHUFFLE
+__device__ __forceinline__ int gki_lane_value(int x, int l) { return __shfl(x, l, 64); }
+#else
+__device__ __forceinline__ int gki_lane_value(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+#endif
+
 // ---------------------------------------------------------------------------------- exclusive scan
 // out[0..n] (n+1 entries), out[n] = total.  Three launches: block sums, scan of block sums, rescan.
 int gki_scan_u32_to_i64(const uint32_t *d_in, int64_t n, int64_t *d_out, void *d_tmp, int64_t tmp_bytes,

@@ -60,32 +60,49 @@ template <> struct OutSel<0> { typedef OutFlat T; };
 template <> struct OutSel<1> { typedef OutV2 T; };
 template <> struct OutSel<2> { typedef OutFlatAll T; };
 
+// The boundary kernels' records leave with the non-temporal hint (global_store ... nt): they are written once and read by
+// a later kernel, while the walk between two expansions re-reads what L2 holds for it -- graph records, predecessor
+// lists, the lanes' scratch.  With plain stores 7-22 GB of records stream through the 4 MB L2 of each XCD per launch and
+// push those lines out: measured with the stores folded onto a few L2-resident lines the kernels' compute takes 2.1 ms
+// (one-node) / 5.5 ms (all-nodes), and the real stores ADD their whole transfer time at the store ceiling instead of
+// hiding under it.  Same-box A/B (profiles/r03_boundary_nt_stores_ab.txt): one-node 2.69 -> 2.43 ms, all-nodes
+// 7.28 -> 6.61 ms, and the count pass that follows 0.587 -> 0.566 ms.  (The interior kernels, which re-read nothing,
+// were 7 % slower with the hint: DESIGN.md 4.1.)  put<false> = plain stores;
+// GKI_BND_PLAIN_STORES builds the plain-store form of everything for the A/B.
+#ifdef GKI_BND_PLAIN_STORES
+template <bool NT, class T> __device__ __forceinline__ void st(T *p, T v) { *p = v; }
+#else
+template <bool NT, class T> __device__ __forceinline__ void st(T *p, T v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+#endif
+template <bool NT = true>
 __device__ __forceinline__ void put(const OutFlat &o, int64_t idx, uint64_t h, int32_t node, int32_t end_node,
                                     int32_t end_off, int64_t pos_id, double af) {
     (void)end_node; (void)end_off;
-    if (o.hash) o.hash[idx] = h;
-    if (o.node) o.node[idx] = (uint32_t)node;
-    if (o.ref_offset) o.ref_offset[idx] = (uint64_t)pos_id;
-    if (o.af) o.af[idx] = (float)af;
+    if (o.hash) st<NT>(&o.hash[idx], h);
+    if (o.node) st<NT>(&o.node[idx], (uint32_t)node);
+    if (o.ref_offset) st<NT>(&o.ref_offset[idx], (uint64_t)pos_id);
+    if (o.af) st<NT>(&o.af[idx], (float)af);
 }
 // No null checks: on gfx950 a branch between two stores makes the compiler drain the first one (vmcnt counts
 // stores, in order), which turns four back-to-back column stores into four serialized round trips.
+template <bool NT = true>
 __device__ __forceinline__ void put(const OutFlatAll &o, int64_t idx, uint64_t h, int32_t node, int32_t end_node,
                                     int32_t end_off, int64_t pos_id, double af) {
     (void)end_node; (void)end_off;
-    o.hash[idx] = h;
-    o.node[idx] = (uint32_t)node;
-    o.ref_offset[idx] = (uint64_t)pos_id;
-    o.af[idx] = (float)af;
+    st<NT>(&o.hash[idx], h);
+    st<NT>(&o.node[idx], (uint32_t)node);
+    st<NT>(&o.ref_offset[idx], (uint64_t)pos_id);
+    st<NT>(&o.af[idx], (float)af);
 }
+template <bool NT = true>
 __device__ __forceinline__ void put(const OutV2 &o, int64_t idx, uint64_t h, int32_t node, int32_t end_node,
                                     int32_t end_off, int64_t pos_id, double af) {
     (void)pos_id;
-    if (o.hash) o.hash[idx] = (int64_t)h;
-    if (o.start_node) o.start_node[idx] = end_node;
-    if (o.start_offset) o.start_offset[idx] = (int16_t)end_off;
-    if (o.node) o.node[idx] = node;
-    if (o.af) o.af[idx] = af;
+    if (o.hash) st<NT>(&o.hash[idx], (int64_t)h);
+    if (o.start_node) st<NT>(&o.start_node[idx], end_node);
+    if (o.start_offset) st<NT>(&o.start_offset[idx], (int16_t)end_off);
+    if (o.node) st<NT>(&o.node[idx], node);
+    if (o.af) st<NT>(&o.af[idx], af);
 }
 
 // SURVEY.md 8a' E1: a restart at a critical point (N, c) with 0 < c < k-1 is not rewound
@@ -556,9 +573,13 @@ struct EvQueue {
 __device__ int g_dbg_skip_expand = 0;     // tools/exp builds only (make tuning): 1 = phase A alone (the walk, no expansion),
                                           // 3 = phase A alone and no node lists built (all-nodes mode; nothing reads them)
                                           // 4 = phase A alone and windows over more than NLQ nodes dropped (output incomplete)
+                                          // 5 = walk and expansion, the expansion's stores folded onto 16 384 record slots: the same
+                                          //     instructions, but the lines stay in L2 and nothing drains to memory (output wrong)
 #define GKI_DBG_SKIP_EXPAND_IS(v) (g_dbg_skip_expand == (v))
+#define GKI_DBG_SLOT(i) (g_dbg_skip_expand == 5 ? ((i) & 0x3FFF) : (i))
 #else
 #define GKI_DBG_SKIP_EXPAND_IS(v) false
+#define GKI_DBG_SLOT(i) (i)
 #endif
 
 // Expansion writes the queued steps in OUTPUT order.  Steps arrive in walk order, i.e. interleaved across the 64
@@ -574,9 +595,7 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
                                              int32_t n_reg = 0, int64_t idx_base = 0) {
     if (GKI_DBG_SKIP_EXPAND_IS(1) || GKI_DBG_SKIP_EXPAND_IS(3) || GKI_DBG_SKIP_EXPAND_IS(4)) return;
     {
-        int ps = my_cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(ps, d, 64); if (lane >= d) ps += t; }
+        const int ps = gki_wave_incl_sum(my_cnt);
         q.lbase[lane] = (uint8_t)(ps - my_cnt);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -616,14 +635,9 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
     // write `nl` records apart and the following turns fill the gaps while the lines are still in L2).
     const int c0 = lane < n_ev ? (int)q.cnt[q.order[lane]] : 0;
     const int c1 = lane + 64 < n_ev ? (int)q.cnt[q.order[lane + 64]] : 0;
-    int s0 = c0, s1 = c1;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t0 = __shfl_up(s0, d, 64), t1 = __shfl_up(s1, d, 64);
-        if (lane >= d) { s0 += t0; s1 += t1; }
-    }
-    const int tot0 = __shfl(s0, 63, 64);
-    const int T = tot0 + __shfl(s1, 63, 64);
+    const int s0 = gki_wave_incl_sum(c0), s1 = gki_wave_incl_sum(c1);
+    const int tot0 = gki_lane_value(s0, 63);
+    const int T = tot0 + gki_lane_value(s1, 63);
     const int ex0 = s0 - c0, ex1 = tot0 + s1 - c1;
     q.pre[lane] = (uint16_t)ex0;
     if (lane + 64 < EVQ) q.pre[lane + 64] = (uint16_t)ex1;
@@ -634,9 +648,7 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
     if (c1) atomicOr(&marks32[ex1 >> 5], 1u << (ex1 & 31));
     __builtin_amdgcn_wave_barrier();
     const int pc = lane < MW ? __popcll(q.marks[lane]) : 0;
-    int ps = pc;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(ps, d, 64); if (lane >= d) ps += t; }
+    const int ps = gki_wave_incl_sum(pc);
     if (lane < MW) q.wrank[lane] = (uint16_t)(ps - pc);
     __builtin_amdgcn_wave_barrier();
     const int shift = ALL ? 0 : (int)((mn_idx + idx_base) & 15);
@@ -670,7 +682,7 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
                 const int j = r - (int)q.pre[sp];
                 const int o = q.from[e] + j, ln = q.ln[e];
                 const uint64_t h = ((q.ctx[e] >> (2 * o)) | (q.own[ln] << (2 * (k - 1 - o)))) & kmask;
-                put(out, (int64_t)q.idx[e] + j, h, q.mn[e], q.n[ln], o, q.pos0[ln] + o, (double)q.maf[e]);
+                put(out, GKI_DBG_SLOT((int64_t)q.idx[e] + j), h, q.mn[e], q.n[ln], o, q.pos0[ln] + o, (double)q.maf[e]);
             }
         }
     } else {
@@ -709,10 +721,8 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
                 first = idx_base + (int64_t)q.idx[e] + (int64_t)j * nl;
                 if (FMT == 1) maf64 = (double)q.maf[e]; else maf32 = (float)q.maf[e];
             }
-            int incl = nl;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-            const int excl = incl - nl, R = __shfl(incl, 63, 64);
+            const int incl = gki_wave_incl_sum(nl);
+            const int excl = incl - nl, R = gki_lane_value(incl, 63);
             uint64_t *rmarks = reinterpret_cast<uint64_t *>(q.lbase);           // 8 words >= (64 * NLQ) / 64 = 5
             static_assert(NLQ * 64 <= 8 * 64, "record marks of one trip fit the reused lbase words");
             if (lane < 8) rmarks[lane] = 0ull;
@@ -733,7 +743,7 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
                 const int64_t pos0_o = (int64_t)__shfl((long long)pos0_v, owner, 64);
                 const int32_t n_o = __shfl(n_v, owner, 64);
                 const double maf_o = FMT == 1 ? __shfl(maf64, owner, 64) : (double)__shfl(maf32, owner, 64);
-                if (live) put(out, first_o + t, h_o, q.nodes[e_o][t], n_o, o_o, pos0_o + o_o, maf_o);
+                if (live) put(out, GKI_DBG_SLOT(first_o + t), h_o, q.nodes[e_o][t], n_o, o_o, pos0_o + o_o, maf_o);
             }
             __builtin_amdgcn_wave_barrier();
 #else
@@ -1145,10 +1155,10 @@ __global__ __launch_bounds__(256) void k_emit_interior(DevGraph g, FindArgs a, c
         if (p < e.glo || p >= e.glo + e.cnt || p < p_begin || p >= p_end) continue;      // (glo = INT64_MAX, cnt = 0: not in the run)
         const uint64_t h = gki_extract(g.seq2, p - (k - 1), k);
         if (FMT == 0) {
-            put(out, p + e.D, h, e.node, e.node, 0, p + e.E, (double)e.af);
+            put<false>(out, p + e.D, h, e.node, e.node, 0, p + e.E, (double)e.af);
         } else {
             const int64_t o = p - g.seq_start[e.node];
-            put(out, p + e.D, h, e.node, e.node, (int32_t)o, 0, g.allele_freq[e.node]);   // v2 keeps float64 (:58)
+            put<false>(out, p + e.D, h, e.node, e.node, (int32_t)o, 0, g.allele_freq[e.node]);   // v2 keeps float64 (:58)
         }
     }
 }

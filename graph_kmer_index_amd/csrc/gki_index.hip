@@ -110,12 +110,7 @@ __global__ __launch_bounds__(RB) void k_radix_scatter(const uint32_t *__restrict
         wave_cnt[0][d] = 0; wave_cnt[1][d] = c0; wave_cnt[2][d] = c0 + c1; wave_cnt[3][d] = c0 + c1 + c2;
         const uint32_t tot = c0 + c1 + c2 + c3;
         // exclusive scan of tot over the 256 digits (4 waves of 64)
-        uint32_t inc = tot;
-#pragma unroll
-        for (int s = 1; s < 64; s <<= 1) {
-            uint32_t o = __shfl_up(inc, s, 64);
-            if (lane >= s) inc += o;
-        }
+        const uint32_t inc = gki_wave_incl_sum(tot);
         __shared__ uint32_t wsum[4];
         if (lane == 63) wsum[wave] = inc;
         __syncthreads();

@@ -91,12 +91,7 @@ __global__ __launch_bounds__(THREADS) void k_digit_hist(const uint32_t *__restri
 template <int THREADS>
 __device__ __forceinline__ uint32_t block_excl(uint32_t v, uint32_t *lds, uint32_t *total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        const uint32_t o = __shfl_up(inc, s, 64);
-        if (lane >= s) inc += o;
-    }
+    const uint32_t inc = gki_wave_incl_sum(v);
     if (lane == 63) lds[wave] = inc;
     __syncthreads();
     uint32_t woff = 0, tot = 0;

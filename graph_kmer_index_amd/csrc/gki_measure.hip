@@ -62,6 +62,21 @@ __global__ __launch_bounds__(256) void k_simulate_reads(const uint8_t *__restric
 
 }  // namespace
 
+// gki_wave_incl_sum (DPP) against the shuffle form, lane by lane, on pseudo-random and on extreme inputs
+__global__ __launch_bounds__(256) void k_selftest_wave_scan(uint64_t seed, int *__restrict__ n_bad) {
+    const int lane = threadIdx.x & 63;
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(blockIdx.x * blockDim.x + threadIdx.x + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    const int kind = blockIdx.x & 3;
+    const int x = kind == 0 ? (int)(z & 31) : kind == 1 ? (int)(z & 0xFFFFF) : kind == 2 ? ((z >> 7) & 1 ? 1 : 0) : (lane == (int)(seed & 63) ? 1000 : 0);
+    int ref = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(ref, d, 64); if (lane >= d) ref += t; }
+    const int got = gki_wave_incl_sum(x);
+    const int tot = gki_lane_value(got, 63);
+    if (got != ref || tot != __shfl(ref, 63, 64)) atomicAdd(n_bad, 1);
+}
+
 extern "C" {
 
 int gki_measure_store_bw(void *d_hashes, void *d_nodes, void *d_ref_offsets, void *d_af32, int64_t n, double *bytes_per_s) {
@@ -90,6 +105,22 @@ done:
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     return rc;
+}
+
+int gki_selftest_wave_scan(int64_t *n_bad) {
+    int *d_bad = nullptr;
+    int h_bad = -1;
+    HIP_TRY(hipMalloc(&d_bad, sizeof(int)));
+    hipError_t e = hipMemset(d_bad, 0, sizeof(int));
+    for (int rep = 0; rep < 4 && e == hipSuccess; rep++) {
+        hipLaunchKernelGGL(k_selftest_wave_scan, dim3(1024), dim3(256), 0, 0, (uint64_t)(0x1234567ull * (rep + 1) + rep * 17), d_bad);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipFree(d_bad);
+    if (e != hipSuccess) return gki_set_error(GKI_ERR_HIP, "selftest_wave_scan: %s", hipGetErrorString(e));
+    *n_bad = h_bad;
+    return GKI_OK;
 }
 
 int gki_simulate_reads(const void *d_haplotype, int64_t hap_len, int64_t n_reads, int read_len, uint64_t seed,

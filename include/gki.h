@@ -372,6 +372,9 @@ int gki_measure_random_loads(int64_t table_bytes, int64_t n_loads, double *loads
  * bytes; the caller's buffers, e.g. the output columns before a run) with nothing else in the kernel, three launches,
  * best of the last two; bytes_per_s = 24 n / time.  bench.py prints it beside the 8 TB/s spec peak. */
 int gki_measure_store_bw(void *d_hashes, void *d_nodes, void *d_ref_offsets, void *d_af32, int64_t n, double *bytes_per_s);
+/* Device self-test of the kernels' wave prefix sum (DPP row shifts and broadcasts, csrc/gki_common.h) against the shuffle
+ * form on random and extreme inputs: *n_bad = lanes that disagree (0 on a correct build).  No reference counterpart. */
+int gki_selftest_wave_scan(int64_t *n_bad);
 /* Read simulator on the device (benchmark input for BASELINE configs[4]): n_reads reads of read_len
  * letters (ASCII ACGT) sampled from a haplotype (uint8 codes 0..3 in HBM): uniform start, either strand, every base
  * substituted with p_substitution, a read replaced by uniform random letters with p_random_read.  Counter-based: read

@@ -125,3 +125,11 @@ def test_a_million_records_default_modulo_device_resident():
     _check(dev, o, n)
     dev.free()
     d.free()
+
+
+def test_wave_prefix_sum_on_the_dpp_path_equals_the_shuffle_form():
+    # csrc/gki_common.h gki_wave_incl_sum: used by the finder's expansion and by both index builds
+    import ctypes as C
+    bad = C.c_int64(-1)
+    _lib.check(_lib.load().gki_selftest_wave_scan(C.byref(bad)))
+    assert bad.value == 0

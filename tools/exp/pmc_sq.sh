@@ -8,7 +8,7 @@ B="SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ
 i=0
 for grp in "$A" "$B"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d "$R/gpurun_out/sq_${tag}_$i" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --reads 0 > "$R/gpurun_out/sq_${tag}_$i.json" 2> "$R/gpurun_out/sq_${tag}_$i.err" || echo "pass $i failed"
+  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d "$R/gpurun_out/sq_${tag}_$i" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --reads 0 "$@" > "$R/gpurun_out/sq_${tag}_$i.json" 2> "$R/gpurun_out/sq_${tag}_$i.err" || echo "pass $i failed"
 done
 cd "$R"
 python3 - "$tag" <<'PY'
@@ -19,7 +19,7 @@ for f in glob.glob("gpurun_out/sq_%s_*/*/*counter_collection.csv" % tag):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "k_emit_boundary_one" in k or "k_count_boundary" in k or "k_emit_interior_runs" in k:
-            acc[k.split("(")[0][-40:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            acc[k.replace("(anonymous namespace)::", "").split("(")[0][-48:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     print("==", tag, k)
     for c, v in sorted(d.items()):
