@@ -150,11 +150,7 @@ __device__ __forceinline__ int gki_wave_incl_sum(int x) {
 }
 __device__ __forceinline__ uint32_t gki_wave_incl_sum(uint32_t x) { return (uint32_t)gki_wave_incl_sum((int)x); }
 // the value lane `l` (a constant) holds, in a scalar register
-#ifdef GKI_TOTAL_SHUFFLE
-__device__ __forceinline__ int gki_lane_value(int x, int l) { return __shfl(x, l, 64); }
-#else
 __device__ __forceinline__ int gki_lane_value(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
-#endif
 
 // ---------------------------------------------------------------------------------- exclusive scan
 // out[0..n] (n+1 entries), out[n] = total.  Three launches: block sums, scan of block sums, rescan.

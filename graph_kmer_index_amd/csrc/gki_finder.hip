@@ -636,8 +636,11 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
     const int c0 = lane < n_ev ? (int)q.cnt[q.order[lane]] : 0;
     const int c1 = lane + 64 < n_ev ? (int)q.cnt[q.order[lane + 64]] : 0;
     const int s0 = gki_wave_incl_sum(c0), s1 = gki_wave_incl_sum(c1);
-    const int tot0 = gki_lane_value(s0, 63);
-    const int T = tot0 + gki_lane_value(s1, 63);
+    // (the totals: read into a scalar register in all-nodes mode, broadcast by shuffle otherwise -- measured, same box:
+    // the one-node kernel takes 2.51 ms with the scalar form and 2.22 ms with the shuffle, the all-nodes kernel 6.65 ms
+    // against 6.84 ms; profiles/r03_wave_scan_ab.txt)
+    const int tot0 = ALL ? gki_lane_value(s0, 63) : __shfl(s0, 63, 64);
+    const int T = tot0 + (ALL ? gki_lane_value(s1, 63) : __shfl(s1, 63, 64));
     const int ex0 = s0 - c0, ex1 = tot0 + s1 - c1;
     q.pre[lane] = (uint16_t)ex0;
     if (lane + 64 < EVQ) q.pre[lane + 64] = (uint16_t)ex1;
@@ -712,17 +715,19 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
             // lane that decoded it, its node from the queued list -- consecutive lanes, consecutive records.
             uint64_t h = 0;
             int nl = 0;
-            int64_t first = 0;
+            uint32_t first = 0;                                                 // slot of the window's first record, from idx_base
             float maf32 = 0.f;
             double maf64 = 0.0;
             if (valid) {
                 h = ((q.ctx[e] >> (2 * o)) | (own_v << (2 * (k - 1 - o)))) & kmask;
                 nl = (int)q.nl[e];
-                first = idx_base + (int64_t)q.idx[e] + (int64_t)j * nl;
+                first = q.idx[e] + (uint32_t)(j * nl);
                 if (FMT == 1) maf64 = (double)q.maf[e]; else maf32 = (float)q.maf[e];
             }
             const int incl = gki_wave_incl_sum(nl);
             const int excl = incl - nl, R = gki_lane_value(incl, 63);
+            const int packed = e | (o << 8) | (excl << 16);                     // what a record's lane wants of its window, one shuffle
+            static_assert(EVQ <= 256 && NLQ * 64 < 32768, "step slot, offset and record number share a word");
             uint64_t *rmarks = reinterpret_cast<uint64_t *>(q.lbase);           // 8 words >= (64 * NLQ) / 64 = 5
             static_assert(NLQ * 64 <= 8 * 64, "record marks of one trip fit the reused lbase words");
             if (lane < 8) rmarks[lane] = 0ull;
@@ -736,10 +741,10 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
                 const uint64_t mw = rmarks[rr0 >> 6];                           // one word per sub-trip, the same for all lanes
                 const int owner = live ? before + __popcll(mw & ((2ull << lane) - 1ull)) - 1 : 0;
                 before += __popcll(mw);
-                const int t = rr - __shfl(excl, owner, 64);
-                const int e_o = __shfl(e, owner, 64), o_o = __shfl(o, owner, 64);
+                const int packed_o = __shfl(packed, owner, 64);
+                const int e_o = packed_o & 0xFF, o_o = (packed_o >> 8) & 0xFF, t = rr - (packed_o >> 16);
                 const uint64_t h_o = (uint64_t)__shfl((unsigned long long)h, owner, 64);
-                const int64_t first_o = (int64_t)__shfl((long long)first, owner, 64);
+                const int64_t first_o = idx_base + (int64_t)(uint32_t)__shfl((int)first, owner, 64);
                 const int64_t pos0_o = (int64_t)__shfl((long long)pos0_v, owner, 64);
                 const int32_t n_o = __shfl(n_v, owner, 64);
                 const double maf_o = FMT == 1 ? __shfl(maf64, owner, 64) : (double)__shfl(maf32, owner, 64);
