@@ -122,8 +122,11 @@ struct gki_graph {
 __device__ __forceinline__ void gki_raise(int *err, int code) {
     atomicOr((unsigned int *)err, code == GKI_ERR_WINDOW_TOO_DEEP ? 2u : 1u);
 }
+// bit 2 = too deep for a reason no deeper stack cures (a history enumeration out of its step budget): the finder's
+// slow path (deep kernel variants, gki_finder_count) is not tried for it
+__device__ __forceinline__ void gki_raise_budget(int *err) { atomicOr((unsigned int *)err, 4u); }
 static inline int gki_error_of_word(int64_t word) {
-    return (word & 2) ? GKI_ERR_WINDOW_TOO_DEEP : (word & 1) ? GKI_ERR_NOT_ONE_REF_SUCC : GKI_OK;
+    return (word & 6) ? GKI_ERR_WINDOW_TOO_DEEP : (word & 1) ? GKI_ERR_NOT_ONE_REF_SUCC : GKI_OK;
 }
 
 // ---------------------------------------------------------------------------------- wave prefix sums (DPP)

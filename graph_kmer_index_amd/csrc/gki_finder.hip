@@ -255,10 +255,49 @@ __device__ __forceinline__ void interior_range(const FindArgs &a, int64_t n, int
 // the levels below it in (scratch) arrays: PMC showed the first version, with the whole stack in scratch, writing
 // 1.4 GB of spills in the count pass and ~5 GB in the emit pass of the 3 Gbp graph, and every step began with a
 // dependent scratch load.  Node facts come from one aligned 32-byte NodeWalk record per visited node.
-struct LevelLo {                 // what a suspended level needs to resume
+// Where the levels below the top live.  The product kernels keep MAXN of them per lane in scratch (LocalStack: a plain
+// array); a window over more than MAXN - 2 nodes -- sixteen or more EMPTY nodes inside one 31-base window -- makes them
+// raise GKI_ERR_WINDOW_TOO_DEEP, and gki_finder_count then runs the pass again with the DEEP instantiation of the same
+// kernels, whose stacks lie in a global-memory arena sized for the run (ArenaStack: level-major, lane-interleaved, so a
+// wave's accesses to one level coalesce; every lane reads only what it wrote).  Same walk, same arithmetic: the slow path
+// differs in where a level is stored, in counters wide enough for its depth, and in all-nodes mode in who writes a
+// many-node window (its lane alone).
+template <class T, int N> struct LocalStack {
+    T v[N];
+    __device__ __forceinline__ T &operator[](int i) { return v[i]; }
+    __device__ __forceinline__ const T &operator[](int i) const { return v[i]; }
+};
+template <class T> struct ArenaStack {
+    T *base; int64_t stride;
+    __device__ __forceinline__ T &operator[](int i) const { return base[(int64_t)i * stride]; }
+};
+struct DeepArena { char *base; int64_t lanes; int32_t cap; int32_t pad; };     // cap levels for each of `lanes` lanes
+// byte offset of every per-level array inside one (level, lane) cell of the arena
+enum { DA_BELOW = 0, DA_PATH = 40, DA_LVLA = 44, DA_CT = 46, DA_CM = 47, DA_HN = 49, DA_HCUR = 53, DA_HEND = 57, DA_HD = 61,
+       DA_HSZ = 65, DA_HF = 69, DA_CELL = 70 };
+template <class T> __device__ __forceinline__ ArenaStack<T> arena_stack(const DeepArena &da, int offset, int64_t lane_global) {
+    ArenaStack<T> st;
+    st.base = reinterpret_cast<T *>(da.base + (int64_t)da.cap * da.lanes * offset) + lane_global;
+    st.stride = da.lanes;
+    return st;
+}
+template <class T, int N, bool DEEP> struct StackOf { typedef LocalStack<T, N> type; };
+template <class T, int N> struct StackOf<T, N, true> { typedef ArenaStack<T> type; };
+template <class T, int N> __device__ __forceinline__ void bind(LocalStack<T, N> &, const DeepArena &, int, int64_t) {}
+template <class T> __device__ __forceinline__ void bind(ArenaStack<T> &st, const DeepArena &da, int offset, int64_t lane_global) {
+    st = arena_stack<T>(da, offset, lane_global);
+}
+template <class T, int N> __device__ __forceinline__ T *raw(LocalStack<T, N> &st) { return st.v; }
+template <class T> __device__ __forceinline__ ArenaStack<T> raw(const ArenaStack<T> &st) { return st; }
+template <bool DEEP> struct CountOf { typedef uint8_t T; };      // variant-node counters of a suspended level
+template <> struct CountOf<true> { typedef uint16_t T; };
+
+template <bool DEEP>
+struct LevelLoT {                // what a suspended level needs to resume
     int32_t cur, end;
-    uint8_t cum, vc;
-    uint8_t a;                   // general graphs: variant count at the first non-free node of the path (0: none yet)
+    uint8_t cum;
+    typename CountOf<DEEP>::T vc;
+    typename CountOf<DEEP>::T a; // general graphs: variant count at the first non-free node of the path (0: none yet)
 };
 
 // ------------------------------------------------------------------------------------ general graphs
@@ -273,23 +312,27 @@ struct LevelLo {                 // what a suspended level needs to resume
 // or in a node inside which every open constraint closes -- what is left then is "that node is entered at all", which
 // gki_classify_nodes settled on the host (GKI_NODE_DEAD is exact).
 constexpr int HMAX = 40;         // nodes of one enumerated history (k-1 one-base nodes + slack)
+// The number of paths into one end node has no bound: a run of s insertion sites inside one window has 2^s of them when
+// no variant limit cuts them (max_variant_nodes large) -- the reference does not return from such a graph either.  A lane
+// of the count kernels that has taken this many steps for ONE end node gives up and the run is refused
+// (GKI_ERR_WINDOW_TOO_DEEP, "too many paths"), so that no kernel runs for hours; the emit pass walks what the count pass
+// walked.  Only descents below level STEP_BUDGET_FROM are counted: every path of an exponential family goes that deep, the
+// walks of ordinary graphs (two to four levels) never do, and a decrement at every step cost the count pass of the 3 Gbp
+// graph 10 % (0.57 -> 0.63 ms).
+constexpr int STEP_BUDGET = 1 << 24, STEP_BUDGET_FROM = 8;
 
 // The graph arrays the enumeration reads, BY VALUE: with `const DevGraph &` the kernel's DevGraph escaped to memory for
 // this out-of-line call and every load through its pointers in the kernel itself became a FLAT load (address space
 // lost) -- which waits on the LDS counter as well as on the memory counter, in kernels full of LDS traffic.
 struct WalkSrc { const NodeWalk *walk; const int32_t *rev_edges; const int64_t *rev_start; };
-// (kernel variants without the flag words never run the general branch that calls history_ok; this overload only
-// lets that branch compile)
-__device__ __forceinline__ bool history_ok(const WalkSrc, const WalkCacheT<false> &, const WalkView &, const uint16_t *, int, int,
-                                           const int32_t *, int, int *) { return false; }
-__device__ __noinline__ bool history_ok(const WalkSrc gs, const WalkCache &wc, const WalkView &wv,
-                                        const uint16_t *__restrict__ nf, int k, int M, const int32_t *path, int L, int *err) {
+template <class P, class A8, class A16, class A32, class AU8>
+__device__ __forceinline__ bool history_ok_impl(const WalkSrc gs, const WalkCache &wc, const WalkView &wv,
+                                                const uint16_t *__restrict__ nf, int k, int M, P path, int L, int *err,
+                                                A8 ct, A16 cm, A32 hn, A32 hcur, A32 hend, A32 hd, A32 hsz, AU8 hf, int hmax) {
     DevGraph g = {};                       // only these three members are read below (helpers are inlined)
     g.walk = gs.walk; g.rev_edges = gs.rev_edges; g.rev_start = gs.rev_start;
     // open constraints of the window's nodes path[0..L] (end node .. q): the step into a non-free node y still sees
     // the history nodes within t bases of q's entry and tolerates fewer than m variant nodes among them
-    int8_t ct[MAXN];
-    int16_t cm[MAXN];
     int nc = 0;
     {
         int between = 0, c = 0;                  // bases / variant nodes of path[i+1..L]
@@ -307,19 +350,22 @@ __device__ __noinline__ bool history_ok(const WalkSrc gs, const WalkCache &wc, c
             c += (fy & GKI_NODE_REF) ? 0 : 1;
         }
     }
-    int32_t hn[HMAX], hcur[HMAX], hend[HMAX], hd[HMAX], hsz[HMAX];     // history nodes, nearest first; hd = bases nearer than the node
-    uint8_t hf[HMAX];
+    // (hn, hcur, hend, hd, hsz, hf: history nodes, nearest first; hd = bases nearer than the node)
     {
         const NodeWalk wq = cached_walk(g, wc, wv, path[L]);
-        preds_begin(g, wq, path[L], &hcur[0], &hend[0]);
+        int32_t c0, e0;
+        preds_begin(g, wq, path[L], &c0, &e0);
+        hcur[0] = c0; hend[0] = e0;
     }
     int h = 0;
     for (int budget = 1 << 16;; budget--) {
         // every lane's enumeration ends: a graph with more than 65 536 history steps behind one window is refused
         // (GKI_ERR_WINDOW_TOO_DEEP) rather than walked for minutes
-        if (budget == 0) { gki_raise(err, GKI_ERR_WINDOW_TOO_DEEP); return false; }
+        if (budget == 0) { gki_raise_budget(err); return false; }
         if (hcur[h] >= hend[h]) { if (h == 0) return false; h--; continue; }
-        const int32_t p = cached_preds_next(g, wc, wv, &hcur[h]);
+        int32_t cur_h = hcur[h];
+        const int32_t p = cached_preds_next(g, wc, wv, &cur_h);
+        hcur[h] = cur_h;
         const uint8_t fp = (uint8_t)cached_flag(nf, nullptr, wc, wv, p);
         if (fp & GKI_NODE_DEAD) continue;
         const int32_t child = h == 0 ? path[L] : hn[h - 1];
@@ -354,15 +400,43 @@ __device__ __noinline__ bool history_ok(const WalkSrc gs, const WalkCache &wc, c
             if (closed) return true;                              // p is not DEAD: some admissible history enters it
         }
         if (!(fp & GKI_NODE_NESTED)) continue;
-        if (h + 1 >= HMAX) { gki_raise(err, GKI_ERR_WINDOW_TOO_DEEP); return false; }
+        if (h + 1 >= hmax) { gki_raise(err, GKI_ERR_WINDOW_TOO_DEEP); return false; }
         h++;
-        preds_begin(g, wp, p, &hcur[h], &hend[h]);
+        {
+            int32_t c0, e0;
+            preds_begin(g, wp, p, &c0, &e0);
+            hcur[h] = c0; hend[h] = e0;
+        }
     }
+}
+// (kernel variants without the flag words never run the general branch that calls history_ok; this overload only
+// lets that branch compile)
+template <class P>
+__device__ __forceinline__ bool history_ok(const WalkSrc, const WalkCacheT<false> &, const WalkView &, const uint16_t *, int, int,
+                                           P, int, int *, const DeepArena &, int64_t) { return false; }
+__device__ __noinline__ bool history_ok(const WalkSrc gs, const WalkCache &wc, const WalkView &wv,
+                                        const uint16_t *__restrict__ nf, int k, int M, const int32_t *path, int L, int *err,
+                                        const DeepArena &, int64_t) {
+    int8_t ct[MAXN];
+    int16_t cm[MAXN];
+    int32_t hn[HMAX], hcur[HMAX], hend[HMAX], hd[HMAX], hsz[HMAX];
+    uint8_t hf[HMAX];
+    return history_ok_impl(gs, wc, wv, nf, k, M, path, L, err, ct, cm, hn, hcur, hend, hd, hsz, hf, HMAX);
+}
+__device__ __noinline__ bool history_ok(const WalkSrc gs, const WalkCache &wc, const WalkView &wv,
+                                        const uint16_t *__restrict__ nf, int k, int M, ArenaStack<int32_t> path, int L, int *err,
+                                        const DeepArena &da, int64_t lane_global) {
+    return history_ok_impl(gs, wc, wv, nf, k, M, path, L, err, arena_stack<int8_t>(da, DA_CT, lane_global),
+                           arena_stack<int16_t>(da, DA_CM, lane_global), arena_stack<int32_t>(da, DA_HN, lane_global),
+                           arena_stack<int32_t>(da, DA_HCUR, lane_global), arena_stack<int32_t>(da, DA_HEND, lane_global),
+                           arena_stack<int32_t>(da, DA_HD, lane_global), arena_stack<int32_t>(da, DA_HSZ, lane_global),
+                           arena_stack<uint8_t>(da, DA_HF, lane_global), da.cap);
 }
 
 // only_store_nodes (kmer_finder.py:145-154): records a window with nodes path[0..n_path) yields -- its smallest node
 // if that is in the set (only_save_one_node_per_kmer), else one per node in the set.
-__device__ __forceinline__ int stored_nodes(const uint8_t *__restrict__ store, const int32_t *path, int n_path, bool one_node) {
+template <class P>
+__device__ __forceinline__ int stored_nodes(const uint8_t *__restrict__ store, P path, int n_path, bool one_node) {
     if (one_node) {
         int32_t mn = path[0];
         for (int i = 1; i < n_path; i++) mn = path[i] < mn ? path[i] : mn;
@@ -377,14 +451,20 @@ __device__ __forceinline__ int stored_nodes(const uint8_t *__restrict__ store, c
 // needs 100 VGPRs unconstrained (4 waves per SIMD; the others 53-55 = 8) -- held to 64 it spills ~30 values around the
 // history_ok call and is still faster at every step: 1.27 / 1.11 / 0.99 / 0.95 / 0.94 ms at 4 / 5 / 6 / 7 / 8 waves on the
 // 3 Gbp SNP graph, 2.19 / 1.88 / 1.70 / 1.66 / 1.64 ms with 20 % nested sites (tools/exp/ab_libs.sh, same box).
-template <bool HAS_LOSSY, bool GEN>
-__global__ __launch_bounds__(256, GEN ? 8 : 1) void k_count_boundary(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
+template <bool HAS_LOSSY, bool GEN, bool DEEP = false>
+__global__ __launch_bounds__(256, (GEN && !DEEP) ? 8 : 1) void k_count_boundary(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
                                                         uint32_t *__restrict__ bcount, uint32_t *__restrict__ total,
-                                                        int *__restrict__ err) {
+                                                        int *__restrict__ err, DeepArena da) {
     __shared__ WalkCache s_wc[4];
-    LevelLo below[MAXN];
+    typedef LevelLoT<DEEP> LevelLo;
+    typedef typename CountOf<DEEP>::T cnt_t;
+    const int64_t lane_global = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (deep variant: the lane's column of the arena)
+    const int cap = DEEP ? da.cap : MAXN;
+    typename StackOf<LevelLo, MAXN, DEEP>::type below;
+    typename StackOf<int32_t, GEN ? MAXN : 1, DEEP>::type path;   // general graphs: the node of every level (level 0 = the end node)
+    bind(below, da, DA_BELOW, lane_global);
+    bind(path, da, DA_PATH, lane_global);
     LevelLo below0 = {0, 0, 0, 0, 0};  // the first suspended level stays in registers (SNP/indel graphs never go deeper)
-    int32_t path[GEN ? MAXN : 1];      // general graphs: the node of every level (level 0 = the end node)
     // levels 1 and 2 of `path` live in registers and reach scratch only right before the rare calls that read the array
     // (history_ok, stored_nodes): a scratch store at every step of the walk sits in front of the next load (in-order vmcnt)
     int32_t pr1 = 0, pr2 = 0;
@@ -431,10 +511,11 @@ __global__ __launch_bounds__(256, GEN ? 8 : 1) void k_count_boundary(DevGraph g,
                 int t_cum = 0, t_vc = v0, t_a = nonfree0 ? v0 : 0;
                 int L = 1;
                 if (GEN) path[0] = (int32_t)n;
+                int steps_left = STEP_BUDGET;
                 while (L > 0) {
                     if (t_cur >= t_end) {
                         L--;
-                        if (L > 0) { const LevelLo b = L == 1 ? below0 : below[L - 1]; t_cur = b.cur; t_end = b.end; t_cum = b.cum; t_vc = b.vc; t_a = b.a; }
+                        if (L > 0) { LevelLo b = below0; if (L != 1) b = below[L - 1]; t_cur = b.cur; t_end = b.end; t_cum = b.cum; t_vc = b.vc; t_a = b.a; }
                         continue;
                     }
                     const int32_t q = cached_preds_next(g, wc, wv, &t_cur);
@@ -453,7 +534,7 @@ __global__ __launch_bounds__(256, GEN ? 8 : 1) void k_count_boundary(DevGraph g,
                         aq = t_a ? t_a : ((fq & (GKI_NODE_REF | GKI_NODE_FORCED)) ? 0 : vq);
                         if (aq && vq - aq >= a.M) continue;
                     }
-                    if (L >= MAXN - 1) { gki_raise(err, GKI_ERR_WINDOW_TOO_DEEP); continue; }
+                    if (L >= cap - 1) { gki_raise(err, GKI_ERR_WINDOW_TOO_DEEP); continue; }
                     if (GEN) { if (L == 1) pr1 = q; else if (L == 2) pr2 = q; else path[L] = q; }
                     const int s = wq.size, c = t_cum;
                     bool deeper;
@@ -473,14 +554,14 @@ __global__ __launch_bounds__(256, GEN ? 8 : 1) void k_count_boundary(DevGraph g,
                         if (GEN && from < to) {
                             bool ok = true;                          // a history before the window's first node?
                             if (!(fq & (GKI_NODE_T | GKI_NODE_SIMPLE)))
-                                ok = (fq & GKI_NODE_NESTED) ? (vq + (int)(fq >> 8) < a.M || (path[1] = pr1, path[2] = pr2, history_ok(WalkSrc{g.walk, g.rev_edges, g.rev_start}, wc, wv, a.nflags, k, a.M, path, L, err))) : false;
+                                ok = (fq & GKI_NODE_NESTED) ? (vq + (int)(fq >> 8) < a.M || (path[1] = pr1, path[2] = pr2, history_ok(WalkSrc{g.walk, g.rev_edges, g.rev_start}, wc, wv, a.nflags, k, a.M, raw(path), L, err, da, lane_global))) : false;
                             if (ok && chk && from <= oc && oc < to && vq >= a.M) gki_raise(err, GKI_ERR_NOT_ONE_REF_SUCC);
                             if (!ok) to = from;
                         }
                         if (GEN && from < 0 && from < to) from = 0;      // offset -1 has no record
                         if (from < to) {
                             uint32_t per_window = a.one_node ? 1u : (uint32_t)(L + 1);
-                            if (GEN && a.store) { path[1] = pr1; path[2] = pr2; per_window = (uint32_t)stored_nodes(a.store, path, L + 1, a.one_node != 0); }
+                            if (GEN && a.store) { path[1] = pr1; path[2] = pr2; per_window = (uint32_t)stored_nodes(a.store, raw(path), L + 1, a.one_node != 0); }
                             count += (uint32_t)(to - from) * per_window;
                         }
                         // the graph ends before the window of oc is complete (graph start): the search saw what there is
@@ -489,11 +570,14 @@ __global__ __launch_bounds__(256, GEN ? 8 : 1) void k_count_boundary(DevGraph g,
                         new_cum = c + s;
                     }
                     if (deeper) {
-                        LevelLo b; b.cur = t_cur; b.end = t_end; b.cum = (uint8_t)t_cum; b.vc = (uint8_t)t_vc; b.a = (uint8_t)t_a;
+                        LevelLo b; b.cur = t_cur; b.end = t_end; b.cum = (uint8_t)t_cum; b.vc = (cnt_t)t_vc; b.a = (cnt_t)t_a;
                         if (L == 1) below0 = b; else below[L - 1] = b;
                         preds_begin(g, wq, q, &t_cur, &t_end);
                         t_cum = new_cum; t_vc = vq; t_a = aq;
                         L++;
+                        // (out of budget: the walk is wound up through its ordinary exit -- a second way out of the loop
+                        // cost the product kernel 13 %)
+                        if (L > STEP_BUDGET_FROM && --steps_left < 0) { gki_raise_budget(err); L = 1; t_cur = t_end = 0; }
                     }
                 }
             }
@@ -764,31 +848,42 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
     }
 }
 
-struct LevelEmit {               // a suspended level of the emit walk
+template <bool DEEP>
+struct LevelEmitT {              // a suspended level of the emit walk
     uint64_t ctx;
     double maf;
     int32_t cur, end, mn;
-    uint8_t cum, vc, evf, evt;
+    uint8_t cum, evf, evt;
+    typename CountOf<DEEP>::T vc;
 };
+static_assert(sizeof(LevelEmitT<false>) == 32 && sizeof(LevelEmitT<true>) <= DA_PATH - DA_BELOW && sizeof(LevelLoT<true>) <= DA_PATH - DA_BELOW,
+              "a level of the product kernels is 32 bytes; the deep variants' levels fit their arena cell");
 
-template <bool HAS_LOSSY, int FMT, bool ALL, bool GEN>
+template <bool HAS_LOSSY, int FMT, bool ALL, bool GEN, bool DEEP = false>
 // (general one-node variants in the flat layouts: LDS allows 4 workgroups per CU; without the request they take 129 VGPRs)
-__global__ __launch_bounds__(256, (EMIT_SLIM && !GEN && !ALL && !HAS_LOSSY && FMT != 1) ? 5 : (GEN && !ALL && FMT != 1) ? 4 : 1) void k_emit_boundary_one(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
+__global__ __launch_bounds__(256, (EMIT_SLIM && !GEN && !ALL && !HAS_LOSSY && FMT != 1) ? 5 : (GEN && !ALL && FMT != 1 && !DEEP) ? 4 : 1) void k_emit_boundary_one(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
                                                            const uint32_t *__restrict__ bcount,
                                                            const int64_t *__restrict__ rec_base,
                                                            const int64_t *__restrict__ bnd_shift,
-                                                           typename OutSel<FMT>::T out, int *__restrict__ err) {
+                                                           typename OutSel<FMT>::T out, int *__restrict__ err, DeepArena da) {
     typedef WalkCacheT<(!ALL && !EMIT_SLIM) || GEN || HAS_LOSSY> WCache;      // the flag words only where they are read (or LDS is not the limit)
     __shared__ EvQueue<FMT, ALL> s_q[4];
     __shared__ WCache s_wc[4];
-    LevelEmit below[MAXN];
+    typedef LevelEmitT<DEEP> LevelEmit;
+    typedef typename CountOf<DEEP>::T cnt_t;
+    const int64_t lane_global = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (deep variant: the lane's column of the arena)
+    const int cap = DEEP ? da.cap : MAXN;
+    typename StackOf<LevelEmit, MAXN, DEEP>::type below;
+    bind(below, da, DA_BELOW, lane_global);
     LevelEmit below0;                  // the first suspended level stays in registers
     below0.ctx = 0; below0.maf = 0.0; below0.cur = below0.end = below0.mn = 0; below0.cum = below0.vc = below0.evf = below0.evt = 0;
-    int32_t path[(ALL || GEN) ? MAXN : 1]; // all-nodes mode / general graphs: the node of every level of the walk (level 0 = the end node)
-    uint8_t lvl_a[GEN ? MAXN : 1];         // general graphs: `a` of the suspended levels (see history_ok)
+    typename StackOf<int32_t, (ALL || GEN) ? MAXN : 1, DEEP>::type path;   // all-nodes mode / general graphs: the node of every level of the walk (level 0 = the end node)
+    typename StackOf<cnt_t, GEN ? MAXN : 1, DEEP>::type lvl_a;             // general graphs: `a` of the suspended levels (see history_ok)
+    bind(path, da, DA_PATH, lane_global);
+    bind(lvl_a, da, DA_LVLA, lane_global);
     constexpr bool LAZY = GEN && !ALL;     // path levels 1, 2 and lvl_a[1] in registers, see k_count_boundary
     int32_t pr1 = 0, pr2 = 0;
-    uint8_t a_l1 = 0;
+    int a_l1 = 0;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     EvQueue<FMT, ALL> &q = s_q[wib];
@@ -861,7 +956,10 @@ __global__ __launch_bounds__(256, (EMIT_SLIM && !GEN && !ALL && !HAS_LOSSY && FM
                     if (t_evf < t_evt) { ev = true; e_from = t_evf; e_to = t_evt; e_ctx = t_ctx; e_mn = t_mn; e_maf = t_maf; e_nl = L; }
                     L--;
                     if (L > 0) {
-                        const LevelEmit b = L == 1 ? below0 : below[L - 1];
+                        // (by value: `L == 1 ? below0 : below[L - 1]` is a choice between two OBJECTS, which keeps below0
+                        // addressable; general emit 2.98 -> 2.58 ms, all-nodes 5.91 -> 5.82 ms, count pass 0.57 -> 0.54 ms)
+                        LevelEmit b = below0;
+                        if (L != 1) b = below[L - 1];
                         t_cur = b.cur; t_end = b.end; t_cum = b.cum; t_vc = b.vc; t_evf = b.evf; t_evt = b.evt;
                         t_ctx = b.ctx; t_mn = b.mn; t_maf = b.maf;
                         if (GEN) t_a = (LAZY && L == 1) ? a_l1 : lvl_a[L];
@@ -882,7 +980,7 @@ __global__ __launch_bounds__(256, (EMIT_SLIM && !GEN && !ALL && !HAS_LOSSY && FM
                                !((fq & GKI_NODE_HFS) && !(a.nflags[!LAZY ? path[L - 1] : L == 1 ? (int32_t)n : L == 2 ? pr1 : L == 3 ? pr2 : path[L - 1]] & GKI_NODE_FORCED));
                     }
                     if (take) {
-                        if (L >= MAXN - 1) {
+                        if (L >= cap - 1) {
                             gki_raise(err, GKI_ERR_WINDOW_TOO_DEEP);
                         } else {
                             const int s = wq.size, c = t_cum;
@@ -903,7 +1001,7 @@ __global__ __launch_bounds__(256, (EMIT_SLIM && !GEN && !ALL && !HAS_LOSSY && FM
                                 if (GEN && from < to && !(fq & (GKI_NODE_T | GKI_NODE_SIMPLE))) {      // a history before q?
                                     // (fq >> 8: no history holds more variant nodes in the k bases before q -- if even
                                     // that many fit under the limit, any history that enters q will do, and q is entered)
-                                    const bool ok = (fq & GKI_NODE_NESTED) ? (vq + (int)(fq >> 8) < a.M || (LAZY ? (void)(path[1] = pr1, path[2] = pr2) : (void)0, history_ok(WalkSrc{g.walk, g.rev_edges, g.rev_start}, wc, wv, a.nflags, k, a.M, path, L, err))) : false;
+                                    const bool ok = (fq & GKI_NODE_NESTED) ? (vq + (int)(fq >> 8) < a.M || (LAZY ? (void)(path[1] = pr1, path[2] = pr2) : (void)0, history_ok(WalkSrc{g.walk, g.rev_edges, g.rev_start}, wc, wv, a.nflags, k, a.M, raw(path), L, err, da, lane_global))) : false;
                                     if (!ok) to = from;
                                 }
                                 const int tq = s < k - 1 - c ? s : k - 1 - c;
@@ -913,10 +1011,10 @@ __global__ __launch_bounds__(256, (EMIT_SLIM && !GEN && !ALL && !HAS_LOSSY && FM
                             }
                             if (deeper) {
                                 LevelEmit b;
-                                b.cur = t_cur; b.end = t_end; b.cum = (uint8_t)t_cum; b.vc = (uint8_t)t_vc;
+                                b.cur = t_cur; b.end = t_end; b.cum = (uint8_t)t_cum; b.vc = (cnt_t)t_vc;
                                 b.evf = (uint8_t)t_evf; b.evt = (uint8_t)t_evt; b.ctx = t_ctx; b.mn = t_mn; b.maf = t_maf;
                                 if (L == 1) below0 = b; else below[L - 1] = b;
-                                if (GEN) { if (LAZY && L == 1) a_l1 = (uint8_t)t_a; else lvl_a[L] = (uint8_t)t_a; t_a = aq; }
+                                if (GEN) { if (LAZY && L == 1) a_l1 = t_a; else lvl_a[L] = (cnt_t)t_a; t_a = aq; }
                                 preds_begin(g, wq, qn, &t_cur, &t_end);
                                 t_cum = new_cum; t_vc = vq;
                                 t_evf = from < to ? from : 0; t_evt = from < to ? to : 0;
@@ -932,11 +1030,36 @@ __global__ __launch_bounds__(256, (EMIT_SLIM && !GEN && !ALL && !HAS_LOSSY && FM
             int e_nls = e_nl;                        // nodes of the window that get a record (only_store_nodes)
             if (GEN && a.store && ev) {
                 if (LAZY) { path[1] = pr1; path[2] = pr2; }
-                e_nls = stored_nodes(a.store, path, e_nl, !ALL);
+                e_nls = stored_nodes(a.store, raw(path), e_nl, !ALL);
                 if (e_nls == 0) ev = false;
             }
             if (ALL && ev && e_nl > NLQ && GKI_DBG_SKIP_EXPAND_IS(4)) ev = false;
-            if (ALL) {
+            if (ALL && DEEP) {
+                // deep variant: a window over more nodes than a queued step carries is written by its lane alone, the
+                // nodes that get a record found in ascending order by repeated selection over the lane's path (the
+                // nodes of a path are distinct) -- quadratic in the window's nodes, and only the slow path pays it
+                if (ev && e_nl > NLQ) {
+                    const bool filt = GEN && a.store;
+                    const int cntw = e_to - e_from;
+                    int32_t prev = INT_MIN;
+                    for (int r = 0; r < e_nls; r++) {
+                        int32_t best = INT_MAX;
+                        for (int a2 = 0; a2 < e_nl; a2++) {
+                            const int32_t v = path[a2];
+                            if (v > prev && v < best && !(filt && !a.store[v])) best = v;
+                        }
+                        for (int w = 0; w < cntw; w++) {
+                            const int o = e_from + w;
+                            const uint64_t h = ((e_ctx >> (2 * o)) | (own << (2 * (k - 1 - o)))) & kmask;
+                            put(out, idx + (int64_t)w * e_nls + r, h, best, (int32_t)n, o, pos0 + o, e_maf);
+                        }
+                        prev = best;
+                    }
+                    idx += (int64_t)cntw * e_nls;
+                    ev = false;
+                }
+            }
+            if (ALL && !DEEP) {
                 // A window over more nodes than a queued step carries (rows of empty or 1-bp nodes, SNPs a few bases
                 // apart): written by the WAVE, one such step at a time.  Written by its lane alone -- per record a
                 // selection over the scratch-resident path -- a single step held its wave for thousands of dependent
@@ -1200,6 +1323,8 @@ struct gki_finder {
     int *d_err; int64_t *d_totals; unsigned long long *d_bsum;
     int64_t *h_totals;                // pinned: {total, error, boundary records, 0, boundary sum} read back by every count
     int32_t *d_rank;                  // topological ranks of the run in progress (non-topological node ids only)
+    DeepArena deep;                   // cap > 0: the run in progress needed the deep kernel variants (their stacks live here)
+    int64_t deep_bytes;
     FindArgs args;
     int64_t n_records, n_boundary_records, n_interior_records;
     int64_t word_begin, word_end, p_begin, p_end;
@@ -1224,14 +1349,30 @@ static int launch_boundary_mode(gki_finder *f, const DevGraph &d, const FindArgs
     const int emit_pad = GKI_KNOB("GKI_EMIT_LDS_PAD", 0);  // tuning builds: unused dynamic LDS, to lower the occupancy
     // the lossy-restart logic costs 0.4-0.5 ms (emit) + 0.1-0.2 ms (count) per step on the 3 Gbp graphs even when the run has
     // no such point (a lossy[q] load per predecessor step): every variant exists without it
+    const DeepArena da = f->deep;
+    if (da.cap > 0) {
+        // the count pass met a window deeper than the product kernels' stacks: the same kernels with their stacks in the
+        // arena, on the grid the arena was sized for
+        const dim3 dgrid((unsigned)(da.lanes / 256));
+        if (a.nflags && a.has_lossy)
+            hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, true, true>), dgrid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err, da);
+        else if (a.nflags)
+            hipLaunchKernelGGL((k_emit_boundary_one<false, FMT, ALL, true, true>), dgrid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err, da);
+        else if (a.has_lossy)
+            hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, false, true>), dgrid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err, da);
+        else
+            hipLaunchKernelGGL((k_emit_boundary_one<false, FMT, ALL, false, true>), dgrid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err, da);
+        HIP_TRY(hipGetLastError());
+        return GKI_OK;
+    }
     if (a.nflags && a.has_lossy)
-        hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, true>), grid, block, emit_pad, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
+        hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, true>), grid, block, emit_pad, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err, da);
     else if (a.nflags)
-        hipLaunchKernelGGL((k_emit_boundary_one<false, FMT, ALL, true>), grid, block, emit_pad, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
+        hipLaunchKernelGGL((k_emit_boundary_one<false, FMT, ALL, true>), grid, block, emit_pad, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err, da);
     else if (a.has_lossy)
-        hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, false>), grid, block, emit_pad, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
+        hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, false>), grid, block, emit_pad, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err, da);
     else
-        hipLaunchKernelGGL((k_emit_boundary_one<false, FMT, ALL, false>), grid, block, emit_pad, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err);
+        hipLaunchKernelGGL((k_emit_boundary_one<false, FMT, ALL, false>), grid, block, emit_pad, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err, da);
     HIP_TRY(hipGetLastError());
     return GKI_OK;
 }
@@ -1379,7 +1520,7 @@ int gki_finder_destroy(gki_finder *f) {
     (void)hipStreamSynchronize(f->stream);
     (void)hipStreamSynchronize(f->stream2);
     void *ptrs[] = {f->bcount, f->total, f->rec_base, f->bnd_base, f->ne, f->lossy, f->scan_tmp, f->d_err, f->d_totals, f->d_bsum,
-                    f->d_rank, f->nflags, f->store};
+                    f->d_rank, f->nflags, f->store, f->deep.base};
     for (void *p : ptrs) if (p) (void)gki_dev_free(p);
     if (f->h_totals) (void)hipHostFree(f->h_totals);
     for (int i = 0; i < 8; i++) (void)hipEventDestroy(f->ev[i]);
@@ -1439,6 +1580,10 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
     f->args = a;
     const int64_t n_run = a.n1 - a.n0;
     if (a.has_lossy && !force_lossy) HIP_TRY(hipMemcpyAsync(f->lossy, p->h_lossy_crit, (size_t)d.n_nodes * 2, hipMemcpyHostToDevice, s));
+    f->deep.cap = 0;                  // the product kernels first; a window deeper than their stacks sends the pass round again
+    int64_t *tot = f->h_totals;       // pinned host memory: the two small copies are true async DMAs
+    unsigned long long bsum = 0;
+    for (;;) {
     HIP_TRY(hipMemsetAsync(f->d_err, 0, 4, s));
     HIP_TRY(hipMemsetAsync(f->d_bsum, 0, 8, s));
 
@@ -1449,18 +1594,30 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
         const int64_t want = ceil_div(n_run, 256), cap = GKI_KNOB("GKI_CNT_BLOCKS", 1 << 30);
         const int count_grid = (int)(want < cap ? want : cap);
         const int cnt_pad = GKI_KNOB("GKI_CNT_LDS_PAD", 0);   // tuning builds: unused dynamic LDS, to lower the occupancy
-        if (a.nflags && a.has_lossy)
+        const DeepArena da = f->deep;
+        if (da.cap > 0) {
+            const dim3 dgrid((unsigned)(da.lanes / 256));
+            if (a.nflags && a.has_lossy)
+                hipLaunchKernelGGL((k_count_boundary<true, true, true>), dgrid, dim3(256), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
+            else if (a.nflags)
+                hipLaunchKernelGGL((k_count_boundary<false, true, true>), dgrid, dim3(256), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
+            else if (a.has_lossy)
+                hipLaunchKernelGGL((k_count_boundary<true, false, true>), dgrid, dim3(256), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
+            else
+                hipLaunchKernelGGL((k_count_boundary<false, false, true>), dgrid, dim3(256), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
+        }
+        else if (a.nflags && a.has_lossy)
             hipLaunchKernelGGL((k_count_boundary<true, true>), dim3(count_grid), dim3(256), cnt_pad, s, d, a, f->lossy,
-                               f->bcount, f->total, f->d_err);
+                               f->bcount, f->total, f->d_err, da);
         else if (a.nflags)
             hipLaunchKernelGGL((k_count_boundary<false, true>), dim3(count_grid), dim3(256), cnt_pad, s, d, a, f->lossy,
-                               f->bcount, f->total, f->d_err);
+                               f->bcount, f->total, f->d_err, da);
         else if (a.has_lossy)
             hipLaunchKernelGGL((k_count_boundary<true, false>), dim3(count_grid), dim3(256), cnt_pad, s, d, a, f->lossy,
-                               f->bcount, f->total, f->d_err);
+                               f->bcount, f->total, f->d_err, da);
         else
             hipLaunchKernelGGL((k_count_boundary<false, false>), dim3(count_grid), dim3(256), cnt_pad, s, d, a, f->lossy,
-                               f->bcount, f->total, f->d_err);
+                               f->bcount, f->total, f->d_err, da);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(f->ev[1], s));
@@ -1483,17 +1640,35 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
     hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, s, f->rec_base, f->bnd_base, a.n1, a.split, f->d_err, f->d_totals);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(f->ev[7], s));
-    int64_t *tot = f->h_totals;                       // pinned host memory: the two small copies are true async DMAs
     HIP_TRY(hipMemcpyAsync(tot, f->d_totals, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(tot + 4, f->d_bsum, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    unsigned long long bsum = (unsigned long long)tot[4];
+    bsum = (unsigned long long)tot[4];
     const int run_err = gki_error_of_word(tot[1]);
-    if (run_err == GKI_ERR_NOT_ONE_REF_SUCC)
+    if (run_err == GKI_ERR_NOT_ONE_REF_SUCC && !(tot[1] & 2))
         return gki_set_error(GKI_ERR_NOT_ONE_REF_SUCC, "a window at the variant limit ends a node that does not have exactly one "
                              "linear-ref successor: the reference asserts here (kmer_finder.py:402); raise max_variant_nodes");
-    if (run_err != GKI_OK)
-        return gki_set_error(run_err, "a k-window (or the history that decides it) crosses more than %d nodes", MAXN - 2);
+    if (run_err == GKI_OK) break;
+    // GKI_ERR_WINDOW_TOO_DEEP.  Bit 1 of the word: a stack of the walk (or of a history) was too short -- the slow path:
+    // the pass again with the deep kernel variants, their stacks in an arena of twice the levels each time round.
+    // Bit 2: a history enumeration ran out of its step budget, which no depth cures.
+    const int next_cap = f->deep.cap == 0 ? 4 * MAXN : 2 * f->deep.cap;
+    if ((tot[1] & 4) || !(tot[1] & 2) || next_cap > GKI_MAX_DEEP_WINDOW_NODES)
+        return gki_set_error(GKI_ERR_WINDOW_TOO_DEEP, (tot[1] & 4) ? "the k-windows ending in one node (or the histories that decide one of them) take more "
+                             "than %d descents to enumerate: too many paths" : "a k-window (or the history that decides it) crosses more than %d nodes",
+                             (tot[1] & 4) ? STEP_BUDGET : GKI_MAX_DEEP_WINDOW_NODES - 2);
+    {
+        // 64 workgroups walk the run (grid-stride): 16 384 lanes x cap levels x 70 bytes = 0.3 GB at the first cap
+        const int64_t lanes = 64 * 256, bytes = lanes * (int64_t)next_cap * DA_CELL;
+        if (bytes > f->deep_bytes) {
+            if (f->deep.base) HIP_TRY(gki_dev_free(f->deep.base));
+            f->deep.base = nullptr; f->deep_bytes = 0;
+            HIP_TRY(gki_dev_malloc((void **)&f->deep.base, (size_t)bytes));
+            f->deep_bytes = bytes;
+        }
+        f->deep.lanes = lanes; f->deep.cap = next_cap; f->deep.pad = 0;
+    }
+    }
     if (a.split) bsum = (unsigned long long)tot[2];
     f->n_records = tot[0];
     f->n_boundary_records = (int64_t)bsum;

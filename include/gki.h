@@ -27,13 +27,16 @@ extern "C" {
 #define GKI_ERR_HIP 1            /* a HIP runtime call failed (message has the HIP error string) */
 #define GKI_ERR_BAD_ARG 2
 #define GKI_ERR_NO_DEVICE 3
-#define GKI_ERR_WINDOW_TOO_DEEP 4 /* a k-window crosses more than GKI_MAX_WINDOW_NODES nodes */
+#define GKI_ERR_WINDOW_TOO_DEEP 4 /* a k-window crosses more nodes than the kernels' stacks hold: GKI_MAX_DEEP_WINDOW_NODES for
+                                     gki_finder_count / emit (which fall back to their slow path above GKI_MAX_WINDOW_NODES),
+                                     GKI_MAX_WINDOW_NODES for the early-stop search (gki_forward_*) */
 #define GKI_ERR_STATE 5          /* call order violated (e.g. emit before count) */
 #define GKI_ERR_OVERFLOW 6       /* a count does not fit the reference's dtype (e.g. int32 directory) */
 #define GKI_ERR_NOT_ONE_REF_SUCC 7 /* the reference's AssertionError kmer_finder.py:402: a reachable window at the
                                      variant limit ends a node that does not have exactly one linear-ref successor */
 
-#define GKI_MAX_WINDOW_NODES 48
+#define GKI_MAX_WINDOW_NODES 48        /* stacks of the product kernels (scratch) */
+#define GKI_MAX_DEEP_WINDOW_NODES 6144 /* stacks of the finder's slow path (a global-memory arena, grown 192, 384, ... levels) */
 #define GKI_MAX_K 31             /* kmer_hashing.py:25 `assert k <= 31` */
 
 /* ---------------------------------------------------------------- runtime */

@@ -32,7 +32,8 @@ from graph_kmer_index.kmer_hashing import power_array  # noqa: E402
 from obgraph import Graph  # noqa: E402
 
 from graph_kmer_index_amd.graph import GraphArrays, synthetic_linear_graph, synthetic_snp_graph  # noqa: E402
-from graphgen import random_bubble_graph, overlapping_bubble_graph, nested_bubble_graph, deep_nested_graph  # noqa: E402
+from graphgen import (random_bubble_graph, overlapping_bubble_graph, nested_bubble_graph, deep_nested_graph,  # noqa: E402
+                      empty_chain_graph)
 from golden_cases import REFERENCE_TEST_GRAPHS, canonical_digest  # noqa: E402
 
 
@@ -359,7 +360,68 @@ def two_chromosome_cases():
     return cases
 
 
+def deep_window_cases():
+    """k-windows crossing far more nodes than the GPU kernels' scratch stacks hold (GKI_MAX_WINDOW_NODES = 48): runs of
+    insertion sites / empty nodes with nothing between them (graphgen.empty_chain_graph).  The reference recurses per node
+    (sys.setrecursionlimit(20000), kmer_finder.py); the GPU library answers these through its slow path."""
+    cases = []
+    rng = np.random.default_rng(20261005)
+
+    def add(name, graph, k, **kw):
+        seqs, edges, lin, af = graph
+        g = Graph.from_dicts(seqs, edges, lin, af)
+        base = dict(name=name, seqs={str(a): b for a, b in seqs.items()}, edges={str(a): b for a, b in edges.items()},
+                    linear=lin, k=k, af=None if af is None else {str(a): b for a, b in af.items()}, kw=kw)
+        fl, crit = run_finder(g, k, **kw)
+        cols = dict(kmers=fl._hashes, nodes=fl._nodes, start_nodes=fl._start_nodes, start_offsets=fl._start_offsets,
+                    allele_frequencies=fl._allele_frequencies)
+        rec = dict(base, crit_nodes=crit[0], crit_offsets=crit[1], n_records=int(len(fl._hashes)), digest=canonical_digest(cols))
+        if len(fl._hashes) <= 1500:                    # small cases carry their records, the others count + digest
+            rec.update({name2: np.asarray(v).tolist() for name2, v in cols.items()})
+        cases.append(rec)
+
+    i = 0
+    for n_sites, k, m in ((20, 31, 2), (46, 31, 1), (47, 12, 2), (50, 31, 1), (70, 31, 1), (70, 6, 2), (120, 31, 1), (120, 9, 1),
+                          (200, 31, 1), (200, 4, 2), (400, 31, 0), (400, 20, 1)):
+        for one in (True, False):
+            graph = empty_chain_graph(rng, n_sites, first_ref=int(rng.integers(3, 40)), last_ref=int(rng.integers(k, 3 * k)),
+                                      with_af=bool(i % 2), p_plain=float(rng.choice([0.0, 0.2, 0.6])))
+            add("deep_%d_sites%d_k%d_m%d_%d" % (i, n_sites, k, m, int(one)), graph, k, only_save_one_node_per_kmer=one, max_variant_nodes=m)
+            i += 1
+    # two deep runs in one graph with ordinary bubbles between them, chunked by critical points
+    for j in range(3):
+        k = int(rng.choice([7, 15, 31]))
+        a = empty_chain_graph(rng, 60, first_ref=k + 3, last_ref=2 * k, with_af=True)
+        b = random_bubble_graph(rng, n_var=4, min_ref=2, max_ref=2 * k, first_ref=k, with_af=True)
+        c = empty_chain_graph(rng, 90, first_ref=5, last_ref=k + 5, with_af=True, p_plain=0.5)
+        seqs, edges, lin, af = {}, {}, [], {}
+        last_tail = None
+        for part in (a, b, c):
+            shift = len(seqs)
+            ps, pe, pl, pa = part
+            for n2, sq in ps.items(): seqs[n2 + shift] = sq
+            for n2, e2 in pe.items(): edges[n2 + shift] = [m2 + shift for m2 in e2]
+            lin += [n2 + shift for n2 in pl]
+            for n2, f2 in pa.items(): af[n2 + shift] = f2
+            if last_tail is not None:
+                edges[last_tail] = [shift]              # the previous part's end node continues into this part's first
+            last_tail = shift + len(ps) - 1
+        g = Graph.from_dicts(seqs, edges, lin, af)
+        n_crit = len(CriticalGraphPaths.from_graph(g, k))
+        add("deep_mixed_%d" % j, (seqs, edges, lin, af), k, only_save_one_node_per_kmer=bool(j % 2), max_variant_nodes=1)
+        for lo, hi in ((0, max(1, n_crit // 2)), (max(1, n_crit // 2), n_crit)):
+            add("deep_mixed_chunk_%d_%d_%d" % (j, lo, hi), (seqs, edges, lin, af), k, start_at_critical_path_number=lo,
+                stop_at_critical_path_number=hi, only_save_one_node_per_kmer=True, max_variant_nodes=2)
+    return cases
+
+
 def main():
+    if sys.argv[1:] == ["deep"]:
+        deep = deep_window_cases()
+        with open(os.path.join(HERE, "finder_deep.json"), "w") as f:
+            json.dump(deep, f, separators=(",", ":"))
+        print("deep-window cases:", len(deep), "records:", [c["n_records"] for c in deep])
+        return
     if sys.argv[1:] == ["two_chrom"]:
         two = two_chromosome_cases()
         with open(os.path.join(HERE, "finder_two_chrom.json"), "w") as f:

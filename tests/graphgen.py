@@ -182,3 +182,40 @@ def deep_nested_graph(rng, n_var=4, max_depth=2, min_ref=1, max_ref=8, p_nest=0.
         link(alt_out, head)
         tail = head
     return seqs, edges, linear, None
+
+
+def empty_chain_graph(rng, n_sites, first_ref=8, last_ref=40, max_ins=2, p_plain=0.2, p_snp=0.1, with_af=False):
+    """A run of `n_sites` variant sites with NOTHING between them, so that one k-window crosses all of them: each site is
+    an insertion (an empty linear-ref dummy beside an inserted allele of 1..max_ins bases), with probability p_plain a
+    single empty node, with probability p_snp a SNP (two 1-bp alleles, which use up window bases).  The windows that take
+    the empty allele everywhere span n_sites + 2 nodes -- the shape behind GKI_MAX_WINDOW_NODES and the finder's slow path.
+    Returns (node_sequences, edges, linear_ref_nodes, allele_frequencies or None)."""
+    seqs, edges, linear, af = {}, {}, [], {}
+
+    def add(seq, is_lin, freq=1.0):
+        nid = len(seqs)
+        seqs[nid] = seq
+        af[nid] = freq
+        if is_lin:
+            linear.append(nid)
+        return nid
+
+    tails = [add(_rand_seq(rng, first_ref), True)]
+    for _ in range(n_sites):
+        u = rng.random()
+        f = float(rng.uniform(0.01, 0.99)) if with_af else 1.0
+        if u < p_plain:
+            alleles = [add("", False, f)]
+        elif u < p_plain + p_snp:
+            r = _rand_seq(rng, 1)
+            alleles = [add(r, True, f), add(_L[(_L.index(r) + 1 + int(rng.integers(0, 3))) % 4], False, 1.0 - f if with_af else 1.0)]
+        else:
+            alleles = [add("", False, f), add(_rand_seq(rng, int(rng.integers(1, max_ins + 1))), False, 1.0 - f if with_af else 1.0)]
+        succ = alleles[::-1] if rng.random() < 0.5 else list(alleles)
+        for t in tails:
+            edges[t] = list(succ)
+        tails = alleles
+    end = add(_rand_seq(rng, last_ref), True)
+    for t in tails:
+        edges[t] = [end]
+    return seqs, edges, linear, (af if with_af else None)

@@ -60,8 +60,13 @@ def test_no_flat_memory_instructions_outside_history_ok(finder_asm):
     offenders = {}
     for name, body in funcs.items():
         n = len(re.findall(r"\n\s*flat_(load|store|atomic)", body))
-        if n and not name.startswith("history_ok"):
-            offenders[name.split("(")[0]] = n
+        short = name.split("(")[0]
+        # (the slow path for deep windows -- last template argument true -- selects between a register level and an
+        # arena level through one generic pointer; it is not where the time goes)
+        deep = (short.startswith("k_emit_boundary_one<") and short.count(",") == 4 and short.endswith(", true>")) or \
+               (short.startswith("k_count_boundary<") and short.count(",") == 2 and short.endswith(", true>"))
+        if n and not name.startswith("history_ok") and not deep:
+            offenders[short] = n
     assert not offenders, "FLAT memory instructions (address space lost): %s" % offenders
 
 
@@ -70,8 +75,9 @@ def test_occupancy_footprints_of_the_walk_kernels(finder_asm):
     waves_by_regs = lambda v: min(8, 512 // ((v + 7) // 8 * 8))
     blocks_by_lds = lambda b: 163840 // b
     # count pass: 8 waves per SIMD in every variant (the general one is held there by __launch_bounds__)
-    for v in ("k_count_boundary<false, false>", "k_count_boundary<true, false>", "k_count_boundary<true, true>",
-              "k_count_boundary<false, true>"):
+    # (last template argument: false = the product kernels; true = the slow path for windows deeper than their stacks)
+    for v in ("k_count_boundary<false, false, false>", "k_count_boundary<true, false, false>", "k_count_boundary<true, true, false>",
+              "k_count_boundary<false, true, false>"):
         assert waves_by_regs(r[v]["vgpr"]) == 8, (v, r[v])
         assert blocks_by_lds(r[v]["lds"]) >= 8, (v, r[v])
     # emit pass, flat layouts (FMT 0 / 2): 4 workgroups per CU in one-node mode, and since round 3 in all-nodes mode too
@@ -79,13 +85,17 @@ def test_occupancy_footprints_of_the_walk_kernels(finder_asm):
     # all-nodes variant of runs with lossy restart points keeps the flag words and stays at 3; registers never the limit
     for lossy in ("false", "true"):
         for fmt in ("0", "2"):
-            one = r["k_emit_boundary_one<%s, %s, false, false>" % (lossy, fmt)]
-            allm = r["k_emit_boundary_one<%s, %s, true, false>" % (lossy, fmt)]
+            one = r["k_emit_boundary_one<%s, %s, false, false, false>" % (lossy, fmt)]
+            allm = r["k_emit_boundary_one<%s, %s, true, false, false>" % (lossy, fmt)]
             assert blocks_by_lds(one["lds"]) == 4 and waves_by_regs(one["vgpr"]) >= 4, (lossy, fmt, one)
             want = 4 if lossy == "false" else 3
             assert blocks_by_lds(allm["lds"]) == want and waves_by_regs(allm["vgpr"]) >= want, (lossy, fmt, allm)
+    # the slow path keeps its stacks out of scratch: a global-memory arena sized for the run
+    for name, res in r.items():
+        if name.endswith(", true>") and (name.startswith("k_emit_boundary_one<") or name.startswith("k_count_boundary<")) and name.count(",") == (4 if "emit" in name else 2):
+            assert res["scratch"] <= 256, (name, res)
     for lossy in ("false", "true"):            # general variants, with and without the lossy-restart logic
-        gen = r["k_emit_boundary_one<%s, 2, false, true>" % lossy]
+        gen = r["k_emit_boundary_one<%s, 2, false, true, false>" % lossy]
         assert blocks_by_lds(gen["lds"]) == 4 and waves_by_regs(gen["vgpr"]) >= 4, (lossy, gen)
 
 
