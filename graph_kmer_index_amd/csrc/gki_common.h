@@ -102,6 +102,9 @@ __device__ __forceinline__ uint64_t node_tail(const NodeWalk &w, int t) {
     return (w.tail >> (2 * (t31 - t))) & ((1ull << (2 * t)) - 1ull);
 }
 
+// arena behind the slow path of a graph walk (see "stacks of the graph walks" below): cap levels for each of `lanes` lanes
+struct DeepArena { char *base; int64_t lanes; int32_t cap; int32_t pad; };
+
 struct gki_graph {
     DevGraph d;
     int64_t *h_seq_start;                    // host copy of d.seq_start [n_nodes+1] (chunk bounds without a device read)
@@ -111,6 +114,8 @@ struct gki_graph {
     int n_owned;
     bool owns_seq;
     hipEvent_t ev_prep0, ev_prep1;
+    DeepArena fwd_deep;                      // early-stop search: arena of its slow path, cap > 0 after a count call that needed it
+    int64_t fwd_deep_bytes;
 };
 
 // ---------------------------------------------------------------------------------- device error word
@@ -128,6 +133,41 @@ __device__ __forceinline__ void gki_raise_budget(int *err) { atomicOr((unsigned 
 static inline int gki_error_of_word(int64_t word) {
     return (word & 6) ? GKI_ERR_WINDOW_TOO_DEEP : (word & 1) ? GKI_ERR_NOT_ONE_REF_SUCC : GKI_OK;
 }
+
+// ---------------------------------------------------------------------------------- stacks of the graph walks
+// Where the levels below the top live.  The product kernels keep MAXN of them per lane in scratch (LocalStack: a plain
+// array); a window over more than MAXN - 2 nodes -- sixteen or more EMPTY nodes inside one 31-base window -- makes them
+// raise GKI_ERR_WINDOW_TOO_DEEP, and gki_finder_count then runs the pass again with the DEEP instantiation of the same
+// kernels, whose stacks lie in a global-memory arena sized for the run (ArenaStack: level-major, lane-interleaved, so a
+// wave's accesses to one level coalesce; every lane reads only what it wrote).  Same walk, same arithmetic: the slow path
+// differs in where a level is stored, in counters wide enough for its depth, and in all-nodes mode in who writes a
+// many-node window (its lane alone).
+template <class T, int N> struct LocalStack {
+    T v[N];
+    __device__ __forceinline__ T &operator[](int i) { return v[i]; }
+    __device__ __forceinline__ const T &operator[](int i) const { return v[i]; }
+};
+template <class T> struct ArenaStack {
+    T *base; int64_t stride;
+    __device__ __forceinline__ T &operator[](int i) const { return base[(int64_t)i * stride]; }
+};
+template <class T> __device__ __forceinline__ ArenaStack<T> arena_stack(const DeepArena &da, int offset, int64_t lane_global) {
+    ArenaStack<T> st;
+    st.base = reinterpret_cast<T *>(da.base + (int64_t)da.cap * da.lanes * offset) + lane_global;
+    st.stride = da.lanes;
+    return st;
+}
+template <class T, int N, bool DEEP> struct StackOf { typedef LocalStack<T, N> type; };
+template <class T, int N> struct StackOf<T, N, true> { typedef ArenaStack<T> type; };
+template <class T, int N> __device__ __forceinline__ void bind(LocalStack<T, N> &, const DeepArena &, int, int64_t) {}
+template <class T> __device__ __forceinline__ void bind(ArenaStack<T> &st, const DeepArena &da, int offset, int64_t lane_global) {
+    st = arena_stack<T>(da, offset, lane_global);
+}
+template <class T, int N> __device__ __forceinline__ T *raw(LocalStack<T, N> &st) { return st.v; }
+template <class T> __device__ __forceinline__ ArenaStack<T> raw(const ArenaStack<T> &st) { return st; }
+template <bool DEEP> struct CountOf { typedef uint8_t T; };      // variant-node counters of a suspended level
+template <> struct CountOf<true> { typedef uint16_t T; };
+
 
 // ---------------------------------------------------------------------------------- wave prefix sums (DPP)
 // Inclusive prefix sum over the 64 lanes of a wave on the data-parallel-primitive path: row shifts by 1, 2, 4, 8 inside

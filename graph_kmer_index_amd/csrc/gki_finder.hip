@@ -255,43 +255,10 @@ __device__ __forceinline__ void interior_range(const FindArgs &a, int64_t n, int
 // the levels below it in (scratch) arrays: PMC showed the first version, with the whole stack in scratch, writing
 // 1.4 GB of spills in the count pass and ~5 GB in the emit pass of the 3 Gbp graph, and every step began with a
 // dependent scratch load.  Node facts come from one aligned 32-byte NodeWalk record per visited node.
-// Where the levels below the top live.  The product kernels keep MAXN of them per lane in scratch (LocalStack: a plain
-// array); a window over more than MAXN - 2 nodes -- sixteen or more EMPTY nodes inside one 31-base window -- makes them
-// raise GKI_ERR_WINDOW_TOO_DEEP, and gki_finder_count then runs the pass again with the DEEP instantiation of the same
-// kernels, whose stacks lie in a global-memory arena sized for the run (ArenaStack: level-major, lane-interleaved, so a
-// wave's accesses to one level coalesce; every lane reads only what it wrote).  Same walk, same arithmetic: the slow path
-// differs in where a level is stored, in counters wide enough for its depth, and in all-nodes mode in who writes a
-// many-node window (its lane alone).
-template <class T, int N> struct LocalStack {
-    T v[N];
-    __device__ __forceinline__ T &operator[](int i) { return v[i]; }
-    __device__ __forceinline__ const T &operator[](int i) const { return v[i]; }
-};
-template <class T> struct ArenaStack {
-    T *base; int64_t stride;
-    __device__ __forceinline__ T &operator[](int i) const { return base[(int64_t)i * stride]; }
-};
-struct DeepArena { char *base; int64_t lanes; int32_t cap; int32_t pad; };     // cap levels for each of `lanes` lanes
+// (LocalStack / ArenaStack / DeepArena, the storage of the levels below the top: csrc/gki_common.h)
 // byte offset of every per-level array inside one (level, lane) cell of the arena
 enum { DA_BELOW = 0, DA_PATH = 40, DA_LVLA = 44, DA_CT = 46, DA_CM = 47, DA_HN = 49, DA_HCUR = 53, DA_HEND = 57, DA_HD = 61,
        DA_HSZ = 65, DA_HF = 69, DA_CELL = 70 };
-template <class T> __device__ __forceinline__ ArenaStack<T> arena_stack(const DeepArena &da, int offset, int64_t lane_global) {
-    ArenaStack<T> st;
-    st.base = reinterpret_cast<T *>(da.base + (int64_t)da.cap * da.lanes * offset) + lane_global;
-    st.stride = da.lanes;
-    return st;
-}
-template <class T, int N, bool DEEP> struct StackOf { typedef LocalStack<T, N> type; };
-template <class T, int N> struct StackOf<T, N, true> { typedef ArenaStack<T> type; };
-template <class T, int N> __device__ __forceinline__ void bind(LocalStack<T, N> &, const DeepArena &, int, int64_t) {}
-template <class T> __device__ __forceinline__ void bind(ArenaStack<T> &st, const DeepArena &da, int offset, int64_t lane_global) {
-    st = arena_stack<T>(da, offset, lane_global);
-}
-template <class T, int N> __device__ __forceinline__ T *raw(LocalStack<T, N> &st) { return st.v; }
-template <class T> __device__ __forceinline__ ArenaStack<T> raw(const ArenaStack<T> &st) { return st; }
-template <bool DEEP> struct CountOf { typedef uint8_t T; };      // variant-node counters of a suspended level
-template <> struct CountOf<true> { typedef uint16_t T; };
-
 template <bool DEEP>
 struct LevelLoT {                // what a suspended level needs to resume
     int32_t cur, end;

@@ -32,12 +32,30 @@ __device__ __forceinline__ void check_one_ref_successor(const DevGraph &g, int32
     if (n_ref != 1) gki_raise(err, GKI_ERR_NOT_ONE_REF_SUCC);
 }
 
-template <bool EMIT>
+// byte offset of every per-level array of the walk inside one (level, lane) cell of the slow path's arena (DeepArena)
+enum { FW_ND = 0, FW_CUR = 4, FW_END = 8, FW_LAST = 12, FW_HS = 16, FW_HAVE = 24, FW_FORCED = 25, FW_VC = 26, FW_CELL = 28 };
+// A path that has not reached its first k-mer after this many descents below level FW_BUDGET_FROM belongs to an
+// exponential family (a run of insertion sites with no variant limit to cut it): the search from that position is wound
+// up and the call refused, as in the finder (csrc/gki_finder.hip, STEP_BUDGET).
+constexpr int FW_BUDGET = 1 << 22, FW_BUDGET_FROM = 8;     // (every step of this walk reads global memory: ~1 us each)
+
+// DEEP = false: the product kernel, FMAX levels per lane in scratch.  DEEP = true: the slow path for forward windows over
+// more nodes than that (sixteen or more empty nodes before the first k-mer is complete), the same walk with its levels
+// in a global-memory arena of da.cap levels per lane (gki_forward_count grows it until the walk fits).
+template <bool EMIT, bool DEEP>
 __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, const uint8_t *__restrict__ follow,
-                             int32_t n0, int32_t o0, int64_t idx, FwdOut out, uint32_t *count_out, int *err) {
-    int32_t nd[FMAX], cur[FMAX], end[FMAX], last[FMAX];
-    uint8_t have[FMAX], vc[FMAX], forced[FMAX];
-    uint64_t hs[FMAX];
+                             int32_t n0, int32_t o0, int64_t idx, FwdOut out, uint32_t *count_out, int *err,
+                             const DeepArena &da, int64_t lane_global) {
+    typedef typename CountOf<DEEP>::T cnt_t;
+    typename StackOf<int32_t, FMAX, DEEP>::type nd, cur, end, last;
+    typename StackOf<uint8_t, FMAX, DEEP>::type have, forced;
+    typename StackOf<cnt_t, FMAX, DEEP>::type vc;
+    typename StackOf<uint64_t, FMAX, DEEP>::type hs;
+    bind(nd, da, FW_ND, lane_global); bind(cur, da, FW_CUR, lane_global); bind(end, da, FW_END, lane_global);
+    bind(last, da, FW_LAST, lane_global); bind(hs, da, FW_HS, lane_global); bind(have, da, FW_HAVE, lane_global);
+    bind(forced, da, FW_FORCED, lane_global); bind(vc, da, FW_VC, lane_global);
+    const int cap = DEEP ? da.cap : FMAX;
+    int steps_left = FW_BUDGET;
     uint32_t count = 0;
     const NodeWalk w0 = g.walk[n0];
     if (o0 < 0 || o0 > w0.size) { *count_out = 0; return; }
@@ -46,7 +64,7 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
     {
         const int avail = w0.size - o0;
         const int t = avail < k ? avail : k;
-        nd[0] = n0; vc[0] = (uint8_t)(w0.is_ref ? 0 : 1);
+        nd[0] = n0; vc[0] = (cnt_t)(w0.is_ref ? 0 : 1);
         hs[0] = t > 0 ? gki_extract(g.seq2, w0.seq_start + o0, t) : 0ull;
         have[0] = (uint8_t)t;
         cur[0] = (int32_t)g.edge_start[n0]; end[0] = (int32_t)g.edge_start[n0 + 1];
@@ -83,17 +101,17 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
             if (q == INT_MAX) { cur[j] = end[j]; continue; }
             last[j] = q;
         } else {
-            q = g.edges[cur[j]++];
+            { const int32_t cj = cur[j]; q = g.edges[cj]; cur[j] = cj + 1; }
         }
         const NodeWalk wq = g.walk[q];
         if (forced[j]) {
         } else if (vc[j] >= M && !wq.is_ref) {
             continue;                                                   // :397-403 only the linear-ref successor
         }
-        if (L >= FMAX - 1) { gki_raise(err, GKI_ERR_WINDOW_TOO_DEEP); continue; }
+        if (L >= cap - 1) { gki_raise(err, GKI_ERR_WINDOW_TOO_DEEP); continue; }
         const int hv = have[j];
         const int t = wq.size < k - hv ? wq.size : k - hv;
-        nd[L] = q; vc[L] = (uint8_t)(vc[j] + (wq.is_ref ? 0 : 1));
+        nd[L] = q; vc[L] = (cnt_t)(vc[j] + (wq.is_ref ? 0 : 1));
         hs[L] = hs[j] | (t > 0 ? gki_extract(g.seq2, wq.seq_start, t) << (2 * hv) : 0ull);
         have[L] = (uint8_t)(hv + t);
         if (hv + t == k) {                          // first k-mer of this path: emit and stop (early stop, :326-330)
@@ -134,6 +152,8 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
         last[L] = INT_MIN;
         if (!EMIT && !forced[L] && vc[L] >= M) check_one_ref_successor(g, q, err);
         L++;
+        // (out of budget: the walk ends through its ordinary exit, see STEP_BUDGET in csrc/gki_finder.hip)
+        if (L > FW_BUDGET_FROM && --steps_left < 0) { gki_raise_budget(err); L = 0; }
     }
     *count_out = count;
 }
@@ -145,19 +165,21 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
 // Then, all-nodes mode: an ascending path is written straight through instead of a selection per record: 5.0 -> 4.05 ms.
 // Tried and dropped: carrying the path's smallest node and minimum allele frequency down the walk instead of looping
 // over the path at every finished k-mer -- two more scratch stores per step cost more than the loops (5.0 -> 5.2 ms).
-template <bool EMIT>
-__global__ __launch_bounds__(64, 8) void k_forward(DevGraph g, int k, int M, int one_node, const uint8_t *__restrict__ follow,
+template <bool EMIT, bool DEEP = false>
+__global__ __launch_bounds__(64, DEEP ? 1 : 8) void k_forward(DevGraph g, int k, int M, int one_node, const uint8_t *__restrict__ follow,
                                                 const int32_t *__restrict__ nodes,
                                                 const int32_t *__restrict__ offsets, int64_t n_pos,
                                                 uint32_t *__restrict__ cnt, const int64_t *__restrict__ rec_start, FwdOut out,
-                                                int *__restrict__ err) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pos) return;
-    uint32_t c = 0;
-    const int32_t n0 = nodes[i];
-    if (n0 < 0 || n0 >= g.n_nodes) { if (!EMIT) cnt[i] = 0; return; }
-    forward_walk<EMIT>(g, k, M, one_node != 0, follow, n0, offsets[i], EMIT ? rec_start[i] : 0, out, &c, err);
-    if (!EMIT) cnt[i] = c;
+                                                int *__restrict__ err, DeepArena da) {
+    const int64_t lane_global = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // product kernel: one position per lane; slow path: the arena's lanes walk the positions grid-stride
+    for (int64_t i = lane_global; i < n_pos; i += DEEP ? da.lanes : n_pos) {
+        uint32_t c = 0;
+        const int32_t n0 = nodes[i];
+        if (n0 < 0 || n0 >= g.n_nodes) { if (!EMIT) cnt[i] = 0; continue; }
+        forward_walk<EMIT, DEEP>(g, k, M, one_node != 0, follow, n0, offsets[i], EMIT ? rec_start[i] : 0, out, &c, err, da, lane_global);
+        if (!EMIT) cnt[i] = c;
+    }
 }
 }  // namespace
 
@@ -175,22 +197,46 @@ int gki_forward_count(gki_graph *gr, int k, int max_variant_nodes, int one_node,
     HIP_TRY(gki_dev_malloc((void **)&d_err, 4));
     HIP_TRY(hipMemset(d_err, 0, 4));
     FwdOut none{nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(k_forward<false>, dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, k, max_variant_nodes > 250 ? 250 : max_variant_nodes,
-                       one_node, (const uint8_t *)d_follow, (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, cnt,
-                       (const int64_t *)nullptr, none, d_err);
-    int rc = hipGetLastError() == hipSuccess ? GKI_OK : gki_set_error(GKI_ERR_HIP, "k_forward launch failed");
-    if (rc == GKI_OK) rc = gki_scan_u32_to_i64(cnt, n_pos, (int64_t *)d_rec_start, tmp, tmp_bytes, 0);
-    int64_t total = 0; int herr = 0;
-    hipError_t e1 = hipMemcpy(&total, (const int64_t *)d_rec_start + n_pos, 8, hipMemcpyDeviceToHost);
-    hipError_t e2 = hipMemcpy(&herr, d_err, 4, hipMemcpyDeviceToHost);
+    const int M = max_variant_nodes > 250 ? 250 : max_variant_nodes;
+    gr->fwd_deep.cap = 0;                 // the product kernel first; the emit call that follows uses what this call settles on
+    int64_t total = 0; int word = 0;
+    int rc = GKI_OK;
+    hipError_t e1 = hipSuccess, e2 = hipSuccess, e3 = hipSuccess;
+    for (;;) {
+        const DeepArena da = gr->fwd_deep;
+        e3 = hipMemset(d_err, 0, 4);
+        if (da.cap > 0)
+            hipLaunchKernelGGL((k_forward<false, true>), dim3((unsigned)(da.lanes / 64)), dim3(64), 0, 0, gr->d, k, M, one_node, (const uint8_t *)d_follow,
+                               (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, cnt, (const int64_t *)nullptr, none, d_err, da);
+        else
+            hipLaunchKernelGGL((k_forward<false, false>), dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, k, M, one_node, (const uint8_t *)d_follow,
+                               (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, cnt, (const int64_t *)nullptr, none, d_err, da);
+        rc = hipGetLastError() == hipSuccess ? GKI_OK : gki_set_error(GKI_ERR_HIP, "k_forward launch failed");
+        if (rc == GKI_OK) rc = gki_scan_u32_to_i64(cnt, n_pos, (int64_t *)d_rec_start, tmp, tmp_bytes, 0);
+        e1 = hipMemcpy(&total, (const int64_t *)d_rec_start + n_pos, 8, hipMemcpyDeviceToHost);
+        e2 = hipMemcpy(&word, d_err, 4, hipMemcpyDeviceToHost);
+        if (rc != GKI_OK || e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) break;
+        // bit 1: a stack of the walk was too short -- again with the deep variant, twice the levels each time round
+        const int next_cap = da.cap == 0 ? 4 * FMAX : 2 * da.cap;
+        if (!(word & 2) || (word & 4) || next_cap > GKI_MAX_DEEP_WINDOW_NODES) break;
+        const int64_t lanes = 64 * 256, bytes = lanes * (int64_t)next_cap * FW_CELL;
+        if (bytes > gr->fwd_deep_bytes) {
+            if (gr->fwd_deep.base) (void)gki_dev_free(gr->fwd_deep.base);
+            gr->fwd_deep.base = nullptr; gr->fwd_deep_bytes = 0;
+            if (gki_dev_malloc((void **)&gr->fwd_deep.base, (size_t)bytes) != hipSuccess) { rc = gki_set_error(GKI_ERR_HIP, "forward search: no memory for %lld bytes of deep stacks", (long long)bytes); break; }
+            gr->fwd_deep_bytes = bytes;
+        }
+        gr->fwd_deep.lanes = lanes; gr->fwd_deep.cap = next_cap; gr->fwd_deep.pad = 0;
+    }
     (void)gki_dev_free(cnt); (void)gki_dev_free(tmp); (void)gki_dev_free(d_err);
     if (rc != GKI_OK) return rc;
-    HIP_TRY(e1); HIP_TRY(e2);
-    herr = gki_error_of_word(herr);
+    HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(e3);
+    const int herr = gki_error_of_word(word);
     if (herr == GKI_ERR_NOT_ONE_REF_SUCC)
         return gki_set_error(herr, "a path at the variant limit ends a node that does not have exactly one linear-ref "
                              "successor: the reference asserts here (kmer_finder.py:402)");
-    if (herr) return gki_set_error(herr, "a forward k-window crosses more than %d nodes", FMAX - 2);
+    if (herr) return gki_set_error(herr, (word & 4) ? "the paths from one start position take more than %d descents to enumerate: too many paths"
+                                   : "a forward k-window crosses more than %d nodes", (word & 4) ? FW_BUDGET : GKI_MAX_DEEP_WINDOW_NODES - 2);
     *n_records = total;
     return GKI_OK;
 }
@@ -203,9 +249,14 @@ int gki_forward_emit(gki_graph *gr, int k, int max_variant_nodes, int one_node, 
     HIP_TRY(gki_dev_malloc((void **)&d_err, 4));
     HIP_TRY(hipMemset(d_err, 0, 4));
     FwdOut out{(int64_t *)d_hashes, (int32_t *)d_start_nodes, (int16_t *)d_start_offsets, (int32_t *)d_nodes_out, (double *)d_af64};
-    hipLaunchKernelGGL(k_forward<true>, dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, k, max_variant_nodes > 250 ? 250 : max_variant_nodes,
-                       one_node, (const uint8_t *)d_follow, (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos,
-                       (uint32_t *)nullptr, (const int64_t *)d_rec_start, out, d_err);
+    const DeepArena da = gr->fwd_deep;         // cap > 0: the count call of this search needed the slow path
+    const int M = max_variant_nodes > 250 ? 250 : max_variant_nodes;
+    if (da.cap > 0)
+        hipLaunchKernelGGL((k_forward<true, true>), dim3((unsigned)(da.lanes / 64)), dim3(64), 0, 0, gr->d, k, M, one_node, (const uint8_t *)d_follow,
+                           (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, (uint32_t *)nullptr, (const int64_t *)d_rec_start, out, d_err, da);
+    else
+        hipLaunchKernelGGL((k_forward<true, false>), dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, k, M, one_node, (const uint8_t *)d_follow,
+                           (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, (uint32_t *)nullptr, (const int64_t *)d_rec_start, out, d_err, da);
     hipError_t e = hipGetLastError();
     hipError_t e2 = hipDeviceSynchronize();
     (void)gki_dev_free(d_err);

@@ -209,6 +209,7 @@ int gki_graph_create_dseq(gki_graph **out, int64_t n_nodes, const int32_t *h_nod
 int gki_graph_destroy(gki_graph *g) {
     if (!g) return GKI_OK;
     for (int i = 0; i < g->n_owned; i++) (void)hipFree(g->owned[i]);
+    if (g->fwd_deep.base) (void)gki_dev_free(g->fwd_deep.base);
     (void)hipEventDestroy(g->ev_prep0);
     (void)hipEventDestroy(g->ev_prep1);
     (void)hipStreamDestroy(g->stream);

@@ -388,6 +388,13 @@ def deep_window_cases():
                                       with_af=bool(i % 2), p_plain=float(rng.choice([0.0, 0.2, 0.6])))
             add("deep_%d_sites%d_k%d_m%d_%d" % (i, n_sites, k, m, int(one)), graph, k, only_save_one_node_per_kmer=one, max_variant_nodes=m)
             i += 1
+    # early-stop searches (find_only_kmers_starting_at_position, kmer_finder.py:170) whose first k-mer lies beyond a deep run
+    for j, (n_sites, k, m, one) in enumerate(((60, 31, 1, True), (60, 31, 2, False), (100, 20, 1, False), (150, 31, 0, True),
+                                              (150, 12, 2, False), (300, 31, 1, True))):
+        first = int(rng.integers(6, k))
+        graph = empty_chain_graph(rng, n_sites, first_ref=first, last_ref=2 * k, with_af=True, p_plain=float(rng.choice([0.0, 0.4])))
+        for off in (0, first - 1):
+            add("deep_from_position_%d_%d" % (j, off), graph, k, from_position=[0, off], only_save_one_node_per_kmer=one, max_variant_nodes=m)
     # two deep runs in one graph with ordinary bubbles between them, chunked by critical points
     for j in range(3):
         k = int(rng.choice([7, 15, 31]))
