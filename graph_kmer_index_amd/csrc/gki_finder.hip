@@ -594,24 +594,45 @@ constexpr bool EMIT_SLIM = true;     // one-node mode too: per-lane facts shuffl
 constexpr bool EMIT_SLIM = false;
 #endif
 
+// One-node mode packs what a record's lane reads about its step and about the step's node into three aligned structs --
+// one ds_read_b128 for {context, first slot}, one ds_read_b64 for {allele-frequency minimum, smallest node}, one
+// ds_read_b128 for the node's {own bases, position id} -- and every mode packs the four byte fields of a step into one
+// word: a record's lane issues 8 LDS reads where it issued 13.
+template <int FMT> struct StepA { uint64_t ctx; int64_t idx; };
+template <int FMT> struct StepB { typename MafOf<FMT>::T maf; int32_t mn; };
+struct LaneC { uint64_t own; int64_t pos0; };
+__device__ __forceinline__ uint32_t step_word(int from, int cnt, int ln, int seq) {
+    return (uint32_t)from | ((uint32_t)cnt << 8) | ((uint32_t)ln << 16) | ((uint32_t)seq << 24);
+}
+__device__ __forceinline__ int sw_from(uint32_t w) { return (int)(w & 0xFFu); }
+__device__ __forceinline__ int sw_cnt(uint32_t w) { return (int)((w >> 8) & 0xFFu); }
+__device__ __forceinline__ int sw_ln(uint32_t w) { return (int)((w >> 16) & 0xFFu); }
+__device__ __forceinline__ int sw_seq(uint32_t w) { return (int)(w >> 24); }
+
+// one-node mode: per node of the group in progress (lane l walks node base + l) its first k-1 bases and the position id
+// of (node, 0); per queued step the context register and first record slot, the allele-frequency minimum and the
+// smallest node.  (All-nodes mode leaves the per-node facts in the walking lane's registers and shuffles them at
+// expansion time; with 32-bit record slots, node lists of five and no `mn`: 40.9 KB per workgroup, a fourth per CU.)
+template <int FMT, bool PACKED> struct EvPacked {};
+template <int FMT> struct EvPacked<FMT, true> {
+    alignas(16) LaneC c[64];
+    alignas(16) StepA<FMT> a[EVQ];
+    alignas(8) StepB<FMT> b[EVQ];
+};
+
 template <int FMT, bool ALL>
-struct EvQueue {
-    // per node of the group in progress (lane l walks node base + l).  All-nodes mode leaves these three in the
-    // walking lane's registers and shuffles them at expansion time; with the 32-bit record slots, the node lists cut to
-    // five and no `mn` that is 3.2 KB per wave less LDS: 40.7 KB per workgroup, a fourth workgroup per CU.
-    uint64_t own[(ALL || EMIT_SLIM) ? 1 : 64];  // the node's first k-1 bases
-    int64_t pos0[(ALL || EMIT_SLIM) ? 1 : 64];  // position id of (node, 0)
-    int32_t n[(ALL || EMIT_SLIM) ? 1 : 64];
-    // per queued step
-    uint64_t ctx[EVQ];
-    typename IdxOf<ALL || EMIT_SLIM>::T idx[EVQ];   // first record slot of the step (all-nodes mode: relative to the node group's first)
-    typename MafOf<FMT>::T maf[EVQ];
-    int32_t mn[ALL ? 1 : EVQ];
+struct EvQueue : EvPacked<FMT, !ALL && !EMIT_SLIM> {
+    static constexpr bool PACKED = !ALL && !EMIT_SLIM;
+    // the other modes: per queued step
+    uint64_t ctx[PACKED ? 1 : EVQ];
+    typename IdxOf<true>::T idx[PACKED ? 1 : EVQ];  // first record slot of the step, relative to the node group's first
+    typename MafOf<FMT>::T maf[PACKED ? 1 : EVQ];
+    int32_t mn[(ALL || PACKED) ? 1 : EVQ];
+    uint32_t small[EVQ];         // step_word: first offset, number of windows, the lane (node) that queued the step and its
+                                 // number among that lane's queued steps
     uint8_t order[EVQ];          // slot of the step at position p of the output order
-    uint8_t ln[EVQ], seq[EVQ];   // the lane (node) that queued the step, and its number among that lane's queued steps
     alignas(8) uint8_t lbase[64];   // output position of a lane's first queued step (all-nodes mode: reused by the expansion as
                                     // eight 64-bit words of record-start marks once the output order is known)
-    uint8_t from[EVQ], cnt[EVQ];
     uint8_t nl[ALL ? EVQ : 1];                 // all-nodes mode: number of distinct window nodes of the step ...
     int32_t nodes[ALL ? EVQ : 1][NLQ];         // ... and the nodes, ascending (np.unique, kmer_finder.py:134)
     // lane-per-window expansion: the queue's windows (one per step and offset) numbered 0 .. T-1 in output order
@@ -652,7 +673,7 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
 #pragma unroll
         for (int b = 0; b < 2; b++) {
             const int e = b * 64 + lane;
-            if (e < n_ev) q.order[(int)q.lbase[q.ln[e]] + (int)q.seq[e]] = (uint8_t)e;
+            if (e < n_ev) { const uint32_t sm = q.small[e]; q.order[(int)q.lbase[sw_ln(sm)] + sw_seq(sm)] = (uint8_t)e; }
             if (ALL && e < n_ev) {
                 // the step's nodes ascending (records of a window are written per distinct node, ascending): a fixed
                 // 9-comparator network on registers, every lane the same instructions; slots >= nl count as +inf
@@ -675,7 +696,8 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
         }
         __builtin_amdgcn_wave_barrier();
     }
-    const int64_t mn_idx = (int64_t)q.idx[q.order[0]];   // smallest record slot of the queue
+    int64_t mn_idx;                                      // smallest record slot of the queue
+    if constexpr (EvQueue<FMT, ALL>::PACKED) mn_idx = q.a[q.order[0]].idx; else mn_idx = (int64_t)q.idx[q.order[0]];
     // One lane per WINDOW (= per record in one-node mode).  Half of the steps of a SNP graph hold a single window, so
     // "one step per half-wave" left two thirds of the lanes idle and the address unit paid for 6.4e7 store
     // instructions on the 3 Gbp graph (SQ_INSTS_VMEM_WR).  Here the T windows of the queue are numbered in output
@@ -684,8 +706,8 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
     // that a store instruction covers whole cache lines of every column wherever the steps are contiguous.  In
     // all-nodes mode a window has one record per distinct node: the lane writes them in turn (neighbouring lanes then
     // write `nl` records apart and the following turns fill the gaps while the lines are still in L2).
-    const int c0 = lane < n_ev ? (int)q.cnt[q.order[lane]] : 0;
-    const int c1 = lane + 64 < n_ev ? (int)q.cnt[q.order[lane + 64]] : 0;
+    const int c0 = lane < n_ev ? sw_cnt(q.small[q.order[lane]]) : 0;
+    const int c1 = lane + 64 < n_ev ? sw_cnt(q.small[q.order[lane + 64]]) : 0;
     const int s0 = gki_wave_incl_sum(c0), s1 = gki_wave_incl_sum(c1);
     // (the totals: read into a scalar register in all-nodes mode, broadcast by shuffle otherwise -- measured, same box:
     // the one-node kernel takes 2.51 ms with the scalar form and 2.22 ms with the shuffle, the all-nodes kernel 6.65 ms
@@ -706,7 +728,7 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
     if (lane < MW) q.wrank[lane] = (uint16_t)(ps - pc);
     __builtin_amdgcn_wave_barrier();
     const int shift = ALL ? 0 : (int)((mn_idx + idx_base) & 15);
-    if (!ALL && EMIT_SLIM) {
+    if constexpr (!ALL && EMIT_SLIM) {
         for (int r0 = -shift; r0 < T; r0 += 64) {
             const int r = r0 + lane;
             const bool valid = r >= 0 && r < T;
@@ -716,7 +738,8 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
                 const int sp = (int)q.wrank[w] + __popcll(q.marks[w] & ((2ull << (r & 63)) - 1ull)) - 1;
                 e = (int)q.order[sp];
                 j = r - (int)q.pre[sp];
-                o = q.from[e] + j; ln = q.ln[e];
+                const uint32_t sm = q.small[e];
+                o = sw_from(sm) + j; ln = sw_ln(sm);
             }
             const uint64_t own_v = (uint64_t)__shfl((unsigned long long)own_reg, ln, 64);
             const int64_t pos0_v = (int64_t)__shfl((long long)pos0_reg, ln, 64);
@@ -726,7 +749,7 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
                 put(out, idx_base + (int64_t)q.idx[e] + j, h, q.mn[e], n_v, o, pos0_v + o, (double)q.maf[e]);
             }
         }
-    } else if (!ALL) {
+    } else if constexpr (!ALL) {
         for (int r0 = -shift; r0 < T; r0 += 64) {
             const int r = r0 + lane;
             if (r >= 0 && r < T) {
@@ -734,9 +757,13 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
                 const int sp = (int)q.wrank[w] + __popcll(q.marks[w] & ((2ull << (r & 63)) - 1ull)) - 1;
                 const int e = (int)q.order[sp];
                 const int j = r - (int)q.pre[sp];
-                const int o = q.from[e] + j, ln = q.ln[e];
-                const uint64_t h = ((q.ctx[e] >> (2 * o)) | (q.own[ln] << (2 * (k - 1 - o)))) & kmask;
-                put(out, GKI_DBG_SLOT((int64_t)q.idx[e] + j), h, q.mn[e], q.n[ln], o, q.pos0[ln] + o, (double)q.maf[e]);
+                const uint32_t sm = q.small[e];
+                const int o = sw_from(sm) + j, ln = sw_ln(sm);
+                const StepA<FMT> sa = q.a[e];
+                const StepB<FMT> sb = q.b[e];
+                const LaneC lc = q.c[ln];
+                const uint64_t h = ((sa.ctx >> (2 * o)) | (lc.own << (2 * (k - 1 - o)))) & kmask;
+                put(out, GKI_DBG_SLOT(sa.idx + j), h, sb.mn, n_reg - lane + ln, o, lc.pos0 + o, (double)sb.maf);
             }
         }
     } else {
@@ -752,7 +779,8 @@ __device__ __forceinline__ void expand_queue(EvQueue<FMT, ALL> &q, int n_ev, int
                 const int sp = (int)q.wrank[w] + __popcll(q.marks[w] & ((2ull << (r & 63)) - 1ull)) - 1;
                 e = (int)q.order[sp];
                 j = r - (int)q.pre[sp];
-                o = q.from[e] + j; ln = q.ln[e];
+                const uint32_t sm = q.small[e];
+                o = sw_from(sm) + j; ln = sw_ln(sm);
             }
             const uint64_t own_v = (uint64_t)__shfl((unsigned long long)own_reg, ln, 64);
             const int64_t pos0_v = (int64_t)__shfl((long long)pos0_reg, ln, 64);
@@ -905,7 +933,7 @@ __global__ __launch_bounds__(256, (EMIT_SLIM && !GEN && !ALL && !HAS_LOSSY && FM
                     t_mn = (int32_t)n; t_maf = FMT == 1 ? g.allele_freq[n] : (double)wn.af;   // float32 rounding is monotonic:
                     // the minimum of the rounded values is the rounded minimum (flat layout), v2 keeps float64
                     own = gki_extract(g.seq2, wn.seq_start, hi);
-                    if (!ALL && !EMIT_SLIM) { q.own[lane] = own; q.pos0[lane] = pos0; q.n[lane] = (int32_t)n; }
+                    if constexpr (EvQueue<FMT, ALL>::PACKED) { LaneC lc; lc.own = own; lc.pos0 = pos0; q.c[lane] = lc; }
                     if (ALL || GEN) path[0] = (int32_t)n;
                     t_a = nonfree0 ? v0 : 0;
                     L = 1;
@@ -1080,11 +1108,16 @@ __global__ __launch_bounds__(256, (EMIT_SLIM && !GEN && !ALL && !HAS_LOSSY && FM
                 }
                 if (ev) {
                     const int slot = n_ev + __popcll(pending & lt_mask);
-                    q.ln[slot] = (uint8_t)lane; q.seq[slot] = (uint8_t)my_cnt++;
-                    q.ctx[slot] = e_ctx; q.idx[slot] = (typename IdxOf<ALL || EMIT_SLIM>::T)(idx - idx_base);
-                    q.maf[slot] = (typename MafOf<FMT>::T)e_maf;
-                    if (!ALL) q.mn[slot] = e_mn;
-                    q.from[slot] = (uint8_t)e_from; q.cnt[slot] = (uint8_t)(e_to - e_from);
+                    q.small[slot] = step_word(e_from, e_to - e_from, lane, my_cnt++);
+                    if constexpr (EvQueue<FMT, ALL>::PACKED) {
+                        StepA<FMT> sa; sa.ctx = e_ctx; sa.idx = idx;
+                        StepB<FMT> sb; sb.maf = (typename MafOf<FMT>::T)e_maf; sb.mn = e_mn;
+                        q.a[slot] = sa; q.b[slot] = sb;
+                    } else {
+                        q.ctx[slot] = e_ctx; q.idx[slot] = (typename IdxOf<true>::T)(idx - idx_base);
+                        q.maf[slot] = (typename MafOf<FMT>::T)e_maf;
+                        if (!ALL) q.mn[slot] = e_mn;
+                    }
                     if (ALL) {
                         q.nl[slot] = (uint8_t)e_nls;
                         const bool filt = GEN && a.store;
