@@ -1584,90 +1584,90 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
     int64_t *tot = f->h_totals;       // pinned host memory: the two small copies are true async DMAs
     unsigned long long bsum = 0;
     for (;;) {
-    HIP_TRY(hipMemsetAsync(f->d_err, 0, 4, s));
-    HIP_TRY(hipMemsetAsync(f->d_bsum, 0, 8, s));
+        HIP_TRY(hipMemsetAsync(f->d_err, 0, 4, s));
+        HIP_TRY(hipMemsetAsync(f->d_bsum, 0, 8, s));
 
-    HIP_TRY(hipEventRecord(f->ev[0], s));
-    if (n_run > 0) {
-        // one group of 256 nodes per workgroup, no grid-stride loop: with 2048 workgroups of 29 groups each (7 fit a CU,
-        // an eighth waits) the pass took 0.70 ms, with one group each 0.59 (GKI_CNT_BLOCKS sweeps it in tuning builds)
-        const int64_t want = ceil_div(n_run, 256), cap = GKI_KNOB("GKI_CNT_BLOCKS", 1 << 30);
-        const int count_grid = (int)(want < cap ? want : cap);
-        const int cnt_pad = GKI_KNOB("GKI_CNT_LDS_PAD", 0);   // tuning builds: unused dynamic LDS, to lower the occupancy
-        const DeepArena da = f->deep;
-        if (da.cap > 0) {
-            const dim3 dgrid((unsigned)(da.lanes / 256));
-            if (a.nflags && a.has_lossy)
-                hipLaunchKernelGGL((k_count_boundary<true, true, true>), dgrid, dim3(256), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
+        HIP_TRY(hipEventRecord(f->ev[0], s));
+        if (n_run > 0) {
+            // one group of 256 nodes per workgroup, no grid-stride loop: with 2048 workgroups of 29 groups each (7 fit a CU,
+            // an eighth waits) the pass took 0.70 ms, with one group each 0.59 (GKI_CNT_BLOCKS sweeps it in tuning builds)
+            const int64_t want = ceil_div(n_run, 256), cap = GKI_KNOB("GKI_CNT_BLOCKS", 1 << 30);
+            const int count_grid = (int)(want < cap ? want : cap);
+            const int cnt_pad = GKI_KNOB("GKI_CNT_LDS_PAD", 0);   // tuning builds: unused dynamic LDS, to lower the occupancy
+            const DeepArena da = f->deep;
+            if (da.cap > 0) {
+                const dim3 dgrid((unsigned)(da.lanes / 256));
+                if (a.nflags && a.has_lossy)
+                    hipLaunchKernelGGL((k_count_boundary<true, true, true>), dgrid, dim3(256), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
+                else if (a.nflags)
+                    hipLaunchKernelGGL((k_count_boundary<false, true, true>), dgrid, dim3(256), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
+                else if (a.has_lossy)
+                    hipLaunchKernelGGL((k_count_boundary<true, false, true>), dgrid, dim3(256), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
+                else
+                    hipLaunchKernelGGL((k_count_boundary<false, false, true>), dgrid, dim3(256), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
+            }
+            else if (a.nflags && a.has_lossy)
+                hipLaunchKernelGGL((k_count_boundary<true, true>), dim3(count_grid), dim3(256), cnt_pad, s, d, a, f->lossy,
+                                   f->bcount, f->total, f->d_err, da);
             else if (a.nflags)
-                hipLaunchKernelGGL((k_count_boundary<false, true, true>), dgrid, dim3(256), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
+                hipLaunchKernelGGL((k_count_boundary<false, true>), dim3(count_grid), dim3(256), cnt_pad, s, d, a, f->lossy,
+                                   f->bcount, f->total, f->d_err, da);
             else if (a.has_lossy)
-                hipLaunchKernelGGL((k_count_boundary<true, false, true>), dgrid, dim3(256), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
+                hipLaunchKernelGGL((k_count_boundary<true, false>), dim3(count_grid), dim3(256), cnt_pad, s, d, a, f->lossy,
+                                   f->bcount, f->total, f->d_err, da);
             else
-                hipLaunchKernelGGL((k_count_boundary<false, false, true>), dgrid, dim3(256), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
+                hipLaunchKernelGGL((k_count_boundary<false, false>), dim3(count_grid), dim3(256), cnt_pad, s, d, a, f->lossy,
+                                   f->bcount, f->total, f->d_err, da);
+            HIP_TRY(hipGetLastError());
         }
-        else if (a.nflags && a.has_lossy)
-            hipLaunchKernelGGL((k_count_boundary<true, true>), dim3(count_grid), dim3(256), cnt_pad, s, d, a, f->lossy,
-                               f->bcount, f->total, f->d_err, da);
-        else if (a.nflags)
-            hipLaunchKernelGGL((k_count_boundary<false, true>), dim3(count_grid), dim3(256), cnt_pad, s, d, a, f->lossy,
-                               f->bcount, f->total, f->d_err, da);
-        else if (a.has_lossy)
-            hipLaunchKernelGGL((k_count_boundary<true, false>), dim3(count_grid), dim3(256), cnt_pad, s, d, a, f->lossy,
-                               f->bcount, f->total, f->d_err, da);
-        else
-            hipLaunchKernelGGL((k_count_boundary<false, false>), dim3(count_grid), dim3(256), cnt_pad, s, d, a, f->lossy,
-                               f->bcount, f->total, f->d_err, da);
-        HIP_TRY(hipGetLastError());
-    }
-    HIP_TRY(hipEventRecord(f->ev[1], s));
-    HIP_TRY(hipEventRecord(f->ev[6], s));
-    // records of nodes [n0, n1) only: rec_base[n0 + i] = exclusive prefix inside the run, rec_base[n1] = total
-    GKI_TRY(gki_scan_u32_to_i64(f->total + a.n0, n_run, f->rec_base + a.n0, f->scan_tmp, f->scan_tmp_bytes, s));
-    if (a.split)
-        GKI_TRY(gki_scan_u32_to_i64(f->bcount + a.n0, n_run, f->bnd_base + a.n0, f->scan_tmp, f->scan_tmp_bytes, s));
-    if (n_run > 0) {
-        // one node per thread, no grid-stride loop: a thread's loads and its 48-byte store form one dependent chain, so the
-        // kernel lives on the number of chains in flight
-        hipLaunchKernelGGL(k_node_emit, dim3((unsigned)ceil_div(n_run, 256)), dim3(256), 0, s, d, a, f->lossy, f->bcount,
-                           f->rec_base, f->ne);
-        HIP_TRY(hipGetLastError());
-    }
-    if (n_run > 0 && !a.split) {
-        hipLaunchKernelGGL(k_sum_u32, dim3(stream_grid(n_run, 256)), dim3(256), 0, s, f->bcount + a.n0, n_run, f->d_bsum);
-        HIP_TRY(hipGetLastError());
-    }
-    hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, s, f->rec_base, f->bnd_base, a.n1, a.split, f->d_err, f->d_totals);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(f->ev[7], s));
-    HIP_TRY(hipMemcpyAsync(tot, f->d_totals, 32, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(tot + 4, f->d_bsum, 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    bsum = (unsigned long long)tot[4];
-    const int run_err = gki_error_of_word(tot[1]);
-    if (run_err == GKI_ERR_NOT_ONE_REF_SUCC && !(tot[1] & 2))
-        return gki_set_error(GKI_ERR_NOT_ONE_REF_SUCC, "a window at the variant limit ends a node that does not have exactly one "
-                             "linear-ref successor: the reference asserts here (kmer_finder.py:402); raise max_variant_nodes");
-    if (run_err == GKI_OK) break;
-    // GKI_ERR_WINDOW_TOO_DEEP.  Bit 1 of the word: a stack of the walk (or of a history) was too short -- the slow path:
-    // the pass again with the deep kernel variants, their stacks in an arena of twice the levels each time round.
-    // Bit 2: a history enumeration ran out of its step budget, which no depth cures.
-    const int next_cap = f->deep.cap == 0 ? 4 * MAXN : 2 * f->deep.cap;
-    if ((tot[1] & 4) || !(tot[1] & 2) || next_cap > GKI_MAX_DEEP_WINDOW_NODES)
-        return gki_set_error(GKI_ERR_WINDOW_TOO_DEEP, (tot[1] & 4) ? "the k-windows ending in one node (or the histories that decide one of them) take more "
-                             "than %d descents to enumerate: too many paths" : "a k-window (or the history that decides it) crosses more than %d nodes",
-                             (tot[1] & 4) ? STEP_BUDGET : GKI_MAX_DEEP_WINDOW_NODES - 2);
-    {
-        // 64 workgroups walk the run (grid-stride): 16 384 lanes x cap levels x 70 bytes = 0.3 GB at the first cap
-        const int64_t lanes = 64 * 256, bytes = lanes * (int64_t)next_cap * DA_CELL;
-        if (bytes > f->deep_bytes) {
-            if (f->deep.base) HIP_TRY(gki_dev_free(f->deep.base));
-            f->deep.base = nullptr; f->deep_bytes = 0;
-            HIP_TRY(gki_dev_malloc((void **)&f->deep.base, (size_t)bytes));
-            f->deep_bytes = bytes;
+        HIP_TRY(hipEventRecord(f->ev[1], s));
+        HIP_TRY(hipEventRecord(f->ev[6], s));
+        // records of nodes [n0, n1) only: rec_base[n0 + i] = exclusive prefix inside the run, rec_base[n1] = total
+        GKI_TRY(gki_scan_u32_to_i64(f->total + a.n0, n_run, f->rec_base + a.n0, f->scan_tmp, f->scan_tmp_bytes, s));
+        if (a.split)
+            GKI_TRY(gki_scan_u32_to_i64(f->bcount + a.n0, n_run, f->bnd_base + a.n0, f->scan_tmp, f->scan_tmp_bytes, s));
+        if (n_run > 0) {
+            // one node per thread, no grid-stride loop: a thread's loads and its 48-byte store form one dependent chain, so the
+            // kernel lives on the number of chains in flight
+            hipLaunchKernelGGL(k_node_emit, dim3((unsigned)ceil_div(n_run, 256)), dim3(256), 0, s, d, a, f->lossy, f->bcount,
+                               f->rec_base, f->ne);
+            HIP_TRY(hipGetLastError());
         }
-        f->deep.lanes = lanes; f->deep.cap = next_cap; f->deep.pad = 0;
-    }
+        if (n_run > 0 && !a.split) {
+            hipLaunchKernelGGL(k_sum_u32, dim3(stream_grid(n_run, 256)), dim3(256), 0, s, f->bcount + a.n0, n_run, f->d_bsum);
+            HIP_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, s, f->rec_base, f->bnd_base, a.n1, a.split, f->d_err, f->d_totals);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(f->ev[7], s));
+        HIP_TRY(hipMemcpyAsync(tot, f->d_totals, 32, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(tot + 4, f->d_bsum, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        bsum = (unsigned long long)tot[4];
+        const int run_err = gki_error_of_word(tot[1]);
+        if (run_err == GKI_ERR_NOT_ONE_REF_SUCC && !(tot[1] & 2))
+            return gki_set_error(GKI_ERR_NOT_ONE_REF_SUCC, "a window at the variant limit ends a node that does not have exactly one "
+                                 "linear-ref successor: the reference asserts here (kmer_finder.py:402); raise max_variant_nodes");
+        if (run_err == GKI_OK) break;
+        // GKI_ERR_WINDOW_TOO_DEEP.  Bit 1 of the word: a stack of the walk (or of a history) was too short -- the slow path:
+        // the pass again with the deep kernel variants, their stacks in an arena of twice the levels each time round.
+        // Bit 2: a history enumeration ran out of its step budget, which no depth cures.
+        const int next_cap = f->deep.cap == 0 ? 4 * MAXN : 2 * f->deep.cap;
+        if ((tot[1] & 4) || !(tot[1] & 2) || next_cap > GKI_MAX_DEEP_WINDOW_NODES)
+            return gki_set_error(GKI_ERR_WINDOW_TOO_DEEP, (tot[1] & 4) ? "the k-windows ending in one node (or the histories that decide one of them) take more "
+                                 "than %d descents to enumerate: too many paths" : "a k-window (or the history that decides it) crosses more than %d nodes",
+                                 (tot[1] & 4) ? STEP_BUDGET : GKI_MAX_DEEP_WINDOW_NODES - 2);
+        {
+            // 64 workgroups walk the run (grid-stride): 16 384 lanes x cap levels x 70 bytes = 0.3 GB at the first cap
+            const int64_t lanes = 64 * 256, bytes = lanes * (int64_t)next_cap * DA_CELL;
+            if (bytes > f->deep_bytes) {
+                if (f->deep.base) HIP_TRY(gki_dev_free(f->deep.base));
+                f->deep.base = nullptr; f->deep_bytes = 0;
+                HIP_TRY(gki_dev_malloc((void **)&f->deep.base, (size_t)bytes));
+                f->deep_bytes = bytes;
+            }
+            f->deep.lanes = lanes; f->deep.cap = next_cap; f->deep.pad = 0;
+        }
     }
     if (a.split) bsum = (unsigned long long)tot[2];
     f->n_records = tot[0];
