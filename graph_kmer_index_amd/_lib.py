@@ -24,6 +24,12 @@ class NotOneLinearRefSuccessor(GkiError, AssertionError):
     """GKI_ERR_NOT_ONE_REF_SUCC: where the reference's `assert len(next_nodes) == 1` fails (kmer_finder.py:402)."""
 
 
+class WindowTooDeep(GkiError, RecursionError):
+    """GKI_ERR_WINDOW_TOO_DEEP: a k-window over more nodes than the kernels' slow path holds, or more paths into one end
+    node than it will enumerate.  The reference ends such a search in a RecursionError (its search recurses per node under
+    sys.setrecursionlimit(20000), kmer_finder.py:7, and re-raises :234-241), so a caller that catches that catches this."""
+
+
 class FindParams(C.Structure):
     """gki_find_params (include/gki.h); struct_size is filled in by the constructor."""
     _fields_ = [("struct_size", C.c_uint32), ("k", C.c_int32), ("max_variant_nodes", C.c_int32),
@@ -150,7 +156,7 @@ def load():
 
 def check(code):
     if code != 0:
-        cls = NotOneLinearRefSuccessor if code == 7 else GkiError
+        cls = NotOneLinearRefSuccessor if code == 7 else WindowTooDeep if code == 4 else GkiError
         raise cls(code, load().gki_last_error().decode("utf-8", "replace"))
 
 

@@ -36,7 +36,8 @@ extern "C" {
                                      variant limit ends a node that does not have exactly one linear-ref successor */
 
 #define GKI_MAX_WINDOW_NODES 48        /* stacks of the product kernels (scratch) */
-#define GKI_MAX_DEEP_WINDOW_NODES 6144 /* stacks of the finder's slow path (a global-memory arena, grown 192, 384, ... levels) */
+#define GKI_MAX_DEEP_WINDOW_NODES 12288 /* stacks of the slow path (a global-memory arena, grown 192, 384, ... levels): beyond
+                                          the ~9 990 nodes at which the reference's own recursion ends in a RecursionError */
 #define GKI_MAX_K 31             /* kmer_hashing.py:25 `assert k <= 31` */
 
 /* ---------------------------------------------------------------- runtime */
