@@ -50,7 +50,8 @@ def search_roots(g, k):
 def classify_nodes(g, k, max_variant_nodes, only_follow_nodes=None, critical_nodes=None, on_device=None, always_flags=True):
     """(uint16[n_nodes] GKI_NODE_* flags | history bound << 8, general) -- gki_classify_nodes (include/gki.h): which nodes the order-free
     form of the variant limit (kmer_finder.py:383-417) can stop at when it looks for a history (on the device by
-    relaxation sweeps, gki_graph_classify_nodes; the host pass takes over without a device and for nested non-free nodes).  `general` False
+    relaxation sweeps and history rounds, gki_graph_classify_nodes; the host pass takes over without a device or beyond that
+    call's stack / budget).  `general` False
     means "at most max_variant_nodes variant nodes in the window" is the whole rule for this graph and the kernels run
     without the flags.  Host pass in topological order; kept on the graph object per (k, limit, follow set)."""
     follow = None
@@ -77,7 +78,7 @@ def classify_nodes(g, k, max_variant_nodes, only_follow_nodes=None, critical_nod
             _lib.check(_lib.load().gki_graph_classify_nodes(
                 DeviceGraph.of(g).handle, _lib.hptr(follow), _lib.hptr(roots), len(roots), int(k), M, _lib.hptr(flags),
                 int(bool(always_flags)), C.byref(general), C.byref(needs_host)))
-        if needs_host.value:                         # no device, or a nested non-free node: the host pass decides its history
+        if needs_host.value:                         # no device, or histories beyond the device call's stack / budget: the host pass
             _lib.check(_lib.load().gki_classify_nodes(
                 g.n_nodes, _lib.hptr(g.node_size), _lib.hptr(g.edge_start), _lib.hptr(g.edges), _lib.hptr(g.rev_start),
                 _lib.hptr(g.rev_edges), _lib.hptr(g.is_ref), _lib.hptr(follow), _lib.hptr(roots), len(roots), int(k),

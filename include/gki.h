@@ -211,9 +211,11 @@ int64_t gki_find_params_size(void);
 
 /* gki_classify_nodes on the device, over a resident graph (csrc/gki_classify.hip): the classes are a least fixed point
  * ("entered" spreads from the search roots, the linear-ref run before a node and the variant bound only grow), reached
- * by relaxation sweeps instead of one pass in topological order.  *needs_host = 1 when the call cannot finish the job --
- * the fixed point holds a nested non-free node, whose admissible-history question is the host pass's deep enumeration,
- * or a dependency chain outlasts the sweep budget -- then nothing is written and the caller runs gki_classify_nodes.
+ * by relaxation sweeps instead of one pass in topological order; whether a nested non-free node has an admissible history
+ * is enumerated on the device as well, in rounds with the relaxation (a node without one is dead, which takes histories
+ * away from the nodes after it).  *needs_host = 1 when the call cannot finish the job -- a history deeper than 64 nodes
+ * or longer than 2^20 steps, more than 48 rounds, or a dependency chain that outlasts the sweep budget -- then nothing
+ * is written and the caller runs gki_classify_nodes.
  * h_out_flags (host uint16[n_nodes] or NULL) is filled when the graph is general, or always with always_copy_flags. */
 int gki_graph_classify_nodes(gki_graph *g, const uint8_t *h_follow, const int32_t *h_roots, int n_roots, int k,
                              int max_variant_nodes, uint16_t *h_out_flags, int always_copy_flags, int32_t *general,

@@ -1,7 +1,8 @@
 """gki_graph_classify_nodes (relaxation sweeps on the device, csrc/gki_classify.hip) against the host pass in
 topological order (gki_classify_nodes): same flag words, same `general` verdict, on every graph family of the suite,
-with and without forced successors, for every limit -- and the hand-over to the host pass where a nested non-free node
-needs its histories enumerated."""
+with and without forced successors, for every limit -- including the graphs where a nested non-free node needs its
+histories enumerated (rounds of relaxation and k_cls_history on the device; the host pass only beyond the kernel's
+stack)."""
 import ctypes as C
 import numpy as np
 import pytest
@@ -13,6 +14,7 @@ from graphgen import random_bubble_graph, nested_bubble_graph, deep_nested_graph
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
+GKI_REF, GKI_FORCED, GKI_T, GKI_SIMPLE, GKI_NESTED, GKI_CHECK, GKI_HFS, GKI_DEAD = (1 << i for i in range(8))   # include/gki.h GKI_NODE_*
 
 
 def device_only(g, k, M, follow, crit):
@@ -32,7 +34,7 @@ def device_only(g, k, M, follow, crit):
 
 def test_random_graphs_equal_the_host_pass():
     rng = np.random.default_rng(44)
-    n_dev = n_host = 0
+    n_dev = n_host = n_hist = 0
     for it in range(500):
         kind = it % 5
         k = int(rng.integers(2, 14))
@@ -59,6 +61,11 @@ def test_random_graphs_equal_the_host_pass():
             follow = set(int(x) for x in rng.choice(cand, size=min(len(cand), int(rng.integers(1, 3))), replace=False)) if cand else None
         want_flags, want_general = classify_nodes(g, k, M, follow, crit, on_device=False)
         flags, general, needs = device_only(g, k, M, follow, crit)
+        # graphs with a nested non-free node (its histories are enumerated: round 3 on the device, k_cls_history)
+        low = want_flags & 0xFF
+        nonfree = (low & (GKI_REF | GKI_FORCED)) == 0
+        if M >= 1 and np.any(nonfree & ((low & GKI_NESTED) != 0) | (nonfree & ((low & GKI_DEAD) != 0) & (g.rev_start[1:] > g.rev_start[:-1]))):
+            n_hist += 1
         if needs:
             n_host += 1
             # the public entry point hands over and still equals the host pass
@@ -68,7 +75,7 @@ def test_random_graphs_equal_the_host_pass():
         n_dev += 1
         assert general == want_general, (it, k, M, follow)
         assert np.array_equal(flags, want_flags), (it, k, M, follow, flags.tolist(), want_flags.tolist())
-    assert n_dev > 250 and n_host > 20, (n_dev, n_host)
+    assert n_dev > 300 and n_host <= 3 and n_hist > 20, (n_dev, n_host, n_hist)
 
 
 @pytest.mark.parametrize("make,expect_general", [
