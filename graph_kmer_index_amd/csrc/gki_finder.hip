@@ -1388,8 +1388,15 @@ static int launch_boundary_fmt(gki_finder *f, const DevGraph &d, const FindArgs 
     }
 #endif
     const int bnd_blocks = GKI_KNOB("GKI_BND_BLOCKS", 0);
-    int gb = stream_grid(a.n1 - a.n0, 256);
-    if (bnd_blocks > 0 && gb > bnd_blocks) gb = bnd_blocks;
+    // One workgroup per group of 256 nodes (two in all-nodes mode), as many workgroups as that takes: the hardware hands
+    // a finished CU its next workgroup, so the walk's uneven node groups balance themselves.  With 2048 workgroups walking
+    // the groups grid-stride (rounds 1-2) the kernel waited for its slowest workgroups: same box, whole graph 2.52 -> 2.31 ms,
+    // all-nodes 6.95 -> 5.89 ms, one rank's shard of eight 0.39 -> 0.35 ms (tools/exp/bnd_grid.sh,
+    // profiles/r03_boundary_grid_ab.txt).  Tuning builds: GKI_BND_BLOCKS = g > 0 caps the grid, -g = g groups per workgroup.
+    int gb = (int)ceil_div(a.n1 - a.n0, 256 * (int64_t)(a.one_node ? 1 : 2));
+    if (bnd_blocks > 0) { gb = stream_grid(a.n1 - a.n0, 256); if (gb > bnd_blocks) gb = bnd_blocks; }
+    if (bnd_blocks < 0) gb = (int)ceil_div(a.n1 - a.n0, 256 * (int64_t)(-bnd_blocks));
+    if (gb < 1) gb = 1;
     const dim3 grid(gb), block(256);
     // split layout: boundary block of node n starts at (number of interior records) + bnd_base[n]
     const int64_t *base = a.split ? f->bnd_base : f->rec_base;
