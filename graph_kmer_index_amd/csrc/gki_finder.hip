@@ -854,16 +854,25 @@ struct LevelEmitT {              // a suspended level of the emit walk
 static_assert(sizeof(LevelEmitT<false>) == 32 && sizeof(LevelEmitT<true>) <= DA_PATH - DA_BELOW && sizeof(LevelLoT<true>) <= DA_PATH - DA_BELOW,
               "a level of the product kernels is 32 bytes; the deep variants' levels fit their arena cell");
 
+// Workgroups of ONE wave: the waves of this kernel never talk to each other (each has its own queue and walk cache), so
+// the workgroup is only the unit the hardware schedules -- and the smaller that unit, the better the uneven node groups
+// balance over the CUs.  Same LDS per wave, same 16 waves per CU.  One-node 2.23 -> 2.13 ms same-box, one rank's shard
+// of eight 0.330 -> 0.311 ms, all-nodes unchanged within its noise (profiles/r03_boundary_grid_ab.txt); two waves per
+// workgroup: half of that.  (-DGKI_BND_WPB=4: the workgroups of rounds 1-3.)
+#ifndef GKI_BND_WPB
+#define GKI_BND_WPB 1
+#endif
+constexpr int BND_WPB = GKI_BND_WPB;      // waves (groups of 64 nodes) per workgroup of the emit kernel
 template <bool HAS_LOSSY, int FMT, bool ALL, bool GEN, bool DEEP = false>
 // (general one-node variants in the flat layouts: LDS allows 4 workgroups per CU; without the request they take 129 VGPRs)
-__global__ __launch_bounds__(256, (EMIT_SLIM && !GEN && !ALL && !HAS_LOSSY && FMT != 1) ? 5 : (GEN && !ALL && FMT != 1 && !DEEP) ? 4 : 1) void k_emit_boundary_one(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
+__global__ __launch_bounds__(64 * BND_WPB, (EMIT_SLIM && !GEN && !ALL && !HAS_LOSSY && FMT != 1) ? 5 : (GEN && !ALL && FMT != 1 && !DEEP) ? 4 : 1) void k_emit_boundary_one(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
                                                            const uint32_t *__restrict__ bcount,
                                                            const int64_t *__restrict__ rec_base,
                                                            const int64_t *__restrict__ bnd_shift,
                                                            typename OutSel<FMT>::T out, int *__restrict__ err, DeepArena da) {
     typedef WalkCacheT<(!ALL && !EMIT_SLIM) || GEN || HAS_LOSSY> WCache;      // the flag words only where they are read (or LDS is not the limit)
-    __shared__ EvQueue<FMT, ALL> s_q[4];
-    __shared__ WCache s_wc[4];
+    __shared__ EvQueue<FMT, ALL> s_q[BND_WPB];
+    __shared__ WCache s_wc[BND_WPB];
     typedef LevelEmitT<DEEP> LevelEmit;
     typedef typename CountOf<DEEP>::T cnt_t;
     const int64_t lane_global = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (deep variant: the lane's column of the arena)
@@ -1353,7 +1362,7 @@ static int launch_boundary_mode(gki_finder *f, const DevGraph &d, const FindArgs
     if (da.cap > 0) {
         // the count pass met a window deeper than the product kernels' stacks: the same kernels with their stacks in the
         // arena, on the grid the arena was sized for
-        const dim3 dgrid((unsigned)(da.lanes / 256));
+        const dim3 dgrid((unsigned)(da.lanes / (64 * BND_WPB)));
         if (a.nflags && a.has_lossy)
             hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, true, true>), dgrid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err, da);
         else if (a.nflags)
@@ -1388,16 +1397,16 @@ static int launch_boundary_fmt(gki_finder *f, const DevGraph &d, const FindArgs 
     }
 #endif
     const int bnd_blocks = GKI_KNOB("GKI_BND_BLOCKS", 0);
-    // One workgroup per group of 256 nodes (two in all-nodes mode), as many workgroups as that takes: the hardware hands
+    // One workgroup per group of nodes (64 * BND_WPB; two groups in all-nodes mode), as many workgroups as that takes: the hardware hands
     // a finished CU its next workgroup, so the walk's uneven node groups balance themselves.  With 2048 workgroups walking
     // the groups grid-stride (rounds 1-2) the kernel waited for its slowest workgroups: same box, whole graph 2.52 -> 2.31 ms,
     // all-nodes 6.95 -> 5.89 ms, one rank's shard of eight 0.39 -> 0.35 ms (tools/exp/bnd_grid.sh,
     // profiles/r03_boundary_grid_ab.txt).  Tuning builds: GKI_BND_BLOCKS = g > 0 caps the grid, -g = g groups per workgroup.
-    int gb = (int)ceil_div(a.n1 - a.n0, 256 * (int64_t)(a.one_node ? 1 : 2));
+    int gb = (int)ceil_div(a.n1 - a.n0, 64 * BND_WPB * (int64_t)(a.one_node ? 1 : 2));
     if (bnd_blocks > 0) { gb = stream_grid(a.n1 - a.n0, 256); if (gb > bnd_blocks) gb = bnd_blocks; }
     if (bnd_blocks < 0) gb = (int)ceil_div(a.n1 - a.n0, 256 * (int64_t)(-bnd_blocks));
     if (gb < 1) gb = 1;
-    const dim3 grid(gb), block(256);
+    const dim3 grid(gb), block(64 * BND_WPB);
     // split layout: boundary block of node n starts at (number of interior records) + bnd_base[n]
     const int64_t *base = a.split ? f->bnd_base : f->rec_base;
     const int64_t *shift = a.split ? f->rec_base + a.n1 : f->d_totals + 3;
