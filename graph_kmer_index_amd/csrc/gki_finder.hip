@@ -418,11 +418,15 @@ __device__ __forceinline__ int stored_nodes(const uint8_t *__restrict__ store, P
 // needs 100 VGPRs unconstrained (4 waves per SIMD; the others 53-55 = 8) -- held to 64 it spills ~30 values around the
 // history_ok call and is still faster at every step: 1.27 / 1.11 / 0.99 / 0.95 / 0.94 ms at 4 / 5 / 6 / 7 / 8 waves on the
 // 3 Gbp SNP graph, 2.19 / 1.88 / 1.70 / 1.66 / 1.64 ms with 20 % nested sites (tools/exp/ab_libs.sh, same box).
+#ifndef GKI_CNT_WPB
+#define GKI_CNT_WPB 1
+#endif
+constexpr int CNT_WPB = GKI_CNT_WPB;      // waves per workgroup of the count kernel (independent waves: see BND_WPB)
 template <bool HAS_LOSSY, bool GEN, bool DEEP = false>
-__global__ __launch_bounds__(256, (GEN && !DEEP) ? 8 : 1) void k_count_boundary(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
+__global__ __launch_bounds__(64 * CNT_WPB, (GEN && !DEEP) ? 8 : 1) void k_count_boundary(DevGraph g, FindArgs a, const uint16_t *__restrict__ lossy,
                                                         uint32_t *__restrict__ bcount, uint32_t *__restrict__ total,
                                                         int *__restrict__ err, DeepArena da) {
-    __shared__ WalkCache s_wc[4];
+    __shared__ WalkCache s_wc[CNT_WPB];
     typedef LevelLoT<DEEP> LevelLo;
     typedef typename CountOf<DEEP>::T cnt_t;
     const int64_t lane_global = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (deep variant: the lane's column of the arena)
@@ -1607,32 +1611,32 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
         if (n_run > 0) {
             // one group of 256 nodes per workgroup, no grid-stride loop: with 2048 workgroups of 29 groups each (7 fit a CU,
             // an eighth waits) the pass took 0.70 ms, with one group each 0.59 (GKI_CNT_BLOCKS sweeps it in tuning builds)
-            const int64_t want = ceil_div(n_run, 256), cap = GKI_KNOB("GKI_CNT_BLOCKS", 1 << 30);
+            const int64_t want = ceil_div(n_run, 64 * CNT_WPB), cap = GKI_KNOB("GKI_CNT_BLOCKS", 1 << 30);
             const int count_grid = (int)(want < cap ? want : cap);
             const int cnt_pad = GKI_KNOB("GKI_CNT_LDS_PAD", 0);   // tuning builds: unused dynamic LDS, to lower the occupancy
             const DeepArena da = f->deep;
             if (da.cap > 0) {
-                const dim3 dgrid((unsigned)(da.lanes / 256));
+                const dim3 dgrid((unsigned)(da.lanes / (64 * CNT_WPB)));
                 if (a.nflags && a.has_lossy)
-                    hipLaunchKernelGGL((k_count_boundary<true, true, true>), dgrid, dim3(256), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
+                    hipLaunchKernelGGL((k_count_boundary<true, true, true>), dgrid, dim3(64 * CNT_WPB), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
                 else if (a.nflags)
-                    hipLaunchKernelGGL((k_count_boundary<false, true, true>), dgrid, dim3(256), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
+                    hipLaunchKernelGGL((k_count_boundary<false, true, true>), dgrid, dim3(64 * CNT_WPB), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
                 else if (a.has_lossy)
-                    hipLaunchKernelGGL((k_count_boundary<true, false, true>), dgrid, dim3(256), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
+                    hipLaunchKernelGGL((k_count_boundary<true, false, true>), dgrid, dim3(64 * CNT_WPB), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
                 else
-                    hipLaunchKernelGGL((k_count_boundary<false, false, true>), dgrid, dim3(256), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
+                    hipLaunchKernelGGL((k_count_boundary<false, false, true>), dgrid, dim3(64 * CNT_WPB), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
             }
             else if (a.nflags && a.has_lossy)
-                hipLaunchKernelGGL((k_count_boundary<true, true>), dim3(count_grid), dim3(256), cnt_pad, s, d, a, f->lossy,
+                hipLaunchKernelGGL((k_count_boundary<true, true>), dim3(count_grid), dim3(64 * CNT_WPB), cnt_pad, s, d, a, f->lossy,
                                    f->bcount, f->total, f->d_err, da);
             else if (a.nflags)
-                hipLaunchKernelGGL((k_count_boundary<false, true>), dim3(count_grid), dim3(256), cnt_pad, s, d, a, f->lossy,
+                hipLaunchKernelGGL((k_count_boundary<false, true>), dim3(count_grid), dim3(64 * CNT_WPB), cnt_pad, s, d, a, f->lossy,
                                    f->bcount, f->total, f->d_err, da);
             else if (a.has_lossy)
-                hipLaunchKernelGGL((k_count_boundary<true, false>), dim3(count_grid), dim3(256), cnt_pad, s, d, a, f->lossy,
+                hipLaunchKernelGGL((k_count_boundary<true, false>), dim3(count_grid), dim3(64 * CNT_WPB), cnt_pad, s, d, a, f->lossy,
                                    f->bcount, f->total, f->d_err, da);
             else
-                hipLaunchKernelGGL((k_count_boundary<false, false>), dim3(count_grid), dim3(256), cnt_pad, s, d, a, f->lossy,
+                hipLaunchKernelGGL((k_count_boundary<false, false>), dim3(count_grid), dim3(64 * CNT_WPB), cnt_pad, s, d, a, f->lossy,
                                    f->bcount, f->total, f->d_err, da);
             HIP_TRY(hipGetLastError());
         }
