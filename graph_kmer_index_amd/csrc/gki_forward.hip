@@ -14,6 +14,23 @@ constexpr int FMAX = GKI_MAX_WINDOW_NODES;
 
 struct FwdOut { int64_t *hash; int32_t *start_node; int16_t *start_offset; int32_t *node; double *af; };
 
+// The output columns are written once and never read by this kernel.  With one record per k-mer (one_node) they leave
+// with the non-temporal hint, as the boundary kernels' records do (csrc/gki_finder.hip): the lines of the graph the walk
+// reads stay in L2 -- 2.98 -> 2.79 ms per batch of 1.14e7 start positions, same box, alternating.  In all-nodes mode a
+// lane writes a k-mer's records (one per path node) into consecutive slots and the plain stores merge into whole lines
+// in L2; the hint sends every partial line to memory on its own: 3.96 -> 7.3 ms, so that mode keeps plain stores
+// (profiles/r03_forward_nt_stores_ab.txt; -DGKI_FWD_NT=0 / =2 rebuild the two partners: hint nowhere / everywhere).
+#ifndef GKI_FWD_NT
+#define GKI_FWD_NT 1
+#endif
+template <bool NT, class T> __device__ __forceinline__ void fst(T *p, T v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+template <bool ONE>
+__device__ __forceinline__ void put_record(const FwdOut &out, int64_t idx, uint64_t h, int32_t end_node, int end_off, int32_t node, double af) {
+    constexpr bool NT = GKI_FWD_NT == 2 || (GKI_FWD_NT == 1 && ONE);
+    fst<NT>(&out.hash[idx], (int64_t)h); fst<NT>(&out.start_node[idx], end_node); fst<NT>(&out.start_offset[idx], (int16_t)end_off);
+    fst<NT>(&out.node[idx], node); fst<NT>(&out.af[idx], af);
+}
+
 // only_follow_nodes (kmer_finder.py:386-388): when a node has successors in the follow set, only those are taken
 // and the variant limit is waived for that step.
 __device__ __forceinline__ bool any_followed(const DevGraph &g, const uint8_t *__restrict__ follow, int32_t node) {
@@ -77,8 +94,7 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
     // completion inside the start node
     if (have[0] == k) {
         if (EMIT) {
-            out.hash[idx] = (int64_t)hs[0]; out.start_node[idx] = n0; out.start_offset[idx] = (int16_t)(o0 + k - 1);
-            out.node[idx] = n0; out.af[idx] = g.allele_freq[n0];
+            put_record<false>(out, idx, hs[0], n0, o0 + k - 1, n0, g.allele_freq[n0]);
         }
         *count_out = 1;
         return;
@@ -120,8 +136,7 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
                 int32_t mn = INT_MAX; double maf = INFINITY;
                 for (int i = 0; i < Lw; i++) { mn = nd[i] < mn ? nd[i] : mn; maf = fmin(maf, g.allele_freq[nd[i]]); }
                 if (one_node) {
-                    out.hash[idx] = (int64_t)hs[L]; out.start_node[idx] = q; out.start_offset[idx] = (int16_t)(t - 1);
-                    out.node[idx] = mn; out.af[idx] = maf; idx++;
+                    put_record<true>(out, idx, hs[L], q, t - 1, mn, maf); idx++;
                 } else {
                     // one record per distinct node, ascending (np.unique, kmer_finder.py:134).  Node ids usually grow along
                     // a forward path: then the path is the order (one pass instead of a selection per record)
@@ -129,16 +144,14 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
                     for (int i = 1; i < Lw; i++) asc = asc && nd[i] > nd[i - 1];
                     if (asc) {
                         for (int r = 0; r < Lw; r++) {
-                            out.hash[idx] = (int64_t)hs[L]; out.start_node[idx] = q; out.start_offset[idx] = (int16_t)(t - 1);
-                            out.node[idx] = nd[r]; out.af[idx] = maf; idx++;
+                            put_record<false>(out, idx, hs[L], q, t - 1, nd[r], maf); idx++;
                         }
                     } else {
                         int32_t last = INT_MIN;
                         for (int r = 0; r < Lw; r++) {
                             int32_t best = INT_MAX;
                             for (int i = 0; i < Lw; i++) if (nd[i] > last && nd[i] < best) best = nd[i];
-                            out.hash[idx] = (int64_t)hs[L]; out.start_node[idx] = q; out.start_offset[idx] = (int16_t)(t - 1);
-                            out.node[idx] = best; out.af[idx] = maf; idx++;
+                            put_record<false>(out, idx, hs[L], q, t - 1, best, maf); idx++;
                             last = best;
                         }
                     }
@@ -165,6 +178,8 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
 // Then, all-nodes mode: an ascending path is written straight through instead of a selection per record: 5.0 -> 4.05 ms.
 // Tried and dropped: carrying the path's smallest node and minimum allele frequency down the walk instead of looping
 // over the path at every finished k-mer -- two more scratch stores per step cost more than the loops (5.0 -> 5.2 ms).
+// Round 3: the records of one-node mode leave with the non-temporal hint (2.98 -> 2.79 ms), all-nodes mode must not
+// (3.96 -> 7.3 ms): put_record above.
 template <bool EMIT, bool DEEP = false>
 __global__ __launch_bounds__(64, DEEP ? 1 : 8) void k_forward(DevGraph g, int k, int M, int one_node, const uint8_t *__restrict__ follow,
                                                 const int32_t *__restrict__ nodes,
