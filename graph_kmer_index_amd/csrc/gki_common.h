@@ -105,6 +105,16 @@ __device__ __forceinline__ uint64_t node_tail(const NodeWalk &w, int t) {
 // arena behind the slow path of a graph walk (see "stacks of the graph walks" below): cap levels for each of `lanes` lanes
 struct DeepArena { char *base; int64_t lanes; int32_t cap; int32_t pad; };
 
+// early-stop search: the finished k-mers the count pass wrote down for the emit pass (csrc/gki_forward.hip, "script"), and
+// the call they belong to -- the emit call uses them only when it is given the same arguments
+struct FwdScript {
+    void *entries;                           // [n_pos][FW_SLOTS] 48-byte entries
+    uint8_t *ncomp;                          // [n_pos] entries in use, 0xFF: the start position did not fit, walk it again
+    int64_t n_pos, overflow;
+    const void *nodes, *offsets, *follow, *rec_start;
+    int k, M, one_node, valid;
+};
+
 struct gki_graph {
     DevGraph d;
     int64_t *h_seq_start;                    // host copy of d.seq_start [n_nodes+1] (chunk bounds without a device read)
@@ -116,6 +126,7 @@ struct gki_graph {
     hipEvent_t ev_prep0, ev_prep1;
     DeepArena fwd_deep;                      // early-stop search: arena of its slow path, cap > 0 after a count call that needed it
     int64_t fwd_deep_bytes;
+    FwdScript fwd_script;                    // early-stop search: what the count call left for the emit call (csrc/gki_forward.hip)
 };
 
 // ---------------------------------------------------------------------------------- device error word

@@ -31,6 +31,52 @@ __device__ __forceinline__ void put_record(const FwdOut &out, int64_t idx, uint6
     fst<NT>(&out.node[idx], node); fst<NT>(&out.af[idx], af);
 }
 
+// "Script" of a search (GKI_FWD_SCRIPT, round 3): the emit pass used to repeat the count pass's whole walk.  Instead the
+// count pass writes every finished k-mer down -- hash, end position, minimum allele frequency, the path's nodes, the
+// number of the k-mer's first record among its start position's -- in one of FW_SLOTS 48-byte entries per start position,
+// and the emit pass is a streaming expansion with one thread per entry.  A start position with more finished k-mers, a
+// path over more than FW_SN nodes or a path whose node ids do not ascend is marked 0xFF and walked by the emit kernel as
+// before (with SNP bubbles ~600 bases apart and FW_SLOTS = 4 that is one start in several hundred).  The script lives in
+// gki_graph::fwd_script between gki_forward_count and the gki_forward_emit call with the same arguments; any other emit
+// call, the slow path for deep windows, or no memory for the script (192 B per start position) mean the emit pass walks.
+// Measured, 1.14e7 start positions on the 1 Gbp graph, alternating on one box (profiles/r03_forward_script_ab.txt):
+// all-nodes mode 4.16 -> 3.73 ms, and 3.75 -> 3.21 ms with short_path_facts below; one node per k-mer 2.98 -> 3.06 ms,
+// so gki_forward_count writes a script in all-nodes mode only.
+#ifndef GKI_FWD_SCRIPT
+#define GKI_FWD_SCRIPT 1
+#endif
+constexpr int FW_SLOTS = 4, FW_SN = 5, FW_ENTRY_U4 = 3;
+__device__ __forceinline__ void script_write(uint4 *e, uint64_t h, double maf, int32_t q, int off, int lw, uint32_t first, const int32_t *nodes) {
+    const uint64_t mb = (uint64_t)__double_as_longlong(maf);
+    e[0] = make_uint4((uint32_t)h, (uint32_t)(h >> 32), (uint32_t)mb, (uint32_t)(mb >> 32));
+    e[1] = make_uint4((uint32_t)q, ((uint32_t)off & 0xFFFFu) | ((uint32_t)lw << 16), first, (uint32_t)nodes[0]);
+    e[2] = make_uint4((uint32_t)nodes[1], (uint32_t)nodes[2], (uint32_t)nodes[3], (uint32_t)nodes[4]);
+}
+
+// The nodes of a finished path over at most FW_SN nodes, their smallest id, their minimum allele frequency, and whether
+// the ids ascend.  A loop over the path is a chain of 2 x Lw dependent round trips (the level's node from the stack, then
+// its allele frequency); here the FW_SN stack slots are read at fixed indices and the FW_SN allele frequencies loaded side
+// by side -- two round trips whatever Lw is.  Slots beyond the path hold stale levels: replaced by the first node before
+// anything is indexed with them.
+template <class NS>
+__device__ __forceinline__ bool short_path_facts(const DevGraph &g, NS &nd, int Lw, int32_t (&v)[FW_SN], int32_t &mn, double &maf) {
+#pragma unroll
+    for (int r = 0; r < FW_SN; r++) v[r] = nd[r];
+#pragma unroll
+    for (int r = 1; r < FW_SN; r++) if (r >= Lw) v[r] = v[0];
+    double f[FW_SN];
+#pragma unroll
+    for (int r = 0; r < FW_SN; r++) f[r] = g.allele_freq[v[r]];
+    mn = v[0]; maf = fmin((double)INFINITY, f[0]);
+    bool asc = true;
+#pragma unroll
+    for (int r = 1; r < FW_SN; r++) {
+        mn = v[r] < mn ? v[r] : mn; maf = fmin(maf, f[r]);
+        if (r < Lw) asc = asc && v[r] > v[r - 1];
+    }
+    return asc;
+}
+
 // only_follow_nodes (kmer_finder.py:386-388): when a node has successors in the follow set, only those are taken
 // and the variant limit is waived for that step.
 __device__ __forceinline__ bool any_followed(const DevGraph &g, const uint8_t *__restrict__ follow, int32_t node) {
@@ -59,10 +105,12 @@ constexpr int FW_BUDGET = 1 << 22, FW_BUDGET_FROM = 8;     // (every step of thi
 // DEEP = false: the product kernel, FMAX levels per lane in scratch.  DEEP = true: the slow path for forward windows over
 // more nodes than that (sixteen or more empty nodes before the first k-mer is complete), the same walk with its levels
 // in a global-memory arena of da.cap levels per lane (gki_forward_count grows it until the walk fits).
-template <bool EMIT, bool DEEP>
+template <bool EMIT, bool DEEP, bool SCRIPT>
 __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, const uint8_t *__restrict__ follow,
                              int32_t n0, int32_t o0, int64_t idx, FwdOut out, uint32_t *count_out, int *err,
-                             const DeepArena &da, int64_t lane_global) {
+                             const DeepArena &da, int64_t lane_global, uint4 *script, uint32_t *used_out) {
+    static_assert(!SCRIPT || (!EMIT && !DEEP), "the script is written by the product count kernel");
+    uint32_t used = 0;                        // SCRIPT: entries written, 0xFF = this start position does not fit
     typedef typename CountOf<DEEP>::T cnt_t;
     typename StackOf<int32_t, FMAX, DEEP>::type nd, cur, end, last;
     typename StackOf<uint8_t, FMAX, DEEP>::type have, forced;
@@ -75,7 +123,7 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
     int steps_left = FW_BUDGET;
     uint32_t count = 0;
     const NodeWalk w0 = g.walk[n0];
-    if (o0 < 0 || o0 > w0.size) { *count_out = 0; return; }
+    if (o0 < 0 || o0 > w0.size) { *count_out = 0; if (SCRIPT) *used_out = 0; return; }
     // level 0: the start node from offset o0 (an empty start node contributes no base)
     int L = 0;
     {
@@ -95,6 +143,11 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
     if (have[0] == k) {
         if (EMIT) {
             put_record<false>(out, idx, hs[0], n0, o0 + k - 1, n0, g.allele_freq[n0]);
+        }
+        if (SCRIPT) {
+            const int32_t one[FW_SN] = {n0, 0, 0, 0, 0};
+            script_write(script, hs[0], g.allele_freq[n0], n0, o0 + k - 1, 1, 0u, one);
+            *used_out = 1;
         }
         *count_out = 1;
         return;
@@ -133,29 +186,57 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
         if (hv + t == k) {                          // first k-mer of this path: emit and stop (early stop, :326-330)
             const int Lw = L + 1;
             if (EMIT) {
-                int32_t mn = INT_MAX; double maf = INFINITY;
-                for (int i = 0; i < Lw; i++) { mn = nd[i] < mn ? nd[i] : mn; maf = fmin(maf, g.allele_freq[nd[i]]); }
+                int32_t v[FW_SN]; int32_t mn = INT_MAX; double maf = INFINITY;
+                bool asc = true;
+                const bool short_path = Lw <= FW_SN;
+                if (short_path) asc = short_path_facts(g, nd, Lw, v, mn, maf);
+                else {
+                    for (int i = 0; i < Lw; i++) { mn = nd[i] < mn ? nd[i] : mn; maf = fmin(maf, g.allele_freq[nd[i]]); }
+                    if (!one_node) for (int i = 1; i < Lw; i++) asc = asc && nd[i] > nd[i - 1];
+                }
                 if (one_node) {
                     put_record<true>(out, idx, hs[L], q, t - 1, mn, maf); idx++;
-                } else {
+                } else if (asc) {
                     // one record per distinct node, ascending (np.unique, kmer_finder.py:134).  Node ids usually grow along
                     // a forward path: then the path is the order (one pass instead of a selection per record)
-                    bool asc = true;
-                    for (int i = 1; i < Lw; i++) asc = asc && nd[i] > nd[i - 1];
-                    if (asc) {
+                    if (short_path) {
+#pragma unroll
+                        for (int r = 0; r < FW_SN; r++)
+                            if (r < Lw) { put_record<false>(out, idx, hs[L], q, t - 1, v[r], maf); idx++; }
+                    } else {
                         for (int r = 0; r < Lw; r++) {
                             put_record<false>(out, idx, hs[L], q, t - 1, nd[r], maf); idx++;
                         }
-                    } else {
-                        int32_t last = INT_MIN;
-                        for (int r = 0; r < Lw; r++) {
-                            int32_t best = INT_MAX;
-                            for (int i = 0; i < Lw; i++) if (nd[i] > last && nd[i] < best) best = nd[i];
-                            put_record<false>(out, idx, hs[L], q, t - 1, best, maf); idx++;
-                            last = best;
-                        }
+                    }
+                } else {
+                    int32_t last = INT_MIN;
+                    for (int r = 0; r < Lw; r++) {
+                        int32_t best = INT_MAX;
+                        for (int i = 0; i < Lw; i++) if (nd[i] > last && nd[i] < best) best = nd[i];
+                        put_record<false>(out, idx, hs[L], q, t - 1, best, maf); idx++;
+                        last = best;
                     }
                 }
+            }
+            if (SCRIPT && used != 0xFFu) {
+                bool fits = used < (uint32_t)FW_SLOTS && (one_node || Lw <= FW_SN);
+                if (fits) {
+                    int32_t v[FW_SN]; int32_t mn = INT_MAX; double maf = INFINITY;
+                    bool asc = true;
+                    if (Lw <= FW_SN) asc = short_path_facts(g, nd, Lw, v, mn, maf);
+                    else for (int i = 0; i < Lw; i++) { mn = nd[i] < mn ? nd[i] : mn; maf = fmin(maf, g.allele_freq[nd[i]]); }   // (one node per k-mer)
+                    fits = one_node || asc;
+                    if (fits) {
+                        int32_t ns[FW_SN] = {mn, 0, 0, 0, 0};
+                        if (!one_node) {
+#pragma unroll
+                            for (int r = 0; r < FW_SN; r++) ns[r] = r < Lw ? v[r] : 0;
+                        }
+                        script_write(script + (size_t)used * FW_ENTRY_U4, hs[L], maf, q, t - 1, one_node ? 1 : Lw, count, ns);
+                        used++;
+                    }
+                }
+                if (!fits) used = 0xFFu;
             }
             count += one_node ? 1u : (uint32_t)Lw;
             continue;
@@ -169,6 +250,7 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
         if (L > FW_BUDGET_FROM && --steps_left < 0) { gki_raise_budget(err); L = 0; }
     }
     *count_out = count;
+    if (SCRIPT) *used_out = used;
 }
 
 // One lane per start position, every read from global memory: latency-bound, so resident waves are what counts.  Without
@@ -180,21 +262,56 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
 // over the path at every finished k-mer -- two more scratch stores per step cost more than the loops (5.0 -> 5.2 ms).
 // Round 3: the records of one-node mode leave with the non-temporal hint (2.98 -> 2.79 ms), all-nodes mode must not
 // (3.96 -> 7.3 ms): put_record above.
-template <bool EMIT, bool DEEP = false>
+template <bool EMIT, bool DEEP = false, bool SCRIPT = false>
 __global__ __launch_bounds__(64, DEEP ? 1 : 8) void k_forward(DevGraph g, int k, int M, int one_node, const uint8_t *__restrict__ follow,
                                                 const int32_t *__restrict__ nodes,
                                                 const int32_t *__restrict__ offsets, int64_t n_pos,
                                                 uint32_t *__restrict__ cnt, const int64_t *__restrict__ rec_start, FwdOut out,
-                                                int *__restrict__ err, DeepArena da) {
+                                                int *__restrict__ err, DeepArena da, uint4 *__restrict__ script, uint8_t *__restrict__ used) {
     const int64_t lane_global = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     // product kernel: one position per lane; slow path: the arena's lanes walk the positions grid-stride
     for (int64_t i = lane_global; i < n_pos; i += DEEP ? da.lanes : n_pos) {
-        uint32_t c = 0;
+        uint32_t c = 0, u = 0;
+        if (EMIT && used && used[i] != 0xFF) continue;          // written by the expansion of the script
         const int32_t n0 = nodes[i];
-        if (n0 < 0 || n0 >= g.n_nodes) { if (!EMIT) cnt[i] = 0; continue; }
-        forward_walk<EMIT, DEEP>(g, k, M, one_node != 0, follow, n0, offsets[i], EMIT ? rec_start[i] : 0, out, &c, err, da, lane_global);
+        if (n0 < 0 || n0 >= g.n_nodes) { if (!EMIT) cnt[i] = 0; if (SCRIPT) used[i] = 0; continue; }
+        forward_walk<EMIT, DEEP, SCRIPT>(g, k, M, one_node != 0, follow, n0, offsets[i], EMIT ? rec_start[i] : 0, out, &c, err, da, lane_global,
+                                         SCRIPT ? script + (size_t)i * (FW_SLOTS * FW_ENTRY_U4) : nullptr, &u);
         if (!EMIT) cnt[i] = c;
+        if (SCRIPT) { used[i] = (uint8_t)u; if (u == 0xFFu) atomicAdd(err + 1, 1); }
     }
+}
+
+// Emit pass over the script: one thread per entry; the records of a start position, and of neighbouring start positions,
+// are neighbours in the output, so a wave's stores cover a contiguous stretch of every column (plain stores: the lines
+// are completed in L2, see put_record).
+__global__ __launch_bounds__(256) void k_forward_expand(const uint4 *__restrict__ script, const uint8_t *__restrict__ used,
+                                                         const int64_t *__restrict__ rec_start, int64_t n_pos, FwdOut out) {
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = tid / FW_SLOTS;
+    const int c = (int)(tid % FW_SLOTS);
+    if (i >= n_pos) return;
+    const uint32_t n = used[i];
+    if (n == 0xFFu || (uint32_t)c >= n) return;
+    const uint4 a = script[tid * FW_ENTRY_U4], b = script[tid * FW_ENTRY_U4 + 1], d = script[tid * FW_ENTRY_U4 + 2];
+    const uint64_t h = (uint64_t)a.x | ((uint64_t)a.y << 32);
+    const double maf = __longlong_as_double((long long)((uint64_t)a.z | ((uint64_t)a.w << 32)));
+    const int lw = (int)((b.y >> 16) & 0xFFu);
+    const int off = (int)(int16_t)(b.y & 0xFFFFu);
+    const int64_t idx = rec_start[i] + (int64_t)b.z;
+    const int32_t ns[FW_SN] = {(int32_t)b.w, (int32_t)d.x, (int32_t)d.y, (int32_t)d.z, (int32_t)d.w};
+#pragma unroll
+    for (int r = 0; r < FW_SN; r++)
+        if (r < lw) put_record<false>(out, idx + r, h, (int32_t)b.x, off, ns[r], maf);
+}
+}  // namespace
+
+namespace {
+void script_drop(gki_graph *gr) {
+    FwdScript &sc = gr->fwd_script;
+    if (sc.entries) (void)gki_dev_free(sc.entries);
+    if (sc.ncomp) (void)gki_dev_free(sc.ncomp);
+    sc = FwdScript{};
 }
 }  // namespace
 
@@ -209,31 +326,45 @@ int gki_forward_count(gki_graph *gr, int k, int max_variant_nodes, int one_node,
     int64_t tmp_bytes = gki_scan_tmp_bytes(n_pos);
     HIP_TRY(gki_dev_malloc((void **)&cnt, (size_t)n_pos * 4));
     HIP_TRY(gki_dev_malloc(&tmp, (size_t)tmp_bytes));
-    HIP_TRY(gki_dev_malloc((void **)&d_err, 4));
-    HIP_TRY(hipMemset(d_err, 0, 4));
+    HIP_TRY(gki_dev_malloc((void **)&d_err, 8));        // [0] the error word, [1] start positions that did not fit the script
+    HIP_TRY(hipMemset(d_err, 0, 8));
     FwdOut none{nullptr, nullptr, nullptr, nullptr, nullptr};
     const int M = max_variant_nodes > 250 ? 250 : max_variant_nodes;
     gr->fwd_deep.cap = 0;                 // the product kernel first; the emit call that follows uses what this call settles on
-    int64_t total = 0; int word = 0;
+    // the script for the emit call (see FW_SLOTS above); without memory for it the emit call walks as it always did
+    script_drop(gr);
+    FwdScript &sc = gr->fwd_script;
+    if (GKI_FWD_SCRIPT && !one_node) {      // (one node per k-mer: 2.98 -> 3.06 ms with the script, it stays out of that mode)
+        if (gki_dev_malloc(&sc.entries, (size_t)n_pos * FW_SLOTS * FW_ENTRY_U4 * 16) != hipSuccess ||
+            gki_dev_malloc((void **)&sc.ncomp, (size_t)n_pos) != hipSuccess) { (void)hipGetLastError(); script_drop(gr); }
+    }
+    int64_t total = 0; int word[2] = {0, 0};
     int rc = GKI_OK;
     hipError_t e1 = hipSuccess, e2 = hipSuccess, e3 = hipSuccess;
     for (;;) {
         const DeepArena da = gr->fwd_deep;
-        e3 = hipMemset(d_err, 0, 4);
-        if (da.cap > 0)
+        e3 = hipMemset(d_err, 0, 8);
+        if (da.cap > 0) {
+            script_drop(gr);                // the slow path writes no script
             hipLaunchKernelGGL((k_forward<false, true>), dim3((unsigned)(da.lanes / 64)), dim3(64), 0, 0, gr->d, k, M, one_node, (const uint8_t *)d_follow,
-                               (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, cnt, (const int64_t *)nullptr, none, d_err, da);
+                               (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, cnt, (const int64_t *)nullptr, none, d_err, da,
+                               (uint4 *)nullptr, (uint8_t *)nullptr);
+        } else if (sc.entries)
+            hipLaunchKernelGGL((k_forward<false, false, true>), dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, k, M, one_node, (const uint8_t *)d_follow,
+                               (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, cnt, (const int64_t *)nullptr, none, d_err, da,
+                               (uint4 *)sc.entries, sc.ncomp);
         else
             hipLaunchKernelGGL((k_forward<false, false>), dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, k, M, one_node, (const uint8_t *)d_follow,
-                               (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, cnt, (const int64_t *)nullptr, none, d_err, da);
+                               (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, cnt, (const int64_t *)nullptr, none, d_err, da,
+                               (uint4 *)nullptr, (uint8_t *)nullptr);
         rc = hipGetLastError() == hipSuccess ? GKI_OK : gki_set_error(GKI_ERR_HIP, "k_forward launch failed");
         if (rc == GKI_OK) rc = gki_scan_u32_to_i64(cnt, n_pos, (int64_t *)d_rec_start, tmp, tmp_bytes, 0);
         e1 = hipMemcpy(&total, (const int64_t *)d_rec_start + n_pos, 8, hipMemcpyDeviceToHost);
-        e2 = hipMemcpy(&word, d_err, 4, hipMemcpyDeviceToHost);
+        e2 = hipMemcpy(word, d_err, 8, hipMemcpyDeviceToHost);
         if (rc != GKI_OK || e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) break;
         // bit 1: a stack of the walk was too short -- again with the deep variant, twice the levels each time round
         const int next_cap = da.cap == 0 ? 4 * FMAX : 2 * da.cap;
-        if (!(word & 2) || (word & 4) || next_cap > GKI_MAX_DEEP_WINDOW_NODES) break;
+        if (!(word[0] & 2) || (word[0] & 4) || next_cap > GKI_MAX_DEEP_WINDOW_NODES) break;
         const int64_t lanes = 64 * 256, bytes = lanes * (int64_t)next_cap * FW_CELL;
         if (bytes > gr->fwd_deep_bytes) {
             if (gr->fwd_deep.base) (void)gki_dev_free(gr->fwd_deep.base);
@@ -244,14 +375,19 @@ int gki_forward_count(gki_graph *gr, int k, int max_variant_nodes, int one_node,
         gr->fwd_deep.lanes = lanes; gr->fwd_deep.cap = next_cap; gr->fwd_deep.pad = 0;
     }
     (void)gki_dev_free(cnt); (void)gki_dev_free(tmp); (void)gki_dev_free(d_err);
+    const int herr = rc == GKI_OK && e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess ? gki_error_of_word(word[0]) : -1;
+    if (herr != GKI_OK || !sc.entries) script_drop(gr);
+    else {                                  // the emit call with these very arguments may expand the script
+        sc.n_pos = n_pos; sc.overflow = word[1]; sc.nodes = d_nodes; sc.offsets = d_offsets; sc.follow = d_follow; sc.rec_start = d_rec_start;
+        sc.k = k; sc.M = M; sc.one_node = one_node ? 1 : 0; sc.valid = 1;
+    }
     if (rc != GKI_OK) return rc;
     HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(e3);
-    const int herr = gki_error_of_word(word);
     if (herr == GKI_ERR_NOT_ONE_REF_SUCC)
         return gki_set_error(herr, "a path at the variant limit ends a node that does not have exactly one linear-ref "
                              "successor: the reference asserts here (kmer_finder.py:402)");
-    if (herr) return gki_set_error(herr, (word & 4) ? "the paths from one start position take more than %d descents to enumerate: too many paths"
-                                   : "a forward k-window crosses more than %d nodes", (word & 4) ? FW_BUDGET : GKI_MAX_DEEP_WINDOW_NODES - 2);
+    if (herr) return gki_set_error(herr, (word[0] & 4) ? "the paths from one start position take more than %d descents to enumerate: too many paths"
+                                   : "a forward k-window crosses more than %d nodes", (word[0] & 4) ? FW_BUDGET : GKI_MAX_DEEP_WINDOW_NODES - 2);
     *n_records = total;
     return GKI_OK;
 }
@@ -266,15 +402,28 @@ int gki_forward_emit(gki_graph *gr, int k, int max_variant_nodes, int one_node, 
     FwdOut out{(int64_t *)d_hashes, (int32_t *)d_start_nodes, (int16_t *)d_start_offsets, (int32_t *)d_nodes_out, (double *)d_af64};
     const DeepArena da = gr->fwd_deep;         // cap > 0: the count call of this search needed the slow path
     const int M = max_variant_nodes > 250 ? 250 : max_variant_nodes;
+    FwdScript &sc = gr->fwd_script;
+    const bool scripted = sc.valid && da.cap == 0 && sc.n_pos == n_pos && sc.nodes == d_nodes && sc.offsets == d_offsets && sc.follow == d_follow &&
+                          sc.rec_start == d_rec_start && sc.k == k && sc.M == M && sc.one_node == (one_node ? 1 : 0);
     if (da.cap > 0)
         hipLaunchKernelGGL((k_forward<true, true>), dim3((unsigned)(da.lanes / 64)), dim3(64), 0, 0, gr->d, k, M, one_node, (const uint8_t *)d_follow,
-                           (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, (uint32_t *)nullptr, (const int64_t *)d_rec_start, out, d_err, da);
-    else
+                           (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, (uint32_t *)nullptr, (const int64_t *)d_rec_start, out, d_err, da,
+                           (uint4 *)nullptr, (uint8_t *)nullptr);
+    else if (scripted) {
+        hipLaunchKernelGGL(k_forward_expand, dim3((unsigned)ceil_div(n_pos * FW_SLOTS, 256)), dim3(256), 0, 0, (const uint4 *)sc.entries, sc.ncomp,
+                           (const int64_t *)d_rec_start, n_pos, out);
+        if (sc.overflow > 0)                // the start positions the script could not hold: walked as before
+            hipLaunchKernelGGL((k_forward<true, false>), dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, k, M, one_node, (const uint8_t *)d_follow,
+                               (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, (uint32_t *)nullptr, (const int64_t *)d_rec_start, out, d_err, da,
+                               (uint4 *)nullptr, sc.ncomp);
+    } else
         hipLaunchKernelGGL((k_forward<true, false>), dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, k, M, one_node, (const uint8_t *)d_follow,
-                           (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, (uint32_t *)nullptr, (const int64_t *)d_rec_start, out, d_err, da);
+                           (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, (uint32_t *)nullptr, (const int64_t *)d_rec_start, out, d_err, da,
+                           (uint4 *)nullptr, (uint8_t *)nullptr);
     hipError_t e = hipGetLastError();
     hipError_t e2 = hipDeviceSynchronize();
     (void)gki_dev_free(d_err);
+    script_drop(gr);                        // one emit per count: a second emit call walks
     HIP_TRY(e); HIP_TRY(e2);
     return GKI_OK;
 }

@@ -210,6 +210,8 @@ int gki_graph_destroy(gki_graph *g) {
     if (!g) return GKI_OK;
     for (int i = 0; i < g->n_owned; i++) (void)hipFree(g->owned[i]);
     if (g->fwd_deep.base) (void)gki_dev_free(g->fwd_deep.base);
+    if (g->fwd_script.entries) (void)gki_dev_free(g->fwd_script.entries);
+    if (g->fwd_script.ncomp) (void)gki_dev_free(g->fwd_script.ncomp);
     (void)hipEventDestroy(g->ev_prep0);
     (void)hipEventDestroy(g->ev_prep1);
     (void)hipStreamDestroy(g->stream);

@@ -250,7 +250,10 @@ int64_t gki_finder_interior_records(const gki_finder *f);
  * bases gives one window; records carry the END position like all finder records.  count -> emit; records of
  * start position i are [rec_start[i], rec_start[i+1]) in depth-first successor order (the reference's order).
  * d_nodes int32[n_pos], d_offsets int32[n_pos], d_rec_start int64[n_pos+1]; output = the v2 columns.
- * d_follow: uint8[n_nodes] membership of only_follow_nodes (:386-388) or NULL. */
+ * d_follow: uint8[n_nodes] membership of only_follow_nodes (:386-388) or NULL.
+ * gki_forward_count may leave the finished k-mers in a buffer owned by the graph (192 bytes per start position, all-nodes
+ * mode); the next gki_forward_emit with the SAME arguments expands them instead of walking again and releases the buffer.
+ * Any other sequence of calls is answered by walking; the results are the same. */
 int gki_forward_count(gki_graph *g, int k, int max_variant_nodes, int one_node, const void *d_follow,
                       const void *d_nodes, const void *d_offsets, int64_t n_pos, void *d_rec_start,
                       int64_t *n_records);
