@@ -426,6 +426,52 @@ def test_kmers_from_positions_when_node_ids_do_not_grow_along_the_path():
     assert out_of_order >= 5
 
 
+def test_early_stop_emit_from_the_script_equals_the_walking_emit():
+    # csrc/gki_forward.hip: in all-nodes mode gki_forward_count leaves the finished k-mers in a script and the
+    # gki_forward_emit call with the same arguments expands it (start positions with more than four finished k-mers or a
+    # path over more than five nodes are walked); the script is released by that call, so a SECOND emit call with the same
+    # arguments walks every start position.  Both forms must fill the five columns identically, and as the oracle does.
+    import ctypes as C
+    from graph_kmer_index_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(35)
+    compared = many_paths = 0
+    dt = [np.int64, np.int32, np.int16, np.int32, np.float64]
+    for it in range(30):
+        k = int(rng.integers(3, 14))
+        M = int(rng.choice([0, 1, 2, 4, 100]))
+        seqs, edges, lin, af = random_bubble_graph(rng, n_var=int(rng.integers(2, 12)), min_ref=1, max_ref=2 * k,
+                                                   p_indel=0.5, with_af=True)
+        g = GraphArrays.from_dicts(seqs, edges, lin, af)
+        f = DenseKmerFinder(g, k, only_save_one_node_per_kmer=False, max_variant_nodes=M)
+        nodes = rng.integers(0, g.n_nodes, size=48).astype(np.int32)
+        offs = np.array([int(rng.integers(0, max(1, g.node_size[n]))) for n in nodes], dtype=np.int32)
+        d_nodes, d_offs = _lib.DeviceArray.from_host(nodes), _lib.DeviceArray.from_host(offs)
+        d_start = _lib.DeviceArray(len(nodes) + 1, np.int64)
+        n = C.c_int64(0)
+        args = (f._device_graph().handle, k, M, 0, None, d_nodes.ptr, d_offs.ptr, len(nodes))
+        _lib.check(lib.gki_forward_count(*args, d_start.ptr, C.byref(n)))
+        if n.value == 0:
+            continue
+        first = [_lib.DeviceArray(n.value, d) for d in dt]
+        second = [_lib.DeviceArray(n.value, d) for d in dt]
+        _lib.check(lib.gki_forward_emit(*args, d_start.ptr, *[b.ptr for b in first]))      # expands the script
+        _lib.check(lib.gki_forward_emit(*args, d_start.ptr, *[b.ptr for b in second]))     # no script left: walks
+        a, b = [x.to_host() for x in first], [x.to_host() for x in second]
+        for col_a, col_b in zip(a, b):
+            assert np.array_equal(col_a, col_b)
+        exp = [oracle.find_from_position(g, k, int(p), int(o), False, M) for p, o in zip(nodes, offs)]
+        exp = {key: np.concatenate([e[key] for e in exp]) for key in exp[0]}
+        got = dict(kmers=a[0], start_nodes=a[1], start_offsets=a[2], nodes=a[3], allele_frequencies=a[4])
+        assert_same_records(got, exp, exact_order=True)
+        per_start = np.diff(d_start.to_host())
+        many_paths += int(np.sum(per_start > 20))          # more records than four finished k-mers of five nodes can hold
+        compared += 1
+        for x in first + second + [d_nodes, d_offs, d_start]:
+            x.free()
+    assert compared >= 20 and many_paths >= 1
+
+
 def test_only_follow_nodes_from_position():
     # unique_variant_kmers.py:91-96: only_store_nodes = only_follow_nodes = {variant node}, early-stop search
     rng = np.random.default_rng(41)
