@@ -65,6 +65,20 @@ def pmc_traffic(n_ref_bases, n_sites, k):
     return None, None
 
 
+def index_roofline(n, n_buckets, nonempty, seconds, hashing, passes=1):
+    """SURVEY.md 8(d)'s ALGORITHMIC bytes of the index build: every 24-byte row read and written once per sort pass (the
+    lower bound is one pass; the implementation's count is stated beside it), the frequency column 2 B per record, the
+    directory initialised (2 x 4 B x buckets) and its non-empty entries written (8 B each); with `hashing` the 25 B per
+    record of enumerate + hash (1 B of sequence read, the 24-byte row written) in front."""
+    per_record = (BYTES_PER_RECORD if hashing else 0) + passes * 48 + 2
+    alg = per_record * n + 8 * n_buckets + 8 * nonempty
+    return {"bound": "hbm", "achieved": alg / seconds / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": alg / seconds / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": int(alg),
+            "bytes_per_record": per_record, "sort_passes_counted": passes,
+            "model": "SURVEY.md 8(d): %s%d pass x 2 x 24 B + 2 B frequency per record, + 8 B x %d buckets + 8 B x %d non-empty"
+                     % ("25 B enumerate+hash + " if hashing else "", passes, n_buckets, nonempty)}
+
+
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
@@ -298,24 +312,46 @@ def secondary_records(lib, _lib, g, k, cp, finder, out, n_reads, cpu2, max_varia
         dt = time.perf_counter() - t
         pool1 = _lib.pool_stats()
     kb = int(modulo - 1).bit_length()
-    # algorithmic bytes of the build as implemented (csrc/gki_index_rows.hip), per record: bucket keys 8 R + 4 W; two
-    # partition passes on the top 19 bits, each 4 R (histogram) + 28 R + 28 W (24-byte row + key); group bounds 4 R;
-    # finish 28 R + 26 W (four columns + frequency); plus the directory itself, 2 x 4 B x modulo, streamed once
-    per_record = 12 + 2 * 60 + 4 + 54
+    # bytes of the build AS IMPLEMENTED (csrc/gki_index_rows.hip), per record: first histogram 8 R (key from the k-mer, not
+    # stored); first partition pass 24 R + 28 W (columns -> row + key), second 4 R (histogram) + 28 R + 28 W; group bounds
+    # 4 R; finish 28 R + 26 W (four columns + frequency); plus the directory itself, 2 x 4 B x modulo, streamed once
+    per_record = 8 + 52 + 60 + 4 + 54
     moved = per_record * nb + 8 * modulo
+    n_kmers_host = idx.n_kmers.to_host()
+    nonempty = int(np.count_nonzero(n_kmers_host))
+    del n_kmers_host
     index_build = {"records": int(nb), "ms": 1e3 * dt, "records_per_s": nb / dt, "modulo": modulo, "key_bits": kb,
                    "form": "row-carrying: 2 stable partition passes (10 + 9 bits) + in-LDS finish on 10 bits",
                    "frequencies": True, "bytes_moved_model": int(moved), "bytes_per_record_model": per_record,
                    "achieved_GBps": moved / dt / 1e9, "frac_of_hbm_peak": moved / dt / 1e9 / HBM_PEAK_GBS,
+                   "roofline": index_roofline(nb, modulo, nonempty, dt, hashing=False),
                    "timed": "wall clock around DeviceIndex.build incl. its allocations, device synchronised",
                    "ms_in_device_allocator": (pool1[2] - pool0[2]) + (pool1[3] - pool0[3]),
                    "cpu_baseline": cpu2.get("index_build")}
-    # scalar CollisionFreeKmerIndex.get (:303-315): one launch + one synchronisation per call (gki_index_get_small)
-    some = bnd.hashes.view(0, min(nb, 4096)).to_host()
+    # scalar CollisionFreeKmerIndex.get (:303-315) on the whole variant index: the class answers one k-mer from its own
+    # host arrays (the device serves the batched getters); half the queries hit, as in BASELINE.md section 2's probe
+    from graph_kmer_index_amd import CollisionFreeKmerIndex
+    t = time.perf_counter()
+    host_index = CollisionFreeKmerIndex(idx.hashes_to_index.to_host(), idx.n_kmers.to_host(), idx.nodes.to_host(nb),
+                                        idx.ref_offsets.to_host(nb), idx.kmers.to_host(nb), modulo, idx.frequencies.to_host(nb),
+                                        idx.allele_frequencies.to_host(nb))
+    t_host = time.perf_counter() - t
+    rng = np.random.default_rng(5)
+    some = np.concatenate([host_index._kmers[rng.integers(0, nb, size=10000)], rng.integers(0, 4 ** k, size=10000, dtype=np.uint64)])
+    rng.shuffle(some)
+    some = [int(x) for x in some]
+    n_found = 0
+    t = time.perf_counter()
+    for x in some:
+        n_found += host_index.get(x)[0] is not None
+    index_build["scalar_get_calls_per_s"] = len(some) / (time.perf_counter() - t)
+    index_build["scalar_get"] = {"calls": len(some), "found": int(n_found), "index_to_host_s": t_host,
+                                 "what": "CollisionFreeKmerIndex.get on the object's host arrays (all %d records), one Python call per k-mer" % nb}
     t = time.perf_counter()
     for x in some[:2000]:
-        idx.get_small([int(x)], 10)
-    index_build["scalar_get_calls_per_s"] = min(len(some), 2000) / (time.perf_counter() - t)
+        idx.get_small([x], 10)
+    index_build["scalar_get_device_calls_per_s"] = 2000 / (time.perf_counter() - t)     # DeviceIndex.get_small: one launch + one sync
+    del host_index
     # ReverseKmerIndex.from_flat_kmers (reverse_kmer_index.py:47-83) of the same records: the same
     # stable radix sort keyed on the node id (gki_reverse_index_build), columns in HBM on both sides
     r_pos, r_cnt = _lib.DeviceArray(g.n_nodes, np.uint32), _lib.DeviceArray(g.n_nodes, np.uint16)
@@ -383,12 +419,14 @@ def secondary_records(lib, _lib, g, k, cp, finder, out, n_reads, cpu2, max_varia
 
 
 def full_index_record(lib, _lib, g, k, cp, out, max_variant_nodes, modulo, n_slices=8):
-    """Every record of the graph hashed AND indexed on this one GPU.  One int32 directory stops at 2^31 records
-    (collision_free_kmer_index.py:453), so the index is built in bucket-range slices -- BASELINE
-    configs[3]'s data flow with the 8 ranks taken in turn: every rank's critical-path shard is enumerated and
-    partitioned by owning slice, the all-to-all is stood in for by device copies in rank order (exactly what
-    gki_comm_alltoall_flat delivers), every slice is built with frequencies.  The step's own output columns become the
-    storage of the partitioned shards (their checksums are kept: the slices' payload must be the same multiset)."""
+    """Every record of the graph hashed AND indexed on this one GPU -- BASELINE's metric in its own words.  One int32
+    directory stops at 2^31 records (collision_free_kmer_index.py:453), so the index is built in bucket-range slices
+    (the class is collision_free_kmer_index.PartitionedDeviceIndex): the whole graph is enumerated and
+    hashed (gki_finder_count + gki_finder_emit_flat, the step of the headline), its 3.16e9 records are partitioned by
+    owning slice in one call (gki_partition_by_bucket_range, no limit on the number of records: two passes of < 2^31 rows
+    laid out behind each other), and every slice is built with frequencies (gki_index_build_range).  On one GPU there is
+    nothing to exchange: round 3 timed a device copy per slice as a stand-in for the all-to-all of configs[3]; that
+    exchange is `sharded_build`'s subject (N > 1), not this record's."""
     from graph_kmer_index_amd.flat_kmers import DeviceFlatKmers
     from graph_kmer_index_amd.collision_free_kmer_index import DeviceIndex, bucket_range, partition_by_bucket_range
     def sync():
@@ -396,102 +434,77 @@ def full_index_record(lib, _lib, g, k, cp, out, max_variant_nodes, modulo, n_sli
     n = out.n
     MASK = (1 << 64) - 1
     cols = ("hashes", "nodes", "ref_offsets", "allele_frequencies")
-    want = [getattr(out, c).checksum(n) for c in cols]
-    # The step's columns are dead from here on (their checksums are kept) and become the storage of the partitioned
-    # shards: no allocation or release of tens of GB inside this record -- hipMalloc / hipFree at that size cost seconds
-    # on this stack (§6 "Device memory pool"), which an earlier version of this record measured instead of the build.
     W = n_slices
     kw = dict(only_save_one_node_per_kmer=True, max_variant_nodes=max_variant_nodes)
     from graph_kmer_index_amd import DenseKmerFinder
-    from graph_kmer_index_amd.sharding import shard_range
-    finder = DenseKmerFinder(g, k, critical_graph_paths=cp, **kw)     # one finder, one device handle, eight chunks
-    ranges, sizes_in = [], []
-    for r in range(W):
-        a, b = shard_range(g, cp, r, W)
-        finder.set_critical_path_range(a, b)
-        ranges.append((a, b))
-        sizes_in.append(finder._count(layout=1))
-    if sum(sizes_in) != n:
-        raise _lib.GkiError(2, "full_index: the shards hold %d records, the step %d" % (sum(sizes_in), n))
-    mine = DeviceFlatKmers.allocate(max(sizes_in))                    # one shard's columns, reused
+    finder = DenseKmerFinder(g, k, critical_graph_paths=cp, **kw)
+    finder._params()
+    if finder._count(layout=1) != n:
+        raise _lib.GkiError(2, "full_index: the graph holds %d records, the step wrote %d" % (finder._count(layout=1), n))
+    parts = DeviceFlatKmers.allocate(n)                   # the partitioned records: 24 B x n beside the step's own columns
+    # everything once untimed: sizes the library's memory pool (hipMalloc / hipFree of tens of GB cost seconds on this stack,
+    # DESIGN.md section 6 "Device memory pool"; the index_build record measures its third build for the same reason)
+    _, start = partition_by_bucket_range(out, modulo, W, out=parts)
+    biggest = max(range(W), key=lambda p: start[p + 1] - start[p])
+    lo, hi = bucket_range(modulo, W, biggest)
+    a, m = start[biggest], start[biggest + 1] - start[biggest]
+    sl = DeviceIndex.build(DeviceFlatKmers(m, *[getattr(parts, c).view(a, m) for c in cols]), modulo, bucket_begin=lo, n_buckets=hi - lo)
+    sl.free()
     sync()
     pool0 = _lib.pool_stats()
-    t_all = time.perf_counter()
-    t_find = t_part = t_copy = t_build = 0.0
-    find_ms = []
-    shards, starts = [], []
-    at = 0
-    for r in range(W):
-        finder.set_critical_path_range(*ranges[r])
-        finder._params()                              # (host-side validation of the chunk: not device work)
-        sync()
-        t = time.perf_counter()
-        mine = finder.find_flat_on_device(mine)
-        finder.synchronize()
-        find_ms.append(1e3 * (time.perf_counter() - t))
-        t_find += time.perf_counter() - t
-        t = time.perf_counter()
-        dest = DeviceFlatKmers(mine.n, *[getattr(out, c).view(at, mine.n) for c in cols])
-        by_dest, send_start = partition_by_bucket_range(mine, modulo, W, out=dest)
-        sync()
-        t_part += time.perf_counter() - t
-        at += mine.n
-        shards.append(by_dest)
-        starts.append(send_start)
-    mine.free()
+    t = time.perf_counter()
+    out = finder.find_flat_on_device(out)
+    finder.synchronize()
+    t_find = time.perf_counter() - t
+    want = [getattr(out, c).checksum(n) for c in cols]
+    sync()
+    t = time.perf_counter()
+    _, start = partition_by_bucket_range(out, modulo, W, out=parts)
+    sync()
+    t_part = time.perf_counter() - t
     got = [(0, 0)] * 4
-    sizes = []
-    recv = DeviceFlatKmers.allocate(max(sum(st[p + 1] - st[p] for st in starts) for p in range(W)))      # one slice's records, reused
-    for p in [-1] + list(range(W)):                # p = -1: slice 0 once untimed, it sizes the library's memory pool (the
-        warm = p < 0                               # index_build record measures its third build for the same reason)
-        p = max(p, 0)
-        t_copy0, t_build0 = t_copy, t_build
-        t = time.perf_counter()
-        n_p = sum(st[p + 1] - st[p] for st in starts)
-        recv.n = n_p
-        at = 0
-        for part, st in zip(shards, starts):
-            m = st[p + 1] - st[p]
-            for col in cols:
-                src, dst = getattr(part, col), getattr(recv, col)
-                if m:
-                    _lib.check(lib.gki_memcpy_d2d(dst.view(at, m).ptr, src.view(st[p], m).ptr, m * src.dtype.itemsize))
-            at += m
-        sync()
-        t_copy += time.perf_counter() - t
-        t = time.perf_counter()
+    sizes, build_ms, nonempty = [], [], 0
+    t_build = 0.0
+    for p in range(W):
         lo, hi = bucket_range(modulo, W, p)
-        sl = DeviceIndex.build(recv, modulo, bucket_begin=lo, n_buckets=hi - lo)
+        a, m = start[p], start[p + 1] - start[p]
+        view = DeviceFlatKmers(m, *[getattr(parts, c).view(a, m) for c in cols])
         sync()
+        t = time.perf_counter()
+        sl = DeviceIndex.build(view, modulo, bucket_begin=lo, n_buckets=hi - lo)
+        sync()
+        build_ms.append(1e3 * (time.perf_counter() - t))
         t_build += time.perf_counter() - t
-        if warm:
-            t_copy, t_build = t_copy0, t_build0
-            pool0 = _lib.pool_stats()
-            sl.free()
-            continue
         for i, colname in enumerate(("kmers", "nodes", "ref_offsets", "allele_frequencies")):
-            s, x = getattr(sl, colname).checksum(sl.n)
-            got[i] = ((got[i][0] + s) & MASK, got[i][1] ^ x)
+            s_, x_ = getattr(sl, colname).checksum(sl.n)
+            got[i] = ((got[i][0] + s_) & MASK, got[i][1] ^ x_)
         sizes.append(sl.n)
+        nonempty += int(np.count_nonzero(sl.n_kmers.to_host()))
         sl.free()                    # checksummed and released before the next slice is built
-    recv.free()
-    dt_all = time.perf_counter() - t_all
     pool1 = _lib.pool_stats()
+    parts.free()
     total = sum(sizes)
+    dt = t_find + t_part + t_build
+    # as implemented, per record: the step 25 B; partition 8 R (histogram) + 24 R + 24 W; slice build 8 + 52 + 60 + 4 + 54
+    moved = (BYTES_PER_RECORD + 56 + 178) * total + 8 * modulo
     rec = {"records": int(total), "slices": W, "records_per_slice": sizes, "exceeds_int32_directory": bool(total >= 2 ** 31),
-           "find_shards_ms": 1e3 * t_find, "find_ms_per_shard": [round(x, 2) for x in find_ms], "partition_ms": 1e3 * t_part, "exchange_standin_copy_ms": 1e3 * t_copy,
-           "build_slices_ms": 1e3 * t_build, "ms": 1e3 * (t_find + t_part + t_copy + t_build),
-           "records_per_s": total / (t_find + t_part + t_copy + t_build),
+           "find_ms": 1e3 * t_find, "partition_ms": 1e3 * t_part, "build_slices_ms": 1e3 * t_build,
+           "build_ms_per_slice": [round(x, 2) for x in build_ms], "ms": 1e3 * dt, "records_per_s": total / dt,
+           "roofline": index_roofline(total, modulo, nonempty, dt, hashing=True),
+           "roofline_at_three_sort_passes": index_roofline(total, modulo, nonempty, dt, hashing=True, passes=3),
+           "bytes_moved_model": int(moved), "achieved_GBps_as_implemented": moved / dt / 1e9,
+           "frac_of_hbm_peak_as_implemented": moved / dt / 1e9 / HBM_PEAK_GBS,
            "device_allocator": {"hipMalloc_calls": pool1[0] - pool0[0], "hipFree_calls": pool1[1] - pool0[1],
                                 "ms_in_hipMalloc": pool1[2] - pool0[2], "ms_in_hipFree": pool1[3] - pool0[3],
-                                "note": "inside the slice builds above, after slice 0 was built once untimed to size the library's "
-                                        "pool: what still reaches hipMalloc / hipFree"},
+                                "note": "inside the timed phases, after one untimed partition and one untimed slice build sized "
+                                        "the library's pool: what still reaches hipMalloc / hipFree"},
            "equals_step_output": bool(total == n),
            "payload_equals_flat_multiset": [tuple(w) for w in want] == [tuple(x) for x in got],
-           "timed": "wall clock, device synchronised per phase: %d critical-path shards enumerated (gki_finder_count + "
-                    "gki_finder_emit_flat) and partitioned by bucket range, per slice a device copy of its parts in rank order "
-                    "+ gki_index_build_range with frequencies; hashed AND indexed, end to end" % W}
-    log("full index: %d records in %d slices: find %.0f + partition %.0f + copy %.0f + build %.0f ms" % (total, W, 1e3 * t_find, 1e3 * t_part, 1e3 * t_copy, 1e3 * t_build))
+           "timed": "wall clock, device synchronised per phase: the whole graph enumerated and hashed (gki_finder_count + "
+                    "gki_finder_emit_flat), its records partitioned by bucket range into %d slices (gki_partition_by_bucket_range, "
+                    "one call), every slice built with frequencies (gki_index_build_range); hashed AND indexed, end to end; "
+                    "checksums of the slices outside the timed phases" % W}
+    log("full index: %d records in %d slices: find %.1f + partition %.1f + build %.1f = %.1f ms" % (total, W, 1e3 * t_find, 1e3 * t_part, 1e3 * t_build, 1e3 * dt))
     return rec
 
 
@@ -825,6 +838,12 @@ def main():
             res["verify"] = checks
         if secondary is not None:
             res["index_build"], res["read_mapping"], res["early_stop_search"], res["full_index"] = secondary
+            fi = res["full_index"]
+            if fi and "records_per_s" in fi:
+                # the metric's own words: every record of the graph hashed AND indexed, end to end (`value` above times
+                # enumeration + hashing; the index build of all records is the full_index record)
+                res["value_hashed_and_indexed"] = fi["records_per_s"]
+                res["hashed_and_indexed_roofline_frac"] = fi["roofline"]["frac"]
         res["cpu_baseline"] = cpu
     if world > 1 and plain and not args.no_sharded_build:
         # The exchange has never run between real GPUs (one GPU per builder box): if a rank fails or a collective never

@@ -191,9 +191,10 @@ def bucket_range(modulo, n_parts, part):
     return modulo * part // n_parts, modulo * (part + 1) // n_parts
 
 
-def partition_by_bucket_range(dflat, modulo, n_parts, out=None):
+def partition_by_bucket_range(dflat, modulo, n_parts, out=None, max_rows_per_pass=0):
     """Stable partition of device FlatKmers columns by owning part.  Returns (DeviceFlatKmers, part_start[n_parts+1]).
-    `out`: columns to write into (at least dflat.n records, not overlapping dflat) instead of a fresh allocation."""
+    `out`: columns to write into (at least dflat.n records, not overlapping dflat) instead of a fresh allocation.
+    Any number of records (2^31 and more go through several passes, `max_rows_per_pass` at a time; 0: the default)."""
     _lib.require_device()
     if out is None:
         out = DeviceFlatKmers.allocate(dflat.n)
@@ -201,9 +202,9 @@ def partition_by_bucket_range(dflat, modulo, n_parts, out=None):
         assert out.hashes.n >= dflat.n
         out.n = dflat.n
     start = (C.c_int64 * (n_parts + 1))()
-    _lib.check(_lib.load().gki_partition_by_bucket_range(
+    _lib.check(_lib.load().gki_partition_by_bucket_range_chunked(
         dflat.hashes.ptr, dflat.nodes.ptr, dflat.ref_offsets.ptr, dflat.allele_frequencies.ptr, dflat.n, int(modulo),
-        int(n_parts), out.hashes.ptr, out.nodes.ptr, out.ref_offsets.ptr, out.allele_frequencies.ptr, start))
+        int(n_parts), int(max_rows_per_pass), out.hashes.ptr, out.nodes.ptr, out.ref_offsets.ptr, out.allele_frequencies.ptr, start))
     return out, [int(x) for x in start]
 
 
@@ -303,6 +304,10 @@ class CounterKmerIndex:
         if min_nodes > n:
             got = np.concatenate([got, np.zeros(min_nodes - n)])
         return got
+
+
+_NO_HITS = np.zeros(0, dtype=np.int64)
+_ONE_HIT = np.zeros(1, dtype=np.int64)
 
 
 class CollisionFreeKmerIndex:
@@ -458,15 +463,33 @@ class CollisionFreeKmerIndex:
         return out
 
     # ------------------------------------------------------------------ probes
+    def _hit_positions(self, kmer):
+        """Positions of `kmer`'s records in the payload arrays, bucket order (collision_free_kmer_index.py:304-309), from
+        this object's own host arrays: one k-mer is a latency-bound accessor -- a device round trip (launch +
+        synchronisation, ~20 us) costs four times the bucket's few reads, so the scalar getters stay on the host and the
+        device serves the batched ones (and `DeviceIndex.get_small` the indexes that only exist in HBM)."""
+        kmer = int(kmer)
+        b = kmer % self._modulo
+        n = int(self._n_kmers[b])                                            # :306
+        if n == 0:
+            return _NO_HITS
+        s = int(self._hashes_to_index[b])                                    # :305
+        try:
+            if n == 1:
+                return _ONE_HIT + s if self._kmers[s] == kmer else _NO_HITS
+            return np.flatnonzero(self._kmers[s:s + n] == kmer) + s          # :309
+        except OverflowError:                                                # a query no element of the column can equal
+            return _NO_HITS
+
     def get(self, kmer, max_hits=10):
-        """collision_free_kmer_index.py:303-315, served by the batched device probe with one query; the hit
-        positions index this object's own arrays, so every dtype comes back as stored."""
-        n, pos = self._device_index().get_small([int(kmer)], max_hits)[0]
-        if n > len(pos):                                 # a k-mer with more than 1024 records: the batched pair
-            _, pos, _ = self._device_index().lookup_positions(np.array([int(kmer)], dtype=np.uint64), max_hits)
+        """collision_free_kmer_index.py:303-315."""
+        pos = self._hit_positions(kmer)
         if len(pos) == 0:
             return None, None, None, None
-        return self._nodes[pos], self._ref_offsets[pos], self._frequencies[pos], self._allele_frequencies[pos]
+        frequencies = self._frequencies[pos]
+        if frequencies[0] > max_hits:                                        # :312
+            return None, None, None, None
+        return self._nodes[pos], self._ref_offsets[pos], frequencies, self._allele_frequencies[pos]
 
     def __contains__(self, item):
         return self.get(int(item), 100000000000)[0] is not None
@@ -485,14 +508,15 @@ class CollisionFreeKmerIndex:
         return [nodes[a:b] for a, b in zip(idx[:-1], idx[1:])]
 
     def get_frequency(self, kmer, include_reverse_complement=True, k=31):
-        """:336-352 -- the k-mer and its reverse complement in ONE launch (first hit's frequency of each)."""
+        """:336-352 -- the first hit's frequency of the k-mer, plus that of its reverse complement."""
         queries = [int(kmer)]
         if include_reverse_complement:
             queries.append(int(kmer_hash_to_reverse_complement_hash(kmer, k)))
         f = 0
-        for n, pos in self._device_index().get_small(queries, 1000000000000000, capacity=1):
-            if n:                                        # the first hit's frequency (:342, :349)
-                f += int(np.asarray(self._frequencies)[pos[0]])
+        for q in queries:
+            pos = self._hit_positions(q)
+            if len(pos):                                 # the first hit's frequency (:342, :349)
+                f += int(self._frequencies[pos[0]])
         return f
 
     def get_frequencies(self, kmers, include_reverse_complement=True, k=31):

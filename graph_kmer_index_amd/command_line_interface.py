@@ -51,6 +51,11 @@ def index(args):
         if ranks > 1:
             return index_on_ranks(args, ranks)
         logging.info("-t %d: one device visible, one process" % args.n_threads)
+    shard = None
+    if args.shard is not None:                       # one rank of `index -t N`: its device FIRST -- the critical paths
+        from . import _lib                           # below are computed on the device and the graph upload is cached on
+        shard = tuple(int(x) for x in args.shard.split("/"))     # the graph object: both must land on this rank's GPU
+        _lib.check(_lib.load().gki_set_device(shard[0] % max(1, _lib.device_count())))
     graph = load_graph(args.graph)
     k = args.kmer_size
     cp = load_critical_paths(args.critical_graph_paths) or CriticalGraphPaths.from_graph(graph, k)
@@ -58,11 +63,9 @@ def index(args):
     if args.whitelist is not None:
         whitelist = CollisionFreeKmerIndex.from_file(args.whitelist)                      # :634 (`kmer in whitelist`)
     chunk = {}
-    if args.shard is not None:                       # one rank of `index -t N`: its range of critical-path numbers
-        from . import _lib
+    if shard is not None:                            # its range of critical-path numbers
         from .sharding import shard_range
-        r, w = (int(x) for x in args.shard.split("/"))
-        _lib.check(_lib.load().gki_set_device(r % max(1, _lib.device_count())))
+        r, w = shard
         a, b = shard_range(GraphArrays.from_obgraph(graph), cp, r, w)
         chunk = dict(start_at_critical_path_number=a, stop_at_critical_path_number=b)
     finder = DenseKmerFinder(graph, k, critical_graph_paths=cp, max_variant_nodes=args.max_variant_nodes,

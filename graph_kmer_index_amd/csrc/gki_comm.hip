@@ -72,12 +72,19 @@ int gki_comm_create(gki_comm **out, int world_size, int rank, const void *h_id) 
     *out = nullptr;
     if (world_size < 1 || rank < 0 || rank >= world_size) return gki_set_error(GKI_ERR_BAD_ARG, "bad rank %d of %d", rank, world_size);
     GKI_TRY(load_rccl());
-    gki_comm *c = new gki_comm();
-    c->world = world_size; c->rank = rank;
     ncclUniqueId id;
     memcpy(&id, h_id, sizeof(id));
-    HIP_TRY(hipStreamCreate(&c->stream));
-    NCCL_TRY(g_rccl.CommInitRank(&c->comm, world_size, id, rank));
+    hipStream_t stream = nullptr;
+    HIP_TRY(hipStreamCreate(&stream));
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = g_rccl.CommInitRank(&comm, world_size, id, rank);
+    if (r != ncclSuccess) {                              // nothing of a half-built communicator stays behind
+        (void)hipStreamDestroy(stream);
+        return gki_set_error(GKI_ERR_HIP, "ncclCommInitRank(world %d, rank %d) -> %s", world_size, rank,
+                             g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error");
+    }
+    gki_comm *c = new gki_comm();
+    c->world = world_size; c->rank = rank; c->stream = stream; c->comm = comm;
     *out = c;
     return GKI_OK;
 }

@@ -53,6 +53,17 @@ __device__ __forceinline__ uint64_t gki_extract(const uint64_t *__restrict__ seq
     return v & ((1ull << (2 * t)) - 1ull);   // t <= 31
 }
 
+// ---------------------------------------------------------------------------------- x % modulo
+// bucket = kmer % modulo (collision_free_kmer_index.py:304, :433) without the 64-bit division routine (~100 instructions
+// for a run-time divisor): q = mulhi(x, floor((2^64 - 1) / modulo)) is the quotient or one or two short.
+struct GkiMod { uint64_t m, inv; };
+static inline GkiMod gki_mod_of(uint64_t modulo) { GkiMod d; d.m = modulo; d.inv = ~0ull / modulo; return d; }
+__device__ __forceinline__ uint64_t gki_mod(const GkiMod &d, uint64_t x) {
+    uint64_t r = x - __umul64hi(x, d.inv) * d.m;
+    while (r >= d.m) r -= d.m;
+    return r;
+}
+
 // ---------------------------------------------------------------------------------- device graph view
 struct alignas(32) NodeWalk { // everything the boundary walk needs about a node, one aligned 32-B record
     int64_t seq_start;
@@ -128,6 +139,9 @@ struct gki_graph {
     int64_t fwd_deep_bytes;
     FwdScript fwd_script;                    // early-stop search: what the count call left for the emit call (csrc/gki_forward.hip)
 };
+
+// GKI_ERR_BAD_ARG unless the device that is current is the one the graph was uploaded to (gki_finder.hip)
+int gki_check_graph_device(const gki_graph *g, const char *who);
 
 // ---------------------------------------------------------------------------------- device error word
 // Kernels report the two conditions a run can end on through ONE word, as bits, so that the outcome does not depend on

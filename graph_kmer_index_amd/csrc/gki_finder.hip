@@ -1334,7 +1334,9 @@ struct gki_finder {
     uint16_t *nflags; uint8_t *store; // general graphs / only_store_nodes (gki_find_params), allocated on first use
     void *scan_tmp; int64_t scan_tmp_bytes;
     int *d_err; int64_t *d_totals; unsigned long long *d_bsum;
-    int64_t *h_totals;                // pinned: {total, error, boundary records, 0, boundary sum} read back by every count
+    int64_t *h_totals;                // pinned: {total, error, boundary records, 0, boundary sum} read back by every count;
+                                      // [5]: the error word after the emit kernels (read by gki_finder_synchronize)
+    bool emit_pending;                // an emit call's error word has not been looked at yet
     int32_t *d_rank;                  // topological ranks of the run in progress (non-topological node ids only)
     DeepArena deep;                   // cap > 0: the run in progress needed the deep kernel variants (their stacks live here)
     int64_t deep_bytes;
@@ -1497,20 +1499,33 @@ static int emit_impl(gki_finder *f, typename OutSel<FMT>::T out) {
     };
     if (boundary_first) { GKI_TRY(run_boundary()); GKI_TRY(run_interior()); }
     else { GKI_TRY(run_interior()); GKI_TRY(run_boundary()); }
+    // an emit kernel that cannot write a group's records (all-nodes mode: 64 consecutive nodes with more than 2^32
+    // records between them; a window deeper than the count pass met) raises the error word and leaves them unwritten:
+    // gki_finder_synchronize returns it (nothing read the word after an emit launch)
+    f->h_totals[5] = 0;
+    HIP_TRY(hipMemcpyAsync(&f->h_totals[5], f->d_err, 4, hipMemcpyDeviceToHost, s2));
+    f->emit_pending = true;
     HIP_TRY(hipEventRecord(f->ev_join, s2));
     HIP_TRY(hipStreamWaitEvent(s, f->ev_join, 0));
     f->ev_valid[1] = true; f->ev_valid[2] = true;
     return GKI_OK;
 }
 
+// The graph's arrays live on ONE device: a finder (its streams and buffers) or an early-stop search made while another
+// device is current would launch kernels there that dereference this device's memory (`index -t N` ranks
+// selected their GPU after the graph upload).  Refuse instead of faulting.
+int gki_check_graph_device(const gki_graph *g, const char *who) {
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != g->device)
+        return gki_set_error(GKI_ERR_BAD_ARG, "%s: the graph was uploaded to device %d, the current device is %d "
+                             "(call gki_set_device before gki_graph_create)", who, g->device, dev);
+    return GKI_OK;
+}
+
 extern "C" {
 
-int gki_finder_create(gki_graph *g, gki_finder **out) {
-    *out = nullptr;
-    if (!g) return gki_set_error(GKI_ERR_BAD_ARG, "finder_create: graph is NULL");
-    gki_finder *f = new gki_finder();
-    memset(f, 0, sizeof(*f));
-    f->g = g;
+static int finder_init(gki_finder *f, gki_graph *g) {
     const int64_t n = g->d.n_nodes;
     HIP_TRY(hipStreamCreate(&f->stream));
     HIP_TRY(hipStreamCreate(&f->stream2));
@@ -1528,26 +1543,38 @@ int gki_finder_create(gki_graph *g, gki_finder **out) {
     HIP_TRY(gki_dev_malloc((void **)&f->d_totals, 4 * 8));
     HIP_TRY(hipMemset(f->d_totals, 0, 4 * 8));
     HIP_TRY(gki_dev_malloc((void **)&f->d_bsum, 8));
-    HIP_TRY(hipHostMalloc((void **)&f->h_totals, 5 * 8, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&f->h_totals, 6 * 8, hipHostMallocDefault));
     f->scan_tmp_bytes = gki_scan_tmp_bytes(n);
     HIP_TRY(gki_dev_malloc(&f->scan_tmp, (size_t)f->scan_tmp_bytes));
+    return GKI_OK;
+}
+
+int gki_finder_create(gki_graph *g, gki_finder **out) {
+    *out = nullptr;
+    if (!g) return gki_set_error(GKI_ERR_BAD_ARG, "finder_create: graph is NULL");
+    GKI_TRY(gki_check_graph_device(g, "gki_finder_create"));
+    gki_finder *f = new gki_finder();
+    memset(f, 0, sizeof(*f));
+    f->g = g;
+    const int rc = finder_init(f, g);
+    if (rc != GKI_OK) { (void)gki_finder_destroy(f); return rc; }      // nothing of a half-built finder stays behind
     *out = f;
     return GKI_OK;
 }
 
 int gki_finder_destroy(gki_finder *f) {
     if (!f) return GKI_OK;
-    (void)hipStreamSynchronize(f->stream);
-    (void)hipStreamSynchronize(f->stream2);
+    if (f->stream) (void)hipStreamSynchronize(f->stream);
+    if (f->stream2) (void)hipStreamSynchronize(f->stream2);
     void *ptrs[] = {f->bcount, f->total, f->rec_base, f->bnd_base, f->ne, f->lossy, f->scan_tmp, f->d_err, f->d_totals, f->d_bsum,
                     f->d_rank, f->nflags, f->store, f->deep.base};
     for (void *p : ptrs) if (p) (void)gki_dev_free(p);
     if (f->h_totals) (void)hipHostFree(f->h_totals);
-    for (int i = 0; i < 8; i++) (void)hipEventDestroy(f->ev[i]);
-    (void)hipEventDestroy(f->ev_ready);
-    (void)hipEventDestroy(f->ev_join);
-    (void)hipStreamDestroy(f->stream);
-    (void)hipStreamDestroy(f->stream2);
+    for (int i = 0; i < 8; i++) if (f->ev[i]) (void)hipEventDestroy(f->ev[i]);
+    if (f->ev_ready) (void)hipEventDestroy(f->ev_ready);
+    if (f->ev_join) (void)hipEventDestroy(f->ev_join);
+    if (f->stream) (void)hipStreamDestroy(f->stream);
+    if (f->stream2) (void)hipStreamDestroy(f->stream2);
     delete f;
     return GKI_OK;
 }
@@ -1728,6 +1755,14 @@ int gki_finder_emit_v2(gki_finder *f, void *d_hashes, void *d_start_nodes, void 
 int gki_finder_synchronize(gki_finder *f) {
     HIP_TRY(hipStreamSynchronize(f->stream));
     HIP_TRY(hipStreamSynchronize(f->stream2));
+    if (f->emit_pending) {
+        f->emit_pending = false;
+        const int64_t word = f->h_totals[5] & 0xFFFFFFFFll;
+        if (word)
+            return gki_set_error(gki_error_of_word(word), "the emit pass left records unwritten (error word %lld): in all-nodes mode 64 "
+                                 "consecutive nodes may hold at most 2^32 records between them -- run the graph in chunks "
+                                 "(gki_find_params.node_begin / node_end)", (long long)word);
+    }
     return GKI_OK;
 }
 

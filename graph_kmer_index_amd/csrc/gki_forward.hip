@@ -319,6 +319,25 @@ __global__ __launch_bounds__(256) void k_forward_expand(const uint4 *__restrict_
 }  // namespace
 
 namespace {
+// the slow path's arena: grown by the call that needs it, returned to the pool when the search is over
+void deep_release(gki_graph *gr) {
+    if (gr->fwd_deep.base) (void)gki_dev_free(gr->fwd_deep.base);
+    gr->fwd_deep = DeepArena{nullptr, 0, 0, 0};
+    gr->fwd_deep_bytes = 0;
+}
+int deep_grow(gki_graph *gr, int next_cap) {
+    const int64_t lanes = 64 * 256, bytes = lanes * (int64_t)next_cap * FW_CELL;
+    if (bytes > gr->fwd_deep_bytes) {
+        if (gr->fwd_deep.base) (void)gki_dev_free(gr->fwd_deep.base);
+        gr->fwd_deep.base = nullptr; gr->fwd_deep_bytes = 0;
+        if (gki_dev_malloc((void **)&gr->fwd_deep.base, (size_t)bytes) != hipSuccess)
+            return gki_set_error(GKI_ERR_HIP, "forward search: no memory for %lld bytes of deep stacks", (long long)bytes);
+        gr->fwd_deep_bytes = bytes;
+    }
+    gr->fwd_deep.lanes = lanes; gr->fwd_deep.cap = next_cap; gr->fwd_deep.pad = 0;
+    return GKI_OK;
+}
+
 void script_drop(gki_graph *gr) {
     FwdScript &sc = gr->fwd_script;
     if (sc.entries) (void)gki_dev_free(sc.entries);
@@ -333,7 +352,9 @@ int gki_forward_count(gki_graph *gr, int k, int max_variant_nodes, int one_node,
                       const void *d_offsets, int64_t n_pos, void *d_rec_start, int64_t *n_records) {
     *n_records = 0;
     if (k < 1 || k > GKI_MAX_K) return gki_set_error(GKI_ERR_BAD_ARG, "k must be in 1..31");
+    GKI_TRY(gki_check_graph_device(gr, "gki_forward_count"));
     if (n_pos <= 0) { HIP_TRY(hipMemset(d_rec_start, 0, 8)); return GKI_OK; }
+    deep_release(gr);                     // a slow-path arena of an earlier search goes back to the pool (up to 5.6 GB)
     uint32_t *cnt = nullptr; void *tmp = nullptr; int *d_err = nullptr;
     int64_t tmp_bytes = gki_scan_tmp_bytes(n_pos);
     HIP_TRY(gki_dev_malloc((void **)&cnt, (size_t)n_pos * 4));
@@ -377,14 +398,8 @@ int gki_forward_count(gki_graph *gr, int k, int max_variant_nodes, int one_node,
         // bit 1: a stack of the walk was too short -- again with the deep variant, twice the levels each time round
         const int next_cap = da.cap == 0 ? 4 * FMAX : 2 * da.cap;
         if (!(word[0] & 2) || (word[0] & 4) || next_cap > GKI_MAX_DEEP_WINDOW_NODES) break;
-        const int64_t lanes = 64 * 256, bytes = lanes * (int64_t)next_cap * FW_CELL;
-        if (bytes > gr->fwd_deep_bytes) {
-            if (gr->fwd_deep.base) (void)gki_dev_free(gr->fwd_deep.base);
-            gr->fwd_deep.base = nullptr; gr->fwd_deep_bytes = 0;
-            if (gki_dev_malloc((void **)&gr->fwd_deep.base, (size_t)bytes) != hipSuccess) { rc = gki_set_error(GKI_ERR_HIP, "forward search: no memory for %lld bytes of deep stacks", (long long)bytes); break; }
-            gr->fwd_deep_bytes = bytes;
-        }
-        gr->fwd_deep.lanes = lanes; gr->fwd_deep.cap = next_cap; gr->fwd_deep.pad = 0;
+        rc = deep_grow(gr, next_cap);
+        if (rc != GKI_OK) break;
     }
     (void)gki_dev_free(cnt); (void)gki_dev_free(tmp); (void)gki_dev_free(d_err);
     const int herr = rc == GKI_OK && e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess ? gki_error_of_word(word[0]) : -1;
@@ -408,35 +423,54 @@ int gki_forward_emit(gki_graph *gr, int k, int max_variant_nodes, int one_node, 
                      const void *d_offsets, int64_t n_pos, const void *d_rec_start, void *d_hashes, void *d_start_nodes, void *d_start_offsets,
                      void *d_nodes_out, void *d_af64) {
     if (n_pos <= 0) return GKI_OK;
+    GKI_TRY(gki_check_graph_device(gr, "gki_forward_emit"));
     int *d_err = nullptr;
     HIP_TRY(gki_dev_malloc((void **)&d_err, 4));
-    HIP_TRY(hipMemset(d_err, 0, 4));
     FwdOut out{(int64_t *)d_hashes, (int32_t *)d_start_nodes, (int16_t *)d_start_offsets, (int32_t *)d_nodes_out, (double *)d_af64};
-    const DeepArena da = gr->fwd_deep;         // cap > 0: the count call of this search needed the slow path
     const int M = max_variant_nodes > 250 ? 250 : max_variant_nodes;
     FwdScript &sc = gr->fwd_script;
-    const bool scripted = sc.valid && da.cap == 0 && sc.n_pos == n_pos && sc.nodes == d_nodes && sc.offsets == d_offsets && sc.follow == d_follow &&
-                          sc.rec_start == d_rec_start && sc.k == k && sc.M == M && sc.one_node == (one_node ? 1 : 0);
-    if (da.cap > 0)
-        hipLaunchKernelGGL((k_forward<true, true>), dim3((unsigned)(da.lanes / 64)), dim3(64), 0, 0, gr->d, k, M, one_node, (const uint8_t *)d_follow,
-                           (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, (uint32_t *)nullptr, (const int64_t *)d_rec_start, out, d_err, da,
-                           (uint4 *)nullptr, (uint8_t *)nullptr);
-    else if (scripted) {
-        hipLaunchKernelGGL(k_forward_expand, dim3((unsigned)ceil_div(n_pos * FW_SLOTS, 256)), dim3(256), 0, 0, (const uint4 *)sc.entries, sc.ncomp,
-                           (const int64_t *)d_rec_start, n_pos, out);
-        if (sc.overflow > 0)                // the start positions the script could not hold: walked as before
+    int word = 0, rc = GKI_OK;
+    hipError_t e = hipSuccess, e2 = hipSuccess, e3 = hipSuccess;
+    // The arena state on the graph handle is whatever the LAST count call left (cap > 0: it needed the slow path), which
+    // need not be this search's count call (count(A), count(B), emit(A); two finders on one graph).  The emit pass
+    // therefore settles the depth itself: it reads its own error word and goes round again with the deep variant like the
+    // count pass does (the word was never read and a too-short stack lost records silently).  Records already
+    // written are written again with the same values.
+    for (;;) {
+        const DeepArena da = gr->fwd_deep;
+        e3 = hipMemset(d_err, 0, 4);
+        const bool scripted = sc.valid && da.cap == 0 && sc.n_pos == n_pos && sc.nodes == d_nodes && sc.offsets == d_offsets && sc.follow == d_follow &&
+                              sc.rec_start == d_rec_start && sc.k == k && sc.M == M && sc.one_node == (one_node ? 1 : 0);
+        if (da.cap > 0)
+            hipLaunchKernelGGL((k_forward<true, true>), dim3((unsigned)(da.lanes / 64)), dim3(64), 0, 0, gr->d, k, M, one_node, (const uint8_t *)d_follow,
+                               (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, (uint32_t *)nullptr, (const int64_t *)d_rec_start, out, d_err, da,
+                               (uint4 *)nullptr, (uint8_t *)nullptr);
+        else if (scripted) {
+            hipLaunchKernelGGL(k_forward_expand, dim3((unsigned)ceil_div(n_pos * FW_SLOTS, 256)), dim3(256), 0, 0, (const uint4 *)sc.entries, sc.ncomp,
+                               (const int64_t *)d_rec_start, n_pos, out);
+            if (sc.overflow > 0)                // the start positions the script could not hold: walked as before
+                hipLaunchKernelGGL((k_forward<true, false>), dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, k, M, one_node, (const uint8_t *)d_follow,
+                                   (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, (uint32_t *)nullptr, (const int64_t *)d_rec_start, out, d_err, da,
+                                   (uint4 *)nullptr, sc.ncomp);
+        } else
             hipLaunchKernelGGL((k_forward<true, false>), dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, k, M, one_node, (const uint8_t *)d_follow,
                                (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, (uint32_t *)nullptr, (const int64_t *)d_rec_start, out, d_err, da,
-                               (uint4 *)nullptr, sc.ncomp);
-    } else
-        hipLaunchKernelGGL((k_forward<true, false>), dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, k, M, one_node, (const uint8_t *)d_follow,
-                           (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, (uint32_t *)nullptr, (const int64_t *)d_rec_start, out, d_err, da,
-                           (uint4 *)nullptr, (uint8_t *)nullptr);
-    hipError_t e = hipGetLastError();
-    hipError_t e2 = hipDeviceSynchronize();
+                               (uint4 *)nullptr, (uint8_t *)nullptr);
+        e = hipGetLastError();
+        e2 = hipMemcpy(&word, d_err, 4, hipMemcpyDeviceToHost);          // (synchronises)
+        if (e != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) break;
+        const int next_cap = da.cap == 0 ? 4 * FMAX : 2 * da.cap;
+        if (!(word & 2) || (word & 4) || next_cap > GKI_MAX_DEEP_WINDOW_NODES) break;
+        rc = deep_grow(gr, next_cap);
+        if (rc != GKI_OK) break;
+    }
     (void)gki_dev_free(d_err);
     script_drop(gr);                        // one emit per count: a second emit call walks
-    HIP_TRY(e); HIP_TRY(e2);
+    deep_release(gr);                       // and the arena goes back to the pool
+    if (rc != GKI_OK) return rc;
+    HIP_TRY(e); HIP_TRY(e2); HIP_TRY(e3);
+    const int herr = gki_error_of_word(word);
+    if (herr) return gki_set_error(herr, "the emit pass of the early-stop search left records unwritten (error word %d)", word);
     return GKI_OK;
 }
 

@@ -18,8 +18,8 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
                          void *d_hashes_to_index, void *d_n_kmers, void *d_out_kmers, void *d_out_nodes,
                          void *d_out_ref_offsets, void *d_out_af32, void *d_out_frequencies, void *d_out_permutation, int *done);
 int gki_partition_columns_by_part(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
-                                  uint64_t modulo, int n_parts, void *d_out_kmers, void *d_out_nodes, void *d_out_ref_offsets,
-                                  void *d_out_af32, int64_t *h_part_start);
+                                  uint64_t modulo, int n_parts, int64_t max_rows_per_pass, void *d_out_kmers, void *d_out_nodes,
+                                  void *d_out_ref_offsets, void *d_out_af32, int64_t *h_part_start);
 int gki_frequencies_for_rows(const int64_t *d_row_begin, const int64_t *d_row_end, int n_ranges, uint64_t modulo,
                              uint64_t bucket_begin, const void *d_hashes_to_index, const void *d_n_kmers,
                              const void *d_kmers, const void *d_refs, void *d_freq, int64_t n, hipStream_t s);
@@ -669,17 +669,23 @@ int gki_index_build(const void *d_kmers, const void *d_nodes, const void *d_ref_
                                  d_out_frequencies, d_out_permutation);
 }
 
+int gki_partition_by_bucket_range_chunked(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32,
+                                          int64_t n, uint64_t modulo, int n_parts, int64_t max_rows_per_pass, void *d_out_kmers,
+                                          void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32, int64_t *h_part_start) {
+    if (modulo == 0 || modulo > 0xFFFFFFFFull) return gki_set_error(GKI_ERR_BAD_ARG, "modulo must be in 1..2^32-1");
+    if (n_parts < 1 || n_parts > 256) return gki_set_error(GKI_ERR_BAD_ARG, "n_parts must be in 1..256");
+    for (int p = 0; p <= n_parts; p++) h_part_start[p] = 0;
+    if (n <= 0) return GKI_OK;
+    // stable passes of the row-carrying build's partition kernel, columns in, columns out (gki_index_rows.hip)
+    return gki_partition_columns_by_part(d_kmers, d_nodes, d_ref_offsets, d_af32, n, modulo, n_parts, max_rows_per_pass, d_out_kmers,
+                                         d_out_nodes, d_out_ref_offsets, d_out_af32, h_part_start);
+}
+
 int gki_partition_by_bucket_range(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32,
                                   int64_t n, uint64_t modulo, int n_parts, void *d_out_kmers, void *d_out_nodes,
                                   void *d_out_ref_offsets, void *d_out_af32, int64_t *h_part_start) {
-    if (modulo == 0 || modulo > 0xFFFFFFFFull) return gki_set_error(GKI_ERR_BAD_ARG, "modulo must be in 1..2^32-1");
-    if (n_parts < 1 || n_parts > 256) return gki_set_error(GKI_ERR_BAD_ARG, "n_parts must be in 1..256");
-    if (n >= (1ll << 31)) return gki_set_error(GKI_ERR_OVERFLOW, "%lld records: partition at most 2^31-1 at a time", (long long)n);
-    for (int p = 0; p <= n_parts; p++) h_part_start[p] = 0;
-    if (n <= 0) return GKI_OK;
-    // one stable pass of the row-carrying build's partition kernel, columns in, columns out (gki_index_rows.hip)
-    return gki_partition_columns_by_part(d_kmers, d_nodes, d_ref_offsets, d_af32, n, modulo, n_parts, d_out_kmers, d_out_nodes,
-                                         d_out_ref_offsets, d_out_af32, h_part_start);
+    return gki_partition_by_bucket_range_chunked(d_kmers, d_nodes, d_ref_offsets, d_af32, n, modulo, n_parts, 0, d_out_kmers,
+                                                 d_out_nodes, d_out_ref_offsets, d_out_af32, h_part_start);
 }
 
 int gki_flag_repeated_kmers(const void *d_kmers, int64_t n, void *d_flags) {

@@ -41,7 +41,15 @@ def kmer_hashes_to_reverse_complement_hash_chunked(hashes, k, chunk_size=1000000
 
 
 def kmer_hash_to_reverse_complement_hash(hash, k):
-    return kmer_hashes_to_reverse_complement_hash(np.array([hash]), k)[0]
+    """kmer_hashing.py:12-13 for ONE hash, in plain integer arithmetic (a device round trip per scalar costs more than
+    the 2k bits are worth): complement every 2-bit digit, reverse the digit order.  Returns numpy.uint64 like the
+    reference's `[...][0]`."""
+    assert k <= 31
+    x = ~int(hash) & ((1 << (2 * k)) - 1)                                           # digit d -> 3 - d
+    x = ((x >> 2) & 0x3333333333333333) | ((x & 0x3333333333333333) << 2)          # reverse the 32 digits of the 64-bit
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0F) | ((x & 0x0F0F0F0F0F0F0F0F) << 4)          # word: digits inside a nibble, nibbles
+    x = int.from_bytes(x.to_bytes(8, "little"), "big")                              # inside a byte, then the bytes
+    return np.uint64(x >> (64 - 2 * k))
 
 
 def kmer_hashes_to_complement_hashes(hashes, k):

@@ -27,9 +27,10 @@ extern "C" {
 #define GKI_ERR_HIP 1            /* a HIP runtime call failed (message has the HIP error string) */
 #define GKI_ERR_BAD_ARG 2
 #define GKI_ERR_NO_DEVICE 3
-#define GKI_ERR_WINDOW_TOO_DEEP 4 /* a k-window crosses more nodes than the kernels' stacks hold: GKI_MAX_DEEP_WINDOW_NODES for
-                                     gki_finder_count / emit (which fall back to their slow path above GKI_MAX_WINDOW_NODES),
-                                     GKI_MAX_WINDOW_NODES for the early-stop search (gki_forward_*) */
+#define GKI_ERR_WINDOW_TOO_DEEP 4 /* a k-window crosses more nodes than the kernels' stacks hold: GKI_MAX_DEEP_WINDOW_NODES, for
+                                     gki_finder_count / emit and for the early-stop search (gki_forward_*) alike -- both
+                                     fall back to their slow path above GKI_MAX_WINDOW_NODES.  Also: an emit pass that
+                                     had to leave records unwritten (gki_finder_synchronize, gki_forward_emit) */
 #define GKI_ERR_STATE 5          /* call order violated (e.g. emit before count) */
 #define GKI_ERR_OVERFLOW 6       /* a count does not fit the reference's dtype (e.g. int32 directory) */
 #define GKI_ERR_NOT_ONE_REF_SUCC 7 /* the reference's AssertionError kmer_finder.py:402: a reachable window at the
@@ -238,6 +239,8 @@ int gki_finder_emit_flat(gki_finder *f, void *d_hashes, void *d_nodes, void *d_r
  * start_offsets int16, nodes int32, allele_frequencies float64. */
 int gki_finder_emit_v2(gki_finder *f, void *d_hashes, void *d_start_nodes, void *d_start_offsets,
                        void *d_nodes, void *d_af64);
+/* Waits for the emit kernels; GKI_ERR_WINDOW_TOO_DEEP if an emit kernel had to leave records unwritten (all-nodes mode:
+ * 64 consecutive nodes hold more than 2^32 records between them -- run such a graph in chunks of nodes). */
 int gki_finder_synchronize(gki_finder *f);
 /* HIP-event time of the most recent launch of one kernel of this finder (after synchronize).
  * which: 0 count-boundary, 1 emit-interior, 2 emit-boundary, 3 scans (sum), 4 graph prepare. */
@@ -253,7 +256,10 @@ int64_t gki_finder_interior_records(const gki_finder *f);
  * d_follow: uint8[n_nodes] membership of only_follow_nodes (:386-388) or NULL.
  * gki_forward_count may leave the finished k-mers in a buffer owned by the graph (192 bytes per start position, all-nodes
  * mode); the next gki_forward_emit with the SAME arguments expands them instead of walking again and releases the buffer.
- * Any other sequence of calls is answered by walking; the results are the same. */
+ * Any other sequence of calls (count(A), count(B), emit(A); a second emit) is answered by walking, and the emit pass
+ * settles by itself whether it needs the slow path's deeper stacks: the results are the same.  The slow path's arena
+ * (up to 5.6 GB) goes back to the library's pool when the emit call returns.  Calls on one graph handle must not overlap
+ * in time (two host threads sharing a graph serialise their searches). */
 int gki_forward_count(gki_graph *g, int k, int max_variant_nodes, int one_node, const void *d_follow,
                       const void *d_nodes, const void *d_offsets, int64_t n_pos, void *d_rec_start,
                       int64_t *n_records);
@@ -279,13 +285,20 @@ int gki_index_build(const void *d_kmers, const void *d_nodes, const void *d_ref_
 /* Bucket-range partitioned build.  Part p of n_parts owns the buckets
  * [modulo*p/n_parts, modulo*(p+1)/n_parts) (integer division): every GPU sorts and owns 1/n_parts of the directory,
  * which removes the redundant full sort of the all-gather build and the 2^31-records-per-index limit.
- * gki_partition_by_bucket_range: stable partition of n (< 2^31) records by part; h_part_start[n_parts+1] (host) receives
- *   the slice boundaries in the output columns.  n_parts <= 256.
+ * gki_partition_by_bucket_range: stable partition of n records (any number: more than 2^31 - 1 are taken in several
+ *   passes whose runs of a part are laid out behind each other) by part; h_part_start[n_parts+1] (host) receives the
+ *   slice boundaries in the output columns.  n_parts <= 256.  The output columns must not overlap the input.
+ * gki_partition_by_bucket_range_chunked: the same with at most max_rows_per_pass records per pass (0: the default);
+ *   bounds the pass's temporaries (a histogram entry per part and 4096 records).
  * gki_index_build_range: gki_index_build for the records of one slice: directory arrays int32 / uint32 [n_buckets],
  *   indexed by bucket - bucket_begin; a record whose bucket lies outside the range is GKI_ERR_BAD_ARG. */
 int gki_partition_by_bucket_range(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32,
                                   int64_t n, uint64_t modulo, int n_parts, void *d_out_kmers, void *d_out_nodes,
                                   void *d_out_ref_offsets, void *d_out_af32, int64_t *h_part_start);
+int gki_partition_by_bucket_range_chunked(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets,
+                                          const void *d_af32, int64_t n, uint64_t modulo, int n_parts,
+                                          int64_t max_rows_per_pass, void *d_out_kmers, void *d_out_nodes,
+                                          void *d_out_ref_offsets, void *d_out_af32, int64_t *h_part_start);
 int gki_index_build_range(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32,
                           int64_t n, uint64_t modulo, uint64_t bucket_begin, uint64_t n_buckets, int skip_frequencies,
                           void *d_hashes_to_index, void *d_n_kmers,

@@ -250,3 +250,50 @@ def test_early_stop_bench_start_positions_follow_the_reference_pattern():
     # every start's segment is followed by a bubble: its successors are a ref allele and the alt allele
     succ_n = g.edge_start[nodes.astype(np.int64) + 1] - g.edge_start[nodes.astype(np.int64)]
     assert np.all(succ_n == 2)
+
+
+def test_scalar_getters_host_form_against_the_oracle(tmp_path):
+    """CollisionFreeKmerIndex.get / get_frequency / __contains__ answer one k-mer from the object's own NumPy arrays
+    (collision_free_kmer_index.py:303-315, :336-352) -- no device involved: checked here against the oracle's get on an
+    oracle-built index, hits, misses, the max_hits rule, int64 and uint64 columns, and after a file round trip."""
+    from graph_kmer_index_amd import CollisionFreeKmerIndex
+    from graph_kmer_index_amd.kmer_hashing import kmer_hash_to_reverse_complement_hash
+    rng = np.random.default_rng(12)
+    pool = rng.integers(0, 4 ** 31, size=3000, dtype=np.int64)
+    kmers = pool[rng.integers(0, len(pool), size=20000)]
+    kmers[:1500] = pool[0]                                        # one k-mer with 1500 records
+    nodes = rng.integers(0, 900, size=len(kmers)).astype(np.uint32)
+    refs = rng.integers(0, 40, size=len(kmers)).astype(np.uint64)
+    af = rng.random(len(kmers)).astype(np.float32)
+    ref = oracle.index_build(kmers.astype(np.uint64), nodes, refs, af, modulo=4001)
+    queries = [int(x) for x in pool[:200]] + [int(x) for x in rng.integers(0, 4 ** 31, size=80)]
+
+    def oracle_freq(q):
+        f = 0
+        for x in (q, int(kmer_hash_to_reverse_complement_hash(q, 31))):
+            r = oracle.index_get(ref, x, 10 ** 15)
+            f += 0 if r[0] is None else int(r[2][0])
+        return f
+
+    for kmer_dtype in (np.uint64, np.int64):
+        index = CollisionFreeKmerIndex(ref["_hashes_to_index"], ref["_n_kmers"], ref["_nodes"], ref["_ref_offsets"],
+                                       ref["_kmers"].astype(kmer_dtype), 4001, ref["_frequencies"], ref["_allele_frequencies"])
+        if kmer_dtype is np.int64:
+            index.to_file(str(tmp_path / "idx"))
+            index = CollisionFreeKmerIndex.from_file(str(tmp_path / "idx"))
+        n_none = 0
+        for mh in (1, 10, 10 ** 15):
+            for q in queries:
+                got, want = index.get(q, max_hits=mh), oracle.index_get(ref, q, mh)
+                if want[0] is None:
+                    n_none += 1
+                    assert got == (None, None, None, None)
+                    continue
+                for a, b in zip(got, want):
+                    assert a.dtype == b.dtype and np.array_equal(a, b)
+        assert n_none > 100
+        assert [index.get_frequency(q) for q in queries] == [oracle_freq(q) for q in queries]
+        assert [q in index for q in queries] == [oracle.index_get(ref, q, 10 ** 15)[0] is not None for q in queries]
+        assert list(index.get_nodes(queries[3])) == list(oracle.index_get(ref, queries[3])[0])
+    assert index._device is None                                  # nothing above touched the device
+    assert index.get(2 ** 64 + 5) == (None, None, None, None) and index.get(-3) == (None, None, None, None)

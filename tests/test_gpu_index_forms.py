@@ -50,6 +50,11 @@ def _check(dev, o, n, perm=None):
     (600000, 1000003, 400000, 30000),   # a 30 000-record bucket inside an ordinary index: one large group
     (70000, 1000003, 3, 0),             # three giant buckets
     (3000, 2, 1, 0),                    # a single k-mer
+    (800000, 100003, 300000, 0),        # 8 records per bucket, k-mers repeated 2-3 times: the finish ranks by ballots (dense
+                                        # slices of a whole-genome index), frequencies through the several-rows-per-k-mer path
+    (700000, 100003, 5000000, 0),       # 7 per bucket, nearly every k-mer once (the bench's full_index slices in small)
+    (300000, 100003, 100000, 0),        # 3 per bucket
+    (1000000, 49999, 700000, 0),        # 20 per bucket: most buckets near the per-lane frequency limit, some beyond it
 ])
 @pytest.mark.parametrize("skip_frequencies", [False, True])
 def test_both_forms_equal_the_oracle(n, modulo, n_distinct, heavy, skip_frequencies):

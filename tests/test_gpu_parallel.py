@@ -171,6 +171,25 @@ def test_partition_is_stable_and_complete():
     assert start == np.concatenate([[0], np.cumsum(np.bincount(part, minlength=n_parts))]).tolist()
 
 
+@pytest.mark.parametrize("n,n_parts,rows_per_pass", [(50000, 7, 4096), (50000, 8, 12000), (70001, 3, 8192), (9000, 256, 4096)])
+def test_partition_in_several_passes_equals_one_pass(n, n_parts, rows_per_pass):
+    """More than 2^31 - 1 records are partitioned in several passes whose runs of a part lie behind each other
+    (gki_partition_by_bucket_range_chunked): with a small pass the chunk seams are crossed at test size, and the result
+    is the stable partition of the whole input."""
+    flat, _ = _random_flat(n, n, 5)
+    dflat = DeviceFlatKmers.from_flat_kmers(flat)
+    modulo = 104729
+    out, start = partition_by_bucket_range(dflat, modulo, n_parts, max_rows_per_pass=rows_per_pass)
+    got = out.to_flat_kmers()
+    bucket = flat._hashes % np.uint64(modulo)
+    begins = np.array([bucket_range(modulo, n_parts, p)[0] for p in range(n_parts)], dtype=np.uint64)
+    part = np.searchsorted(begins, bucket, side="right") - 1
+    order = np.argsort(part, kind="stable")
+    for name in ("_hashes", "_nodes", "_ref_offsets", "_allele_frequencies"):
+        assert np.array_equal(getattr(got, name), getattr(flat, name)[order]), name
+    assert start == np.concatenate([[0], np.cumsum(np.bincount(part, minlength=n_parts))]).tolist()
+
+
 def test_rccl_world1_partitioned_build_and_read_mapping():
     g = synthetic_snp_graph(120000, 1300, k=31, seed=19)
     cp = CriticalGraphPaths.from_graph(g, 31)

@@ -15,7 +15,7 @@ tag = sys.argv[1]
 print("==", tag, open("gpurun_out/r3/ab_%s.json" % tag).read().strip())
 f = glob.glob("gpurun_out/r3/ab_%s/*/*kernel_stats.csv" % tag)[0]
 for r in csv.DictReader(open(f)):
-    if any(x in r["Name"] for x in ("k_partition", "k_group", "k_digit", "k_bucket_keys_hist")):
+    if any(x in r["Name"] for x in ("k_partition", "k_group", "k_digit", "k_bucket_keys_hist", "k_kmer_digit")):
         print("  %-50s x%-3s %8.3f ms" % (r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:50], r["Calls"], float(r["AverageNs"]) / 1e6))
 PY
 done
