@@ -185,6 +185,29 @@ def node_graph(args, plane, rank, local_rank):
     return g, t_gen, time.perf_counter() - t1, (gdir if local_rank == 0 else None)
 
 
+def adapter_times(g, args):
+    """GraphArrays.from_obgraph at this graph's size: an obgraph-like object over the synthetic graph
+    (tools/obgraph_like.py: the accessor methods + obgraph's whole-array attributes), (a) through its whole arrays --
+    the sample check against the accessors included --, (b) node by node through the accessors on a 2e5-node graph of
+    the same kind, scaled by nodes (the full walk takes minutes: the reason for (a))."""
+    if args.linear or args.indels or args.nested:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from obgraph_like import ObgraphLike
+    from graph_kmer_index_amd.graph import GraphArrays, synthetic_snp_graph
+    t = time.perf_counter()
+    got = GraphArrays.from_obgraph(ObgraphLike(g))
+    t_fast = time.perf_counter() - t
+    same = all(np.array_equal(getattr(got, c), getattr(g, c)) for c in ("node_size", "edge_start", "edges", "is_ref", "rev_start", "rev_edges"))
+    small = synthetic_snp_graph(40_000_000, 66_667, k=args.k, seed=1234)
+    t = time.perf_counter()
+    GraphArrays._from_obgraph_accessors(ObgraphLike(small, with_arrays=False))
+    t_small = time.perf_counter() - t
+    return {"nodes": int(g.n_nodes), "whole_arrays_s": t_fast, "equals_the_graph": bool(same),
+            "accessor_walk_s_scaled": t_small * g.n_nodes / small.n_nodes,
+            "accessor_walk_measured": {"nodes": int(small.n_nodes), "s": t_small}}
+
+
 # ------------------------------------------------------------------------------------------ CPU baselines (oracle)
 _CPU = {}
 
@@ -726,6 +749,7 @@ def main():
     plane = SocketControlPlane(rank, world)           # barrier + max / sum of two scalars; a no-op at world 1
 
     g, t_gen, t_map, cleanup_dir = node_graph(args, plane, rank, local_rank)
+    adapter = adapter_times(g, args) if rank == 0 and world == 1 else None
 
     from graph_kmer_index_amd import _lib, DenseKmerFinder, CriticalGraphPaths, DeviceGraph
     from graph_kmer_index_amd.sharding import shard_range
@@ -832,7 +856,7 @@ def main():
                                          + ("; per rank: %s" % ["%.0f" % c for c in ceilings] if world > 1 else "")},
             "kernels_ms_rank0_last_step": kern,
             "setup_s": {"generate_graph_host_once_per_node": t_gen, "map_shared_graph": t_map, "critical_paths_device": t_crit, "classify_nodes_and_run_parameters": t_cls,
-                        "upload_and_prepare": t_up},
+                        "upload_and_prepare": t_up, "from_obgraph_adapter": adapter},
         }
         if checks is not None:
             res["verify"] = checks

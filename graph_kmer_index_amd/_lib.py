@@ -36,12 +36,16 @@ class FindParams(C.Structure):
                 ("one_node_per_kmer", C.c_int32), ("layout", C.c_int32), ("node_begin", C.c_int64),
                 ("off_begin", C.c_int64), ("node_end", C.c_int64), ("off_end", C.c_int64),
                 ("h_lossy_crit", C.c_void_p), ("h_node_rank", C.c_void_p), ("h_node_flags", C.c_void_p),
-                ("h_store_nodes", C.c_void_p)]
+                ("h_store_nodes", C.c_void_p),
+                ("d_lossy_crit", C.c_void_p), ("d_node_rank", C.c_void_p), ("d_node_flags", C.c_void_p),
+                ("d_store_nodes", C.c_void_p), ("rank_begin", C.c_int32), ("rank_end", C.c_int32)]
 
     def __init__(self, k, max_variant_nodes, one_node_per_kmer, layout, node_begin, off_begin, node_end, off_end,
-                 h_lossy_crit=None, h_node_rank=None, h_node_flags=None, h_store_nodes=None):
+                 h_lossy_crit=None, h_node_rank=None, h_node_flags=None, h_store_nodes=None,
+                 d_lossy_crit=None, d_node_rank=None, d_node_flags=None, d_store_nodes=None, rank_begin=0, rank_end=0):
         super().__init__(C.sizeof(FindParams), k, max_variant_nodes, one_node_per_kmer, layout, node_begin, off_begin,
-                         node_end, off_end, h_lossy_crit, h_node_rank, h_node_flags, h_store_nodes)
+                         node_end, off_end, h_lossy_crit, h_node_rank, h_node_flags, h_store_nodes,
+                         d_lossy_crit, d_node_rank, d_node_flags, d_store_nodes, rank_begin, rank_end)
 
 
 class IndexView(C.Structure):

@@ -1331,6 +1331,7 @@ struct gki_finder {
     int64_t *rec_base, *bnd_base;     // by-node layout: rec_base only; split layout: interior bases / boundary bases
     NodeEmit *ne;
     uint16_t *lossy;
+    const uint16_t *lossy_cur;        // the table of the run in progress: `lossy` (uploaded by the count) or the caller's device table
     uint16_t *nflags; uint8_t *store; // general graphs / only_store_nodes (gki_find_params), allocated on first use
     void *scan_tmp; int64_t scan_tmp_bytes;
     int *d_err; int64_t *d_totals; unsigned long long *d_bsum;
@@ -1370,24 +1371,24 @@ static int launch_boundary_mode(gki_finder *f, const DevGraph &d, const FindArgs
         // arena, on the grid the arena was sized for
         const dim3 dgrid((unsigned)(da.lanes / (64 * BND_WPB)));
         if (a.nflags && a.has_lossy)
-            hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, true, true>), dgrid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err, da);
+            hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, true, true>), dgrid, block, 0, s2, d, a, f->lossy_cur, f->bcount, base, shift, out, f->d_err, da);
         else if (a.nflags)
-            hipLaunchKernelGGL((k_emit_boundary_one<false, FMT, ALL, true, true>), dgrid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err, da);
+            hipLaunchKernelGGL((k_emit_boundary_one<false, FMT, ALL, true, true>), dgrid, block, 0, s2, d, a, f->lossy_cur, f->bcount, base, shift, out, f->d_err, da);
         else if (a.has_lossy)
-            hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, false, true>), dgrid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err, da);
+            hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, false, true>), dgrid, block, 0, s2, d, a, f->lossy_cur, f->bcount, base, shift, out, f->d_err, da);
         else
-            hipLaunchKernelGGL((k_emit_boundary_one<false, FMT, ALL, false, true>), dgrid, block, 0, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err, da);
+            hipLaunchKernelGGL((k_emit_boundary_one<false, FMT, ALL, false, true>), dgrid, block, 0, s2, d, a, f->lossy_cur, f->bcount, base, shift, out, f->d_err, da);
         HIP_TRY(hipGetLastError());
         return GKI_OK;
     }
     if (a.nflags && a.has_lossy)
-        hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, true>), grid, block, emit_pad, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err, da);
+        hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, true>), grid, block, emit_pad, s2, d, a, f->lossy_cur, f->bcount, base, shift, out, f->d_err, da);
     else if (a.nflags)
-        hipLaunchKernelGGL((k_emit_boundary_one<false, FMT, ALL, true>), grid, block, emit_pad, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err, da);
+        hipLaunchKernelGGL((k_emit_boundary_one<false, FMT, ALL, true>), grid, block, emit_pad, s2, d, a, f->lossy_cur, f->bcount, base, shift, out, f->d_err, da);
     else if (a.has_lossy)
-        hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, false>), grid, block, emit_pad, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err, da);
+        hipLaunchKernelGGL((k_emit_boundary_one<true, FMT, ALL, false>), grid, block, emit_pad, s2, d, a, f->lossy_cur, f->bcount, base, shift, out, f->d_err, da);
     else
-        hipLaunchKernelGGL((k_emit_boundary_one<false, FMT, ALL, false>), grid, block, emit_pad, s2, d, a, f->lossy, f->bcount, base, shift, out, f->d_err, da);
+        hipLaunchKernelGGL((k_emit_boundary_one<false, FMT, ALL, false>), grid, block, emit_pad, s2, d, a, f->lossy_cur, f->bcount, base, shift, out, f->d_err, da);
     HIP_TRY(hipGetLastError());
     return GKI_OK;
 }
@@ -1588,13 +1589,13 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
                              "written against another version of include/gki.h", p->struct_size, (unsigned)sizeof(gki_find_params));
     if (p->k < 1 || p->k > GKI_MAX_K) return gki_set_error(GKI_ERR_BAD_ARG, "k must be in 1..31 (got %d)", p->k);
     if (p->max_variant_nodes < 0) return gki_set_error(GKI_ERR_BAD_ARG, "max_variant_nodes < 0");
-    if (p->node_begin < 0 || p->node_end > d.n_nodes || (!p->h_node_rank && p->node_begin > p->node_end))
+    if (p->node_begin < 0 || p->node_end > d.n_nodes || (!p->h_node_rank && !p->d_node_rank && p->node_begin > p->node_end))
         return gki_set_error(GKI_ERR_BAD_ARG, "bad node range [%lld, %lld]", (long long)p->node_begin, (long long)p->node_end);
     hipStream_t s = f->stream;
     FindArgs a;
     a.k = p->k; a.M = p->max_variant_nodes > 250 ? 250 : p->max_variant_nodes;
     a.one_node = p->one_node_per_kmer ? 1 : 0;
-    a.has_lossy = p->h_lossy_crit ? 1 : 0;
+    a.has_lossy = (p->h_lossy_crit || p->d_lossy_crit) ? 1 : 0;
     // tuning builds: run the lossy-restart kernel variants on a graph without such points (what does the variant cost?)
     const bool force_lossy = !a.has_lossy && GKI_KNOB("GKI_FORCE_LOSSY", 0) != 0;
     if (force_lossy) { HIP_TRY(hipMemsetAsync(f->lossy, 0xFF, (size_t)d.n_nodes * 2, s)); a.has_lossy = 1; }
@@ -1604,18 +1605,26 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
     a.split = p->layout == GKI_LAYOUT_SPLIT ? 1 : 0; a.pad = 0;
     a.rank = nullptr; a.rank_begin = 0; a.rank_end = 0;
     a.nflags = nullptr; a.store = nullptr;
-    if (p->h_store_nodes) {
-        if (!p->h_node_flags) return gki_set_error(GKI_ERR_BAD_ARG, "h_store_nodes needs h_node_flags (gki_classify_nodes)");
-        if (!f->store) HIP_TRY(gki_dev_malloc((void **)&f->store, (size_t)d.n_nodes));
-        HIP_TRY(hipMemcpyAsync(f->store, p->h_store_nodes, (size_t)d.n_nodes, hipMemcpyHostToDevice, s));
-        a.store = f->store;
+    // the four per-run tables: already on the device (d_ forms: nothing to upload), or host arrays uploaded per count
+    if (p->d_store_nodes || p->h_store_nodes) {
+        if (!p->h_node_flags && !p->d_node_flags) return gki_set_error(GKI_ERR_BAD_ARG, "store_nodes needs node_flags (gki_classify_nodes)");
+        if (p->d_store_nodes) a.store = p->d_store_nodes;
+        else {
+            if (!f->store) HIP_TRY(gki_dev_malloc((void **)&f->store, (size_t)d.n_nodes));
+            HIP_TRY(hipMemcpyAsync(f->store, p->h_store_nodes, (size_t)d.n_nodes, hipMemcpyHostToDevice, s));
+            a.store = f->store;
+        }
     }
-    if (p->h_node_flags) {
+    if (p->d_node_flags) a.nflags = p->d_node_flags;
+    else if (p->h_node_flags) {
         if (!f->nflags) HIP_TRY(gki_dev_malloc((void **)&f->nflags, (size_t)d.n_nodes * 2));
         HIP_TRY(hipMemcpyAsync(f->nflags, p->h_node_flags, (size_t)d.n_nodes * 2, hipMemcpyHostToDevice, s));
         a.nflags = f->nflags;
     }
-    if (p->h_node_rank) {
+    if (p->d_node_rank) {
+        a.rank = p->d_node_rank; a.rank_begin = p->rank_begin; a.rank_end = p->rank_end;
+        a.n0 = 0; a.n1 = d.n_nodes;
+    } else if (p->h_node_rank) {
         // node ids are not topological: membership by rank, every node is looked at
         if (!f->d_rank) HIP_TRY(gki_dev_malloc((void **)&f->d_rank, (size_t)d.n_nodes * 4));
         HIP_TRY(hipMemcpyAsync(f->d_rank, p->h_node_rank, (size_t)d.n_nodes * 4, hipMemcpyHostToDevice, s));
@@ -1626,7 +1635,11 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
     }
     f->args = a;
     const int64_t n_run = a.n1 - a.n0;
-    if (a.has_lossy && !force_lossy) HIP_TRY(hipMemcpyAsync(f->lossy, p->h_lossy_crit, (size_t)d.n_nodes * 2, hipMemcpyHostToDevice, s));
+    f->lossy_cur = f->lossy;
+    if (a.has_lossy && !force_lossy) {
+        if (p->d_lossy_crit) f->lossy_cur = p->d_lossy_crit;
+        else HIP_TRY(hipMemcpyAsync(f->lossy, p->h_lossy_crit, (size_t)d.n_nodes * 2, hipMemcpyHostToDevice, s));
+    }
     f->deep.cap = 0;                  // the product kernels first; a window deeper than their stacks sends the pass round again
     int64_t *tot = f->h_totals;       // pinned host memory: the two small copies are true async DMAs
     unsigned long long bsum = 0;
@@ -1645,25 +1658,25 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
             if (da.cap > 0) {
                 const dim3 dgrid((unsigned)(da.lanes / (64 * CNT_WPB)));
                 if (a.nflags && a.has_lossy)
-                    hipLaunchKernelGGL((k_count_boundary<true, true, true>), dgrid, dim3(64 * CNT_WPB), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
+                    hipLaunchKernelGGL((k_count_boundary<true, true, true>), dgrid, dim3(64 * CNT_WPB), 0, s, d, a, f->lossy_cur, f->bcount, f->total, f->d_err, da);
                 else if (a.nflags)
-                    hipLaunchKernelGGL((k_count_boundary<false, true, true>), dgrid, dim3(64 * CNT_WPB), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
+                    hipLaunchKernelGGL((k_count_boundary<false, true, true>), dgrid, dim3(64 * CNT_WPB), 0, s, d, a, f->lossy_cur, f->bcount, f->total, f->d_err, da);
                 else if (a.has_lossy)
-                    hipLaunchKernelGGL((k_count_boundary<true, false, true>), dgrid, dim3(64 * CNT_WPB), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
+                    hipLaunchKernelGGL((k_count_boundary<true, false, true>), dgrid, dim3(64 * CNT_WPB), 0, s, d, a, f->lossy_cur, f->bcount, f->total, f->d_err, da);
                 else
-                    hipLaunchKernelGGL((k_count_boundary<false, false, true>), dgrid, dim3(64 * CNT_WPB), 0, s, d, a, f->lossy, f->bcount, f->total, f->d_err, da);
+                    hipLaunchKernelGGL((k_count_boundary<false, false, true>), dgrid, dim3(64 * CNT_WPB), 0, s, d, a, f->lossy_cur, f->bcount, f->total, f->d_err, da);
             }
             else if (a.nflags && a.has_lossy)
-                hipLaunchKernelGGL((k_count_boundary<true, true>), dim3(count_grid), dim3(64 * CNT_WPB), cnt_pad, s, d, a, f->lossy,
+                hipLaunchKernelGGL((k_count_boundary<true, true>), dim3(count_grid), dim3(64 * CNT_WPB), cnt_pad, s, d, a, f->lossy_cur,
                                    f->bcount, f->total, f->d_err, da);
             else if (a.nflags)
-                hipLaunchKernelGGL((k_count_boundary<false, true>), dim3(count_grid), dim3(64 * CNT_WPB), cnt_pad, s, d, a, f->lossy,
+                hipLaunchKernelGGL((k_count_boundary<false, true>), dim3(count_grid), dim3(64 * CNT_WPB), cnt_pad, s, d, a, f->lossy_cur,
                                    f->bcount, f->total, f->d_err, da);
             else if (a.has_lossy)
-                hipLaunchKernelGGL((k_count_boundary<true, false>), dim3(count_grid), dim3(64 * CNT_WPB), cnt_pad, s, d, a, f->lossy,
+                hipLaunchKernelGGL((k_count_boundary<true, false>), dim3(count_grid), dim3(64 * CNT_WPB), cnt_pad, s, d, a, f->lossy_cur,
                                    f->bcount, f->total, f->d_err, da);
             else
-                hipLaunchKernelGGL((k_count_boundary<false, false>), dim3(count_grid), dim3(64 * CNT_WPB), cnt_pad, s, d, a, f->lossy,
+                hipLaunchKernelGGL((k_count_boundary<false, false>), dim3(count_grid), dim3(64 * CNT_WPB), cnt_pad, s, d, a, f->lossy_cur,
                                    f->bcount, f->total, f->d_err, da);
             HIP_TRY(hipGetLastError());
         }
@@ -1676,7 +1689,7 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
         if (n_run > 0) {
             // one node per thread, no grid-stride loop: a thread's loads and its 48-byte store form one dependent chain, so the
             // kernel lives on the number of chains in flight
-            hipLaunchKernelGGL(k_node_emit, dim3((unsigned)ceil_div(n_run, 256)), dim3(256), 0, s, d, a, f->lossy, f->bcount,
+            hipLaunchKernelGGL(k_node_emit, dim3((unsigned)ceil_div(n_run, 256)), dim3(256), 0, s, d, a, f->lossy_cur, f->bcount,
                                f->rec_base, f->ne);
             HIP_TRY(hipGetLastError());
         }

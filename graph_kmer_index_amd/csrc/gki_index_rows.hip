@@ -333,21 +333,32 @@ __global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
 }
 
 // First row and one-past-last row of every group (group = key >> L) in the keys sorted by group; arrays zeroed before.
-// One coalesced load per key, the neighbours' keys by shuffle (the two edge lanes of a wave load theirs).
+// Four keys per lane (one 16-byte load), the key before a lane's four from the lane below (the first lane of a wave loads
+// it): a boundary between rows i - 1 and i ends the group of i - 1 and begins the group of i.  Round 3's form (one key per
+// lane, 2048 grid-stride workgroups) ran at 1.4 TB/s: 1.09 ms per 3.95e8 keys.
 __global__ __launch_bounds__(256) void k_group_bounds(const uint32_t *__restrict__ keys, int64_t n, int L,
                                                       uint32_t *__restrict__ gbegin, uint32_t *__restrict__ gend) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int lane = threadIdx.x & 63;
-    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); i0 < n; i0 += stride) {
-        const int64_t i = i0 + lane;
-        const bool valid = i < n;
-        const uint32_t g = valid ? keys[i] >> L : 0u;
-        uint32_t before = __shfl_up(g, 1, 64), after = __shfl_down(g, 1, 64);
-        if (lane == 0 && i > 0) before = keys[i - 1] >> L;
-        if (lane == 63 && i + 1 < n) after = keys[i + 1] >> L;
-        if (!valid) continue;
-        if (i == 0 || before != g) gbegin[g] = (uint32_t)i;
-        if (i == n - 1 || after != g || (lane < 63 && i + 1 >= n)) gend[g] = (uint32_t)(i + 1);
+    const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    uint32_t g[4] = {0, 0, 0, 0};
+    if (base + 3 < n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(keys + base);
+        g[0] = v.x >> L; g[1] = v.y >> L; g[2] = v.z >> L; g[3] = v.w >> L;
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; t++) if (base + t < n) g[t] = keys[base + t] >> L;
+    }
+    uint32_t before = __shfl_up(g[3], 1, 64);
+    if (lane == 0 && base > 0 && base < n) before = keys[base - 1] >> L;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int64_t i = base + t;
+        if (i < n) {
+            const uint32_t prev = t == 0 ? before : g[t - 1];
+            if (i == 0) gbegin[g[t]] = 0;
+            else if (prev != g[t]) { gbegin[g[t]] = (uint32_t)i; gend[prev] = (uint32_t)i; }
+            if (i == n - 1) gend[g[t]] = (uint32_t)n;
+        }
     }
 }
 
@@ -700,6 +711,12 @@ __global__ __launch_bounds__(THREADS) void k_kmer_digit_hist(const uint64_t *__r
 #ifndef GKI_PT_RI
 #define GKI_PT_RI 8
 #endif
+// tile of the bucket-range partition (<= 256 parts: its runs are long whatever the tile): 2048 rows, 72 KB of LDS, two
+// workgroups per CU -- one loads while the other stores: 50.1 -> 45.0 ms per 3.16e9 records, same box
+// (profiles/r04_full_index_ab.txt).  The build's 512- and 1024-way passes keep 4096-row tiles (longer runs matter more there).
+#ifndef GKI_PR_THREADS
+#define GKI_PR_THREADS 256
+#endif
 
 // Which way k_group_finish ranks the rows of a bucket: by ballots (cost independent of the bucket) from this many rows per
 // bucket on, by LDS atomics + a loop over the bucket below it.  -DGKI_FINISH_WRANK=0 / =1 force one way (A/B builds).
@@ -802,7 +819,7 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
             cur_rows = a.rows_out; cur_keys = a.keys_out;
             shift += bits;
         }
-        hipLaunchKernelGGL(k_group_bounds, dim3(stream_grid(n, 256)), dim3(256), 0, s, cur_keys, n, L, gbegin, gend);
+        hipLaunchKernelGGL(k_group_bounds, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s, cur_keys, n, L, gbegin, gend);
         HIP_G(hipGetLastError());
         hipLaunchKernelGGL(k_group_scan, dim3(stream_grid(n_groups, 256)), dim3(256), 0, s, gbegin, gend, n_groups,
                            (uint32_t)GROUP_CAP, stats, large, large_cap);
@@ -889,7 +906,7 @@ __global__ void k_part_bases(ChunkOffs co, int n_parts, int bins, int64_t *__res
 int gki_partition_columns_by_part(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
                                   uint64_t modulo, int n_parts, int64_t max_rows_per_pass, void *d_out_kmers, void *d_out_nodes,
                                   void *d_out_ref_offsets, void *d_out_af32, int64_t *h_part_start) {
-    constexpr int THREADS = GKI_PT_THREADS, RI = GKI_PT_RI, TILE = THREADS * RI;
+    constexpr int THREADS = GKI_PR_THREADS, RI = GKI_PT_RI, TILE = THREADS * RI;
     hipStream_t s = 0;
     int bits = 0;
     while ((1 << bits) < n_parts) bits++;

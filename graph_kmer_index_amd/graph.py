@@ -21,6 +21,8 @@ uploaded to HBM once:
 object can be handed to code written against obgraph (used by the golden-vector
 generator to drive the reference on synthetic graphs).
 """
+import logging
+
 import numpy as np
 
 _LETTER_TO_CODE = np.zeros(256, dtype=np.uint8)
@@ -45,6 +47,36 @@ def _csr_from_lists(n_nodes, adjacency):
     for n, lst in adjacency.items():
         flat[start[n]:start[n] + len(lst)] = lst
     return start, flat
+
+
+def _ragged_rows(r, n_rows):
+    """(row_start int64[n_rows + 1], flat) of a ragged array with npstructures.RaggedArray's surface -- flat data from
+    `ravel()` or `_data`, row bounds from `shape.starts` / `shape.lengths` (`_shape` in older versions) -- cut or padded
+    with empty rows to n_rows, the rows laid out one after the other.  None when the object offers no such thing."""
+    if r is None:
+        return None
+    shape = getattr(r, "shape", None)
+    if not hasattr(shape, "starts"):
+        shape = getattr(r, "_shape", None)
+    starts, lengths = getattr(shape, "starts", None), getattr(shape, "lengths", None)
+    flat = r.ravel() if hasattr(r, "ravel") else getattr(r, "_data", None)
+    if starts is None or lengths is None or flat is None:
+        return None
+    starts, lengths, flat = np.asarray(starts, dtype=np.int64), np.asarray(lengths, dtype=np.int64), np.asarray(flat)
+    if starts.ndim != 1 or starts.shape != lengths.shape or flat.ndim != 1:
+        return None
+    m = min(n_rows, len(lengths))
+    row_len = np.zeros(n_rows, dtype=np.int64)
+    row_len[:m] = lengths[:m]
+    row_start = np.zeros(n_rows + 1, dtype=np.int64)
+    np.cumsum(row_len, out=row_start[1:])
+    total = int(row_start[-1])
+    if m and (lengths[:m].min() < 0 or starts[:m].min() < 0 or int((starts[:m] + lengths[:m]).max()) > len(flat)):
+        return None
+    if np.array_equal(starts[:m], row_start[:m]):                   # the usual case: rows already back to back
+        return row_start, flat[:total]
+    src = np.repeat(starts[:m] - row_start[:m], row_len[:m]) + np.arange(total, dtype=np.int64)
+    return row_start, flat[src]
 
 
 def _reverse_csr(n_nodes, edge_start, edges):
@@ -147,16 +179,90 @@ class GraphArrays:
         return cls(node_size, seq, edge_start, flat_edges, is_ref, af, exists, first, chrom, ntro)
 
     @classmethod
-    def from_obgraph(cls, graph):
-        """Extract the flat arrays through the accessor methods the reference itself uses
-        (SURVEY.md 8b); obgraph's private array names are not relied upon."""
+    def from_obgraph(cls, graph, check_nodes=2000):
+        """The flat arrays of an obgraph `Graph`.
+
+        The reference reads the graph node by node inside its search (kmer_finder.py:259, :279, :350, :384, :138, :143);
+        the device wants it whole.  Two ways:
+          * whole arrays, when the object offers them (duck-typed, obgraph's private layout is not verifiable offline):
+            ragged `edges` / `numeric_node_sequences` with npstructures' RaggedArray surface (`ravel()` or `_data`,
+            `shape.starts` / `shape.lengths`), the per-node accessors called with an array of all nodes
+            (`is_linear_ref_node_or_linear_ref_dummy_node`, `get_node_allele_frequencies`).  What they give is compared
+            with the accessor methods on `check_nodes` random nodes (plus the first and last ones) before it is trusted;
+          * otherwise -- or when that comparison fails -- the accessor methods node by node: two Python
+            loops, minutes at the 1.5e7 nodes of a human graph."""
         if isinstance(graph, cls):
             return graph
+        fast = cls._from_obgraph_arrays(graph)
+        if fast is not None:
+            bad = cls._first_disagreement(graph, fast, check_nodes)
+            if bad is None:
+                return fast
+            logging.warning("from_obgraph: the graph's whole arrays disagree with its accessors (%s): reading node by node" % bad)
+        return cls._from_obgraph_accessors(graph)
+
+    @classmethod
+    def _obgraph_head(cls, graph):
         n_nodes = int(graph.max_node_id()) + 1
         sizes = np.asarray(graph.nodes)
         node_size = np.zeros(n_nodes, dtype=np.int32)
         m = min(n_nodes, len(sizes))
         node_size[:m] = sizes[:m]
+        return n_nodes, node_size
+
+    @classmethod
+    def _obgraph_tail(cls, graph, n_nodes, node_size, seq, edge_start, flat_edges, is_ref, exists):
+        af = np.asarray(graph.get_node_allele_frequencies(np.arange(n_nodes)), dtype=np.float64)
+        chrom = list(graph.chromosome_start_nodes.values())
+        ntro = getattr(graph, "node_to_ref_offset", None)
+        return cls(node_size, seq, edge_start, flat_edges, is_ref, af, exists, int(graph.get_first_node()), chrom, ntro)
+
+    @classmethod
+    def _from_obgraph_arrays(cls, graph):
+        """None unless the object offers everything as whole arrays."""
+        try:
+            n_nodes, node_size = cls._obgraph_head(graph)
+            e = _ragged_rows(getattr(graph, "edges", None), n_nodes)
+            q = _ragged_rows(getattr(graph, "numeric_node_sequences", None), n_nodes)
+            if e is None or q is None:
+                return None
+            edge_start, flat_edges = e
+            seq_start, seq = q
+            if not np.array_equal(np.diff(seq_start), node_size):
+                return None
+            if len(flat_edges) and (flat_edges.min() < 0 or flat_edges.max() >= n_nodes):
+                return None
+            ref = np.asarray(graph.is_linear_ref_node_or_linear_ref_dummy_node(np.arange(n_nodes)))
+            if ref.shape != (n_nodes,):
+                return None
+            has_pred = np.bincount(flat_edges, minlength=n_nodes) > 0
+            exists = ((node_size > 0) | (np.diff(edge_start) > 0) | has_pred).astype(np.uint8)
+            is_ref = ((ref != 0) & (exists != 0)).astype(np.uint8)
+            return cls._obgraph_tail(graph, n_nodes, node_size, seq, edge_start, flat_edges, is_ref, exists)     # (no copies: views of the object's arrays)
+        except (AttributeError, TypeError, ValueError, IndexError, KeyError):
+            return None
+
+    @staticmethod
+    def _first_disagreement(graph, arrays, check_nodes):
+        """A node on which the accessor methods and `arrays` differ (as text), or None."""
+        n = arrays.n_nodes
+        rng = np.random.default_rng(n)
+        nodes = np.unique(np.concatenate([rng.integers(0, n, size=min(n, int(check_nodes))), np.arange(min(n, 8)),
+                                          np.arange(max(0, n - 8), n)]))
+        for v in nodes.tolist():
+            if [int(x) for x in graph.get_edges(v)] != arrays.get_edges(v):
+                return "edges of node %d" % v
+            if arrays.node_size[v] > 0 and not np.array_equal(np.asarray(graph.get_numeric_node_sequence(v)),
+                                                            arrays.get_numeric_node_sequence(v)):
+                return "sequence of node %d" % v
+            if arrays.exists[v] and bool(graph.is_linear_ref_node_or_linear_ref_dummy_node(v)) != bool(arrays.is_ref[v]):
+                return "linear-ref flag of node %d" % v
+        return None
+
+    @classmethod
+    def _from_obgraph_accessors(cls, graph):
+        """Through the accessor methods the reference itself uses, node by node."""
+        n_nodes, node_size = cls._obgraph_head(graph)
         rev = graph.get_reverse_edges_hashtable()
         adjacency, seqs = {}, []
         exists = np.zeros(n_nodes, dtype=np.uint8)
@@ -177,11 +283,7 @@ class GraphArrays:
                 is_ref[n] = 1 if graph.is_linear_ref_node_or_linear_ref_dummy_node(n) else 0
         seq = np.concatenate(seqs) if seqs else np.zeros(0, dtype=np.uint8)
         edge_start, flat_edges = _csr_from_lists(n_nodes, adjacency)
-        af = np.asarray(graph.get_node_allele_frequencies(np.arange(n_nodes)), dtype=np.float64)
-        chrom = list(graph.chromosome_start_nodes.values())
-        ntro = getattr(graph, "node_to_ref_offset", None)
-        return cls(node_size, seq, edge_start, flat_edges, is_ref, af, exists,
-                   int(graph.get_first_node()), chrom, ntro)
+        return cls._obgraph_tail(graph, n_nodes, node_size, seq, edge_start, flat_edges, is_ref, exists)
 
     # ------------------------------------------------------------------ .npz round trip
     _FILE_KEYS = ("node_size", "seq", "edge_start", "edges", "is_ref", "allele_freq", "exists")

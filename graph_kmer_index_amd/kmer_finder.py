@@ -12,10 +12,11 @@ kernels then enumerate those histories (`classify_nodes`, include/gki.h GKI_NODE
 `assert len(next_nodes) == 1` (kmer_finder.py:402) fails, find() raises `_lib.NotOneLinearRefSuccessor`
 (an AssertionError).
 
-Still refused:
-  * a chromosome other than the first starting with a node shorter than k -> NotImplementedError
+Refused:
   * a critical point (N, c) with 3 <= c < k-1 on a node longer than 2k+3: the reference itself
     emits meaningless hashes there (SURVEY.md 8a' E1 + bulk path)        -> ValueError
+  * a k-window over more than GKI_MAX_DEEP_WINDOW_NODES - 2 (12 286) nodes, or more paths into one end node than the
+    walk will enumerate -> `_lib.WindowTooDeep` (a RecursionError, which is how the reference ends there)
 """
 import ctypes as C
 import logging
@@ -87,6 +88,19 @@ def classify_nodes(g, k, max_variant_nodes, only_follow_nodes=None, critical_nod
     return cache[key]
 
 
+def _resident(owner, table):
+    """The device copy of a host table, uploaded once per (owner, table object): `owner` (a graph or a finder) keeps the
+    last few, each together with the host array it mirrors (so that the identity stays valid)."""
+    _lib.require_device()
+    cache = owner.__dict__.setdefault("_resident_tables", {})
+    hit = cache.get(id(table))
+    if hit is None or hit[0] is not table:
+        if len(cache) >= 6:
+            cache.pop(next(iter(cache)))[1].free()
+        hit = cache[id(table)] = (table, _lib.DeviceArray.from_host(np.ascontiguousarray(table)))
+    return hit[1]
+
+
 def lossy_table(g, k, crit_nodes, crit_offsets, start_at=None, stop_at=None):
     """uint16[n_nodes] of critical offsets c with 0 < c < k-1 (SURVEY.md 8a' E1), or None.  Raises for the critical
     points THIS run restarts from (numbers [start_at, stop_at), kmer_finder.py:192-205) at which the reference's output
@@ -134,6 +148,7 @@ class DenseKmerFinder:
         self._stop_at_critical_path_number = stop_at_critical_path_number
         self._whitelist = whitelist
         self._only_store_nodes = only_store_nodes
+        self._store_table = None
         self._only_follow_nodes = only_follow_nodes   # kmer_finder.py:386-388 (unique_variant_kmers.py:91-96)
         self._params_cache = None
         self._whitelist_device = None
@@ -188,13 +203,24 @@ class DenseKmerFinder:
         flags, general = classify_nodes(g, k, self._max_variant_nodes, self._only_follow_nodes, crit_nodes)
         crit_offsets = np.asarray(cp.offsets).astype(np.int64)
         start_at, stop_at = self._start_at_critical_path_number, self._stop_at_critical_path_number
-        lossy = lossy_table(g, k, crit_nodes, crit_offsets, start_at, stop_at)
+        lossy = lossy_table(g, k, crit_nodes, crit_offsets, start_at, stop_at)     # (raises for THIS run's restarts; the table
+        patch = None                                                                #  itself is the same for every chunk)
         if start_at is not None and 0 < start_at < len(crit_nodes) and crit_offsets[start_at] == 0:
             # A run that STARTS at a critical point at offset 0 is not rewound either (:231-232): none of its windows
             # reaches before that node.  (In a full run the previous search passes through the point and emits them.)
-            if lossy is None:
-                lossy = np.full(g.n_nodes, 0xFFFF, dtype=np.uint16)
-            lossy[int(crit_nodes[start_at])] = 0
+            patch = int(crit_nodes[start_at])
+        if lossy is not None or patch is not None:
+            # one array object per distinct content, so that its device copy is uploaded once (_resident)
+            known = self.__dict__.setdefault("_lossy_tables", {})
+            if patch not in known:
+                if len(known) >= 3:
+                    known.pop(next(iter(known)))
+                if lossy is None:
+                    lossy = np.full(g.n_nodes, 0xFFFF, dtype=np.uint16)
+                if patch is not None:
+                    lossy[patch] = 0
+                known[patch] = lossy
+            lossy = known[patch]
         node_begin, off_begin, node_end, off_end = 0, 0, g.n_nodes, 0
         n_crit = len(crit_nodes)
         chunked = False
@@ -239,16 +265,30 @@ class DenseKmerFinder:
         general = general or getattr(self, "_force_general_kernels", False)    # bench.py --general: price of the flags
         store = None
         if self._only_store_nodes is not None:                     # kmer_finder.py:153, applied by the general kernels
-            store = np.zeros(g.n_nodes, dtype=np.uint8)
-            ids = np.fromiter((int(x) for x in self._only_store_nodes), dtype=np.int64)
-            store[ids[(ids >= 0) & (ids < g.n_nodes)]] = 1
+            store = self._store_table
+            if store is None:
+                store = np.zeros(g.n_nodes, dtype=np.uint8)
+                ids = np.fromiter((int(x) for x in self._only_store_nodes), dtype=np.int64)
+                store[ids[(ids >= 0) & (ids < g.n_nodes)]] = 1
+                self._store_table = store
             general = True
-        p = _lib.FindParams(k, self._max_variant_nodes, int(self._only_save_one_node_per_kmer), 0,
-                            node_begin, off_begin, node_end, off_end, _lib.hptr(lossy), _lib.hptr(rank),
-                            _lib.hptr(flags) if general else None, _lib.hptr(store))
-        p._keep = (lossy, rank, flags, store)
         if node_begin >= g.n_nodes:
             return None
+        # The per-run tables stay resident in HBM: uploaded once per graph (flags, ranks) or per finder (store set, lossy
+        # restarts), handed to gki_finder_count as device pointers -- a chunked run (`index -t N`, shards, one count per
+        # chunk) re-uploaded up to 2 + 1 + 2 + 4 bytes per node per chunk before.
+        d_flags = _resident(g, flags) if general else None
+        d_rank = _resident(g, rank) if rank is not None else None
+        d_store = _resident(self, store) if store is not None else None
+        d_lossy = _resident(self, lossy) if lossy is not None else None
+        INT_MAX = 2 ** 31 - 1
+        rank_begin = int(rank[node_begin]) if rank is not None and node_begin < g.n_nodes else INT_MAX
+        rank_end = int(rank[node_end]) if rank is not None and node_end < g.n_nodes else INT_MAX
+        ptr = lambda d: None if d is None else d.ptr
+        p = _lib.FindParams(k, self._max_variant_nodes, int(self._only_save_one_node_per_kmer), 0,
+                            node_begin, off_begin, node_end, off_end, None, None, None, None,
+                            ptr(d_lossy), ptr(d_rank), ptr(d_flags), ptr(d_store), rank_begin, rank_end)
+        p._keep = (lossy, rank, flags, store, d_lossy, d_rank, d_flags, d_store)
         return p
 
     def set_critical_path_range(self, start_at_critical_path_number, stop_at_critical_path_number):

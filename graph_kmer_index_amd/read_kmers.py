@@ -88,6 +88,12 @@ class ReadKmers:
             read = "".join("acgt"[int(c) & 3] for c in read) if read.dtype.kind in "iu" else "".join(read.tolist())
         return hash_reads([read], k, 0)[0]
 
+    @staticmethod
+    def get_kmers_from_read_dynamic_slow(read, k):
+        """read_kmers.py:72-74: the reference raises before its rolling-hash loop runs; so does this (use
+        `get_kmers_from_read_dynamic`)."""
+        raise NotImplementedError()
+
     def __iter__(self):
         return self.kmers.__iter__()
 

@@ -206,6 +206,16 @@ typedef struct {
      * node in the set -- except the records of the bulk path (offsets k+2 .. size-2 of a node longer than 2k+3), which
      * the reference writes regardless (:370-374).  Needs h_node_flags (the general kernels apply it). */
     const uint8_t *h_store_nodes;
+    /* The same four tables already RESIDENT on the finder's device (same dtypes and lengths); a non-NULL d_ pointer is
+     * used as it is and its h_ twin is ignored: nothing is uploaded by gki_finder_count.  For chunked runs (one count per
+     * chunk of critical-path numbers, every `index -t N` rank) and for flags that gki_graph_classify_nodes left on the
+     * device.  The tables must stay valid until the emit that follows the count has completed.  With d_node_rank the
+     * ranks of node_begin and node_end come in rank_begin / rank_end (node_end == n_nodes: INT32_MAX). */
+    const uint16_t *d_lossy_crit;
+    const int32_t *d_node_rank;
+    const uint16_t *d_node_flags;
+    const uint8_t *d_store_nodes;
+    int32_t rank_begin, rank_end;
 } gki_find_params;
 /* sizeof(gki_find_params) of this build, for bindings to check at load time. */
 int64_t gki_find_params_size(void);

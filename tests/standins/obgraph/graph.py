@@ -16,6 +16,33 @@ class VariantNotFoundException(Exception):
 _CODE = {"a": 0, "c": 1, "g": 2, "t": 3, "n": 0, "m": 0}
 
 
+class _RaggedShape:
+    def __init__(self, lengths):
+        self.lengths = np.asarray(lengths, dtype=np.int64)
+        self.ends = np.cumsum(self.lengths)
+        self.starts = self.ends - self.lengths
+
+
+class _Ragged:
+    """The slice of npstructures.RaggedArray's surface that obgraph's `edges` / `numeric_node_sequences` attributes show:
+    flat data (`ravel()`, `_data`), `shape.starts` / `shape.lengths` / `shape.ends`, row indexing."""
+
+    def __init__(self, rows, dtype):
+        self.shape = _RaggedShape([len(r) for r in rows])
+        self._data = np.concatenate([np.asarray(r, dtype=dtype) for r in rows]) if len(rows) else np.zeros(0, dtype)
+        if self._data.dtype != dtype:
+            self._data = self._data.astype(dtype)
+
+    def ravel(self):
+        return self._data
+
+    def __len__(self):
+        return len(self.shape.lengths)
+
+    def __getitem__(self, row):
+        return self._data[self.shape.starts[row]:self.shape.ends[row]]
+
+
 class Graph:
     def __init__(self, node_sequences, edges, linear_ref_nodes, allele_frequencies=None, chromosome_start_nodes=None):
         self._seq = {int(n): np.array([_CODE[c] for c in s.lower()], dtype=np.uint8)
@@ -36,6 +63,10 @@ class Graph:
                 self._af[n] = f
         self._ref_or_dummy = None
         self.make_linear_ref_node_and_ref_dummy_node_index()
+        # whole-array attributes, as obgraph keeps them beside its accessors (rows of absent ids are empty)
+        n_ids = max(self._seq) + 1
+        self.edges = _Ragged([self._edges.get(n, []) for n in range(n_ids)], np.int32)
+        self.numeric_node_sequences = _Ragged([self._seq.get(n, []) for n in range(n_ids)], np.uint8)
         first = self._linear_list[0] if self._linear_list else min(self._seq)
         self.chromosome_start_nodes = {1: first} if chromosome_start_nodes is None else \
             {i + 1: int(n) for i, n in enumerate(chromosome_start_nodes)}
@@ -86,6 +117,8 @@ class Graph:
         return list(self._edges.get(int(node), []))
 
     def is_linear_ref_node_or_linear_ref_dummy_node(self, node):
+        if np.ndim(node) > 0:                    # (obgraph answers from an index array: vectorised for free)
+            return np.array([bool(self._ref_or_dummy.get(int(n), False)) for n in node])
         return self._ref_or_dummy[int(node)]
 
     def get_node_allele_frequencies(self, nodes):

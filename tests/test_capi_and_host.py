@@ -297,3 +297,77 @@ def test_scalar_getters_host_form_against_the_oracle(tmp_path):
         assert list(index.get_nodes(queries[3])) == list(oracle.index_get(ref, queries[3])[0])
     assert index._device is None                                  # nothing above touched the device
     assert index.get(2 ** 64 + 5) == (None, None, None, None) and index.get(-3) == (None, None, None, None)
+
+
+_GRAPH_COLS = ("node_size", "seq", "edge_start", "edges", "rev_start", "rev_edges", "is_ref", "allele_freq", "exists")
+
+
+def test_from_obgraph_whole_arrays_equal_the_accessor_walk():
+    """GraphArrays.from_obgraph takes whole arrays when the object offers them (ragged edges / sequences, vectorised
+    flags) and otherwise walks the accessor methods node by node: both give the same arrays on random graphs (SNPs,
+    indels with empty nodes, chains), the obgraph stand-in goes the fast way, and arrays that disagree with the accessors
+    are not trusted."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "standins"))
+    from obgraph_like import ObgraphLike
+    from obgraph.graph import Graph as StandinGraph
+    import graphgen
+    from graph_kmer_index_amd import graph as graph_mod
+    rng = np.random.default_rng(77)
+    n_graphs = 0
+    for i in range(220):
+        gen = (graphgen.random_bubble_graph, graphgen.nested_bubble_graph, graphgen.deep_nested_graph)[i % 3]
+        made = gen(rng)
+        seqs, edges, lin = made[0], made[1], made[2]
+        g = GraphArrays.from_dicts(seqs, edges, lin)
+        fast = GraphArrays._from_obgraph_arrays(ObgraphLike(g))
+        assert fast is not None and GraphArrays._first_disagreement(ObgraphLike(g), fast, 50) is None
+        slow = GraphArrays._from_obgraph_accessors(ObgraphLike(g, with_arrays=False))
+        assert GraphArrays._from_obgraph_arrays(ObgraphLike(g, with_arrays=False)) is None
+        for name in _GRAPH_COLS:
+            assert np.array_equal(getattr(fast, name), getattr(slow, name)), (i, name)
+            assert np.array_equal(getattr(fast, name), getattr(g, name)), (i, name)
+        assert (fast.first_node, fast._chromosome_start_nodes) == (slow.first_node, slow._chromosome_start_nodes)
+        if i < 60:                                   # the reference's own entry: obgraph (stand-in) objects
+            sg = StandinGraph.from_dicts(seqs, edges, lin)
+            via_fast = GraphArrays._from_obgraph_arrays(sg)
+            assert via_fast is not None
+            via_slow = GraphArrays._from_obgraph_accessors(sg)
+            for name in _GRAPH_COLS:
+                assert np.array_equal(getattr(via_fast, name), getattr(via_slow, name)), (i, name)
+        n_graphs += 1
+    assert n_graphs >= 200
+    # whole arrays that contradict the accessors: found by the sample, the accessor walk answers
+    g = synthetic_snp_graph(30000, 300, k=31, seed=4)
+    liar = ObgraphLike(g)
+    twisted = g.edges.copy()
+    twisted[::7] = np.roll(twisted, 1)[::7]
+    liar.edges = type(liar.edges)(g.edge_start, twisted)
+    assert GraphArrays._first_disagreement(liar, GraphArrays._from_obgraph_arrays(liar), 2000) is not None
+    got = GraphArrays.from_obgraph(liar)
+    for name in _GRAPH_COLS:
+        assert np.array_equal(getattr(got, name), getattr(g, name)), name
+    # rows not laid out back to back (a ragged view after row selection): gathered
+    rs, flat = graph_mod._ragged_rows(_Shuffled(g.edge_start, g.edges), g.n_nodes)
+    assert np.array_equal(rs, g.edge_start) and np.array_equal(flat, g.edges)
+
+
+class _Shuffled:
+    """A ragged array whose rows lie in reverse order in its flat data."""
+
+    def __init__(self, row_start, flat):
+        lengths = np.diff(row_start)
+        order = np.arange(len(lengths))[::-1]
+        pieces = [flat[row_start[r]:row_start[r + 1]] for r in order]
+        self._data = np.concatenate(pieces) if pieces else flat[:0]
+        starts = np.zeros(len(lengths), dtype=np.int64)
+        starts[order] = np.concatenate([[0], np.cumsum(lengths[order])[:-1]])
+
+        class S:
+            pass
+        self.shape = S()
+        self.shape.starts, self.shape.lengths = starts, lengths
+
+    def ravel(self):
+        return self._data

@@ -8,6 +8,6 @@ for i in $(seq 1 "$rounds"); do
     timeout -k 10 400 python3 bench.py --no-cpu-baseline --reads 2e6 --steps 5 --warmup 2 > /tmp/abf_line.json 2> /tmp/abf_line.err || { echo "$lib FAILED"; tail -3 /tmp/abf_line.err; continue; }
     python3 -c "
 import json; d = json.loads(open('/tmp/abf_line.json').readline()); f = d['full_index']
-print('%-42s step %.2f  full_index %.0f ms (find %.1f, partition %.1f, copies %.1f, builds %.1f)  index_build %.2f  early_stop %.2f ms' % ('$lib', d['ms_per_step'], f['ms'], f['find_shards_ms'], f['partition_ms'], f['exchange_standin_copy_ms'], f['build_slices_ms'], d['index_build']['ms'], d['early_stop_search']['ms']))"
+print('%-42s step %.2f  full_index %.0f ms (find %.1f, partition %.1f, builds %.1f) ok=%s  index_build %.2f  scalar get %.0f/s  early_stop %.2f ms' % ('$lib', d['ms_per_step'], f['ms'], f['find_ms'], f['partition_ms'], f['build_slices_ms'], f['payload_equals_flat_multiset'], d['index_build']['ms'], d['index_build']['scalar_get_calls_per_s'], d['early_stop_search']['ms']))"
   done
 done
