@@ -145,7 +145,11 @@ def launch_ranks(args):
             time.sleep(0.2)
             bad = [p for p in procs if p.poll() not in (None, 0)]
             if bad:                                       # one rank failed: the others would wait for it at a barrier
-                time.sleep(2.0)
+                # rank 0 prints the line (its watchdog fires on the same timer as the other ranks'): give it time to
+                # do so before the survivors are ended
+                t_bad = time.perf_counter()
+                while procs[0].poll() is None and time.perf_counter() - t_bad < 20.0:
+                    time.sleep(0.2)
                 for p in procs:
                     if p.poll() is None:
                         p.kill()
@@ -593,6 +597,11 @@ def sharded_build_record(lib, _lib, plane, finder, out, modulo, same_device_rank
     info = comm.info()
     rec = dict(info)
     rec["ranks"] = world
+    # which GPU every rank really sits on (a LOCAL_RANK % n_devices that maps two ranks to one card shows here), and what
+    # RCCL says about the communicator on every rank
+    from graph_kmer_index_amd.parallel import device_identity
+    rec["device_of_rank"] = [b.decode() for b in plane._allgather_bytes(device_identity().encode())]
+    rec["rccl_ranks_seen_by_rank"] = plane.allgather_int(int(info.get("rccl_ranks") or 0))
     n_int = finder.interior_records()
     nb = out.n - n_int
     bnd = DeviceFlatKmers(nb, out.hashes.view(n_int, nb), out.nodes.view(n_int, nb), out.ref_offsets.view(n_int, nb),
@@ -875,8 +884,13 @@ def main():
         import threading
 
         def give_up():
+            # a hang is a FINDING, not a pass: the line says so at its top level (`incomplete`), the headline numbers above
+            # it stand (they were measured before the exchange started), and the exit code is the launcher's to report:
+            # rank 0 leaves with 0 only so that its line is not discarded with it, every other rank with 3
             if rank == 0:
-                res["sharded_build"] = {"timed_out_after_s": args.sharded_build_budget}
+                res["sharded_build"] = {"timed_out_after_s": args.sharded_build_budget, "failed": "no answer from the exchange "
+                                        "or the build within the budget; stderr has rank 0's '[gki comm]' phase lines"}
+                res["incomplete"] = ["sharded_build"]
                 print(json.dumps(res), flush=True)
             os._exit(0 if rank == 0 else 3)
         dog = threading.Timer(args.sharded_build_budget, give_up)

@@ -11,6 +11,7 @@
 #include "gki_common.h"
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <time.h>
 
 struct gki_comm {
     ncclComm_t comm;
@@ -50,6 +51,20 @@ int load_rccl() {
 #undef SYM
     g_rccl.h = h;
     return GKI_OK;
+}
+
+// The exchanges have never run between more than one real GPU before a user's (or the driver's) first multi-GPU run: rank 0
+// says on stderr what it posted and when it completed, so that a stall names its phase.
+void comm_trace(const gki_comm *c, const char *phase, const char *what, int sends, int recvs, double bytes, double ms) {
+    if (c->rank != 0 || c->world < 2) return;
+    if (ms < 0) fprintf(stderr, "[gki comm] %s: %s (%d sends, %d receives, %.3f GB out of rank 0, world %d)\n", phase, what, sends, recvs, bytes / 1e9, c->world);
+    else fprintf(stderr, "[gki comm] %s: %s after %.1f ms\n", phase, what, ms);
+    fflush(stderr);
+}
+double now_ms() {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return 1e3 * (double)t.tv_sec + 1e-6 * (double)t.tv_nsec;
 }
 
 #define NCCL_TRY(call)                                                                                      \
@@ -122,24 +137,34 @@ int gki_comm_allgather_flat(gki_comm *c, const int64_t *h_counts, const void *d_
         if (h_counts[me] > 0)
             HIP_TRY(hipMemcpyAsync((char *)outp[col] + (size_t)my_off * esz[col], in[col], (size_t)h_counts[me] * esz[col],
                                    hipMemcpyDeviceToDevice, s));
+    const double t0 = now_ms();
     if (W > 1) {
+        int n_send = 0, n_recv = 0;
+        double bytes = 0;
         NCCL_TRY(g_rccl.GroupStart());
         for (int col = 0; col < 4; col++) {
             int64_t o = 0;
             for (int r = 0; r < W; r++) {
                 if (r != me) {
-                    if (h_counts[me] > 0)
+                    if (h_counts[me] > 0) {
                         NCCL_TRY(g_rccl.Send(in[col], (size_t)h_counts[me] * esz[col], ncclUint8, r, c->comm, s));
-                    if (h_counts[r] > 0)
+                        n_send++; bytes += (double)h_counts[me] * esz[col];
+                    }
+                    if (h_counts[r] > 0) {
                         NCCL_TRY(g_rccl.Recv((char *)outp[col] + (size_t)o * esz[col], (size_t)h_counts[r] * esz[col], ncclUint8, r,
                                              c->comm, s));
+                        n_recv++;
+                    }
                 }
                 o += h_counts[r];
             }
         }
+        comm_trace(c, "all-gather", "group posted, closing it", n_send, n_recv, bytes, -1);
         NCCL_TRY(g_rccl.GroupEnd());
+        comm_trace(c, "all-gather", "group closed, waiting for the stream", n_send, n_recv, bytes, -1);
     }
     HIP_TRY(hipStreamSynchronize(s));
+    comm_trace(c, "all-gather", "completed", 0, 0, 0, now_ms() - t0);
     return GKI_OK;
 }
 
@@ -163,23 +188,33 @@ int gki_comm_alltoall_flat(gki_comm *c, const int64_t *h_send_start, const void 
             HIP_TRY(hipMemcpyAsync((char *)outp[col] + (size_t)h_recv_start[me] * esz[col],
                                    (const char *)in[col] + (size_t)h_send_start[me] * esz[col], (size_t)own * esz[col],
                                    hipMemcpyDeviceToDevice, s));
+    const double t0 = now_ms();
     if (W > 1) {
         // one point-to-point pair per peer and column; xGMI is fully connected, so all pairs move at once
+        int n_send = 0, n_recv = 0;
+        double bytes = 0;
         NCCL_TRY(g_rccl.GroupStart());
         for (int col = 0; col < 4; col++)
             for (int r = 0; r < W; r++) {
                 if (r == me) continue;
                 const int64_t ns = h_send_start[r + 1] - h_send_start[r], nr = h_recv_start[r + 1] - h_recv_start[r];
-                if (ns > 0)
+                if (ns > 0) {
                     NCCL_TRY(g_rccl.Send((const char *)in[col] + (size_t)h_send_start[r] * esz[col], (size_t)ns * esz[col], ncclUint8,
                                          r, c->comm, s));
-                if (nr > 0)
+                    n_send++; bytes += (double)ns * esz[col];
+                }
+                if (nr > 0) {
                     NCCL_TRY(g_rccl.Recv((char *)outp[col] + (size_t)h_recv_start[r] * esz[col], (size_t)nr * esz[col], ncclUint8, r,
                                          c->comm, s));
+                    n_recv++;
+                }
             }
+        comm_trace(c, "all-to-all", "group posted, closing it", n_send, n_recv, bytes, -1);
         NCCL_TRY(g_rccl.GroupEnd());
+        comm_trace(c, "all-to-all", "group closed, waiting for the stream", n_send, n_recv, bytes, -1);
     }
     HIP_TRY(hipStreamSynchronize(s));
+    comm_trace(c, "all-to-all", "completed", 0, 0, 0, now_ms() - t0);
     return GKI_OK;
 }
 

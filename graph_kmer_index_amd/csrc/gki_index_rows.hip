@@ -103,22 +103,44 @@ __device__ __forceinline__ int64_t tile_of_block(int64_t n_tiles, int xcd_tiles)
     return (int64_t)(blockIdx.x & 7) * xcd_tiles + (blockIdx.x >> 3);
 }
 
+// A tile's digit histogram into hist[digit * n_tiles + tile] (bin-major: the exclusive scan of that array is every run's
+// first output row).  Blocks take their tiles XCD-major like the partition kernel: a digit's entries of consecutive tiles
+// share 32-byte sectors, and with tiles dealt round-robin over the eight XCDs every sector was written 4 bytes at a time
+// through eight L2s that do not merge each other's partial lines.
+// Few digits (the bucket-range partition: <= 16 parts): counted by ballots, one add per wave and digit -- LDS atomics of
+// 4096 rows on 8 addresses serialise.
+template <int THREADS>
+__device__ __forceinline__ void tile_hist_add(uint32_t *h, uint32_t dig, bool valid, int bits) {
+    if (bits <= 4) {
+        const int lane = threadIdx.x & 63;
+        for (int d = 0; d < (1 << bits); d++) {
+            const uint32_t c = (uint32_t)__popcll(__ballot(valid && dig == (uint32_t)d));
+            if (lane == 0 && c) atomicAdd(&h[d], c);
+        }
+    } else if (valid) atomicAdd(&h[dig], 1u);
+}
+
 template <int THREADS, int RI>
 __global__ __launch_bounds__(THREADS) void k_digit_hist(const uint32_t *__restrict__ keys, int64_t n, int shift, int bits,
-                                                        uint32_t *__restrict__ hist, int64_t n_tiles) {
+                                                        uint32_t *__restrict__ hist, int64_t n_tiles, int xcd_tiles) {
     __shared__ uint32_t h[MAXB];
+    const int64_t tile = tile_of_block(n_tiles, xcd_tiles);
+    if (tile >= n_tiles) return;
     const int bins = 1 << bits;
     for (int d = threadIdx.x; d < bins; d += THREADS) h[d] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * (THREADS * RI);
+    const int64_t base = tile * (THREADS * RI);
     const uint32_t mask = (uint32_t)bins - 1u;
+    uint32_t key[RI];
 #pragma unroll
     for (int r = 0; r < RI; r++) {
         const int64_t i = base + r * THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
+        key[r] = i < n ? keys[i] : 0u;
     }
+#pragma unroll
+    for (int r = 0; r < RI; r++) tile_hist_add<THREADS>(h, (key[r] >> shift) & mask, base + r * THREADS + threadIdx.x < n, bits);
     __syncthreads();
-    for (int d = threadIdx.x; d < bins; d += THREADS) hist[(int64_t)d * n_tiles + blockIdx.x] = h[d];
+    for (int d = threadIdx.x; d < bins; d += THREADS) hist[(int64_t)d * n_tiles + tile] = h[d];
 }
 
 // Exclusive scan of v over the THREADS threads of the block (lds: THREADS / 64 + 1 words)
@@ -677,14 +699,17 @@ int key_bits(uint64_t max_key) {
 // written and 4 read back).  *out_of_range is set when a bucket lies outside the slice.
 template <int THREADS, int RI>
 __global__ __launch_bounds__(THREADS) void k_kmer_digit_hist(const uint64_t *__restrict__ kmers, int64_t n, KeyRule rule, int shift, int bits,
-                                                             uint32_t *__restrict__ hist, int64_t n_tiles, int *__restrict__ out_of_range) {
+                                                             uint32_t *__restrict__ hist, int64_t n_tiles, int xcd_tiles,
+                                                             int *__restrict__ out_of_range) {
     __shared__ uint32_t h[MAXB];
     __shared__ uint32_t s_pb[MAX_PARTS + 1];
+    const int64_t tile = tile_of_block(n_tiles, xcd_tiles);
+    if (tile >= n_tiles) return;
     const int bins = 1 << bits;
     for (int d = threadIdx.x; d < bins; d += THREADS) h[d] = 0;
     stage_parts(rule, s_pb);
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * (THREADS * RI);
+    const int64_t base = tile * (THREADS * RI);
     const uint32_t mask = (uint32_t)bins - 1u;
     uint64_t km[RI];
 #pragma unroll
@@ -695,12 +720,13 @@ __global__ __launch_bounds__(THREADS) void k_kmer_digit_hist(const uint64_t *__r
     bool bad = false;
 #pragma unroll
     for (int r = 0; r < RI; r++) {
-        const int64_t i = base + r * THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&h[(key_of(rule, s_pb, km[r], &bad) >> shift) & mask], 1u);
+        const bool valid = base + r * THREADS + threadIdx.x < n;
+        const uint32_t key = valid ? key_of(rule, s_pb, km[r], &bad) : 0u;
+        tile_hist_add<THREADS>(h, (key >> shift) & mask, valid, bits);
     }
     if (bad) *out_of_range = 1;
     __syncthreads();
-    for (int d = threadIdx.x; d < bins; d += THREADS) hist[(int64_t)d * n_tiles + blockIdx.x] = h[d];
+    for (int d = threadIdx.x; d < bins; d += THREADS) hist[(int64_t)d * n_tiles + tile] = h[d];
 }
 
 // Tile shape of the partition passes.  4096-row tiles (one workgroup of 512 threads per CU, 144 KB of LDS) give every
@@ -796,12 +822,14 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
             const int bits = (top - (shift - L) + (n_pass - p) - 1) / (n_pass - p);       // remaining bits spread evenly (an odd bit
                                                                                            // first or last: no difference measured)
             const int64_t bins_n = ((int64_t)1 << bits) * n_tiles;
+            const int xcd_tiles = (int)ceil_div(n_tiles, 8);
+            const unsigned xgrid = (unsigned)(xcd_tiles * 8);
             if (p == 0)
-                hipLaunchKernelGGL((k_kmer_digit_hist<THREADS, RI>), dim3((unsigned)n_tiles), dim3(THREADS), 0, s, (const uint64_t *)d_kmers,
-                                   n, rule, shift, bits, hist, n_tiles, (int *)(stats + 3));
+                hipLaunchKernelGGL((k_kmer_digit_hist<THREADS, RI>), dim3(xgrid), dim3(THREADS), 0, s, (const uint64_t *)d_kmers,
+                                   n, rule, shift, bits, hist, n_tiles, xcd_tiles, (int *)(stats + 3));
             else
-                hipLaunchKernelGGL((k_digit_hist<THREADS, RI>), dim3((unsigned)n_tiles), dim3(THREADS), 0, s, cur_keys, n, shift, bits,
-                                   hist, n_tiles);
+                hipLaunchKernelGGL((k_digit_hist<THREADS, RI>), dim3(xgrid), dim3(THREADS), 0, s, cur_keys, n, shift, bits,
+                                   hist, n_tiles, xcd_tiles);
             HIP_G(hipGetLastError());
             rc = gki_scan_u32_to_u32(hist, bins_n, offs, tmp, tmp_bytes, s);
             if (rc != GKI_OK) goto done;
@@ -811,10 +839,9 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
             a.n = n; a.n_tiles = n_tiles; a.shift = shift; a.bits = bits; a.offs = offs; a.carry_index = d_out_permutation != nullptr;
             a.rows_out = rows[p & 1]; a.keys_out = keys[p & 1];
             a.o_kmers = nullptr; a.o_nodes = nullptr; a.o_refs = nullptr; a.o_af = nullptr; a.dbase = nullptr;
-            a.xcd_tiles = (int)ceil_div(n_tiles, 8);
-            const unsigned grid = (unsigned)(a.xcd_tiles * 8);
-            if (p == 0) hipLaunchKernelGGL((k_partition_rows<THREADS, RI, true>), dim3(grid), dim3(THREADS), 0, s, a);
-            else hipLaunchKernelGGL((k_partition_rows<THREADS, RI, false>), dim3(grid), dim3(THREADS), 0, s, a);
+            a.xcd_tiles = xcd_tiles;
+            if (p == 0) hipLaunchKernelGGL((k_partition_rows<THREADS, RI, true>), dim3(xgrid), dim3(THREADS), 0, s, a);
+            else hipLaunchKernelGGL((k_partition_rows<THREADS, RI, false>), dim3(xgrid), dim3(THREADS), 0, s, a);
             HIP_G(hipGetLastError());
             cur_rows = a.rows_out; cur_keys = a.keys_out;
             shift += bits;
@@ -906,7 +933,7 @@ __global__ void k_part_bases(ChunkOffs co, int n_parts, int bins, int64_t *__res
 int gki_partition_columns_by_part(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
                                   uint64_t modulo, int n_parts, int64_t max_rows_per_pass, void *d_out_kmers, void *d_out_nodes,
                                   void *d_out_ref_offsets, void *d_out_af32, int64_t *h_part_start) {
-    constexpr int THREADS = GKI_PR_THREADS, RI = GKI_PT_RI, TILE = THREADS * RI;
+    constexpr int THREADS = GKI_PR_THREADS, RI = 8, TILE = THREADS * RI;
     hipStream_t s = 0;
     int bits = 0;
     while ((1 << bits) < n_parts) bits++;
@@ -944,8 +971,9 @@ int gki_partition_columns_by_part(const void *d_kmers, const void *d_nodes, cons
             co.n_tiles[c] = n_tiles; co.hist_n[c] = hist_n;
             HIP_G(gki_dev_malloc((void **)&offs[c], (size_t)(hist_n + 1) * 4));
             co.offs[c] = offs[c];
-            hipLaunchKernelGGL((k_kmer_digit_hist<THREADS, RI>), dim3((unsigned)n_tiles), dim3(THREADS), 0, s, (const uint64_t *)d_kmers + c0,
-                               nc, rule, 0, bits, hist, n_tiles, bad);
+            const int xcd_tiles = (int)ceil_div(n_tiles, 8);
+            hipLaunchKernelGGL((k_kmer_digit_hist<THREADS, RI>), dim3((unsigned)(xcd_tiles * 8)), dim3(THREADS), 0, s, (const uint64_t *)d_kmers + c0,
+                               nc, rule, 0, bits, hist, n_tiles, xcd_tiles, bad);
             HIP_G(hipGetLastError());
             rc = gki_scan_u32_to_u32(hist, hist_n, offs[c], tmp, tmp_bytes, s);
             if (rc != GKI_OK) goto done;
