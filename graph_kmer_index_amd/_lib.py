@@ -102,7 +102,10 @@ SYMBOLS = {
     "gki_index_build": (_I32, [_P, _P, _P, _P, _I64, _U64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gki_partition_by_bucket_range": (_I32, [_P, _P, _P, _P, _I64, _U64, _I32, _P, _P, _P, _P, C.POINTER(_I64)]),
     "gki_partition_by_bucket_range_chunked": (_I32, [_P, _P, _P, _P, _I64, _U64, _I32, _I64, _P, _P, _P, _P, C.POINTER(_I64)]),
+    "gki_partition_by_bucket_range_grouped": (_I32, [_P, _P, _P, _P, _I64, _U64, _I32, _I32, _I64, _P, _P, _P, _P, C.POINTER(_I64)]),
     "gki_index_build_range": (_I32, [_P, _P, _P, _P, _I64, _U64, _U64, _U64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gki_index_build_range_grouped": (_I32, [_P, _P, _P, _P, _I64, _U64, _U64, _U64, _I32, _I32, C.POINTER(_I64),
+                                             _P, _P, _P, _P, _P, _P, _P, _P]),
     "gki_index_build_pairs": (_I32, [_P, _P, _P, _P, _I64, _U64, _U64, _U64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gki_reverse_index_build": (_I32, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
     "gki_index_lookup_count": (_I32, [C.POINTER(IndexView), _P, _I64, _I64, _P, C.POINTER(_I64)]),

@@ -35,10 +35,12 @@ class DeviceIndex:
 
     @classmethod
     def build(cls, dflat, modulo=452930477, skip_frequencies=False, want_permutation=False, bucket_begin=0, n_buckets=None,
-              pairs_form=False):
+              pairs_form=False, group_start=None):
         """gki_index_build(_range) on device-resident FlatKmers columns.  With a bucket range, `dflat` must hold only
         records of that range (one slice of `partition_by_bucket_range`).  pairs_form=True runs the pair-sorting form of
-        the build (gki_index_build_pairs) instead of the row-carrying one; the results are identical."""
+        the build (gki_index_build_pairs) instead of the row-carrying one; the results are identical.
+        group_start (2^g + 1 row numbers): the records arrive grouped by the top g bits of their key, as
+        `partition_by_bucket_range(..., group_bits=g)` leaves the records of a part (gki_index_build_range_grouped)."""
         _lib.require_device()
         n = dflat.n
         na = max(n, 1)
@@ -48,12 +50,18 @@ class DeviceIndex:
                   _lib.DeviceArray(na, np.float32), _lib.DeviceArray(na, np.uint16), bucket_begin, nb)
         perm = _lib.DeviceArray(na, np.uint32) if want_permutation else None
         out.permutation = perm
-        fn = _lib.load().gki_index_build_pairs if pairs_form else _lib.load().gki_index_build_range
-        _lib.check(fn(
-            dflat.hashes.ptr, dflat.nodes.ptr, dflat.ref_offsets.ptr, dflat.allele_frequencies.ptr, n, int(modulo),
-            int(bucket_begin), nb, int(bool(skip_frequencies)), out.hashes_to_index.ptr, out.n_kmers.ptr, out.kmers.ptr,
-            out.nodes.ptr, out.ref_offsets.ptr, out.allele_frequencies.ptr, out.frequencies.ptr,
-            None if perm is None else perm.ptr))
+        head = (dflat.hashes.ptr, dflat.nodes.ptr, dflat.ref_offsets.ptr, dflat.allele_frequencies.ptr, n, int(modulo),
+                int(bucket_begin), nb, int(bool(skip_frequencies)))
+        tail = (out.hashes_to_index.ptr, out.n_kmers.ptr, out.kmers.ptr, out.nodes.ptr, out.ref_offsets.ptr,
+                out.allele_frequencies.ptr, out.frequencies.ptr, None if perm is None else perm.ptr)
+        if group_start is not None and not pairs_form:
+            group_bits = (len(group_start) - 1).bit_length() - 1
+            assert len(group_start) == (1 << group_bits) + 1
+            bounds = (C.c_int64 * len(group_start))(*[int(x) for x in group_start])
+            _lib.check(_lib.load().gki_index_build_range_grouped(*head, group_bits, bounds, *tail))
+        else:
+            fn = _lib.load().gki_index_build_pairs if pairs_form else _lib.load().gki_index_build_range
+            _lib.check(fn(*head, *tail))
         return out
 
     def lookup_positions(self, queries, max_hits=10, use_probe_table=True):
@@ -191,20 +199,24 @@ def bucket_range(modulo, n_parts, part):
     return modulo * part // n_parts, modulo * (part + 1) // n_parts
 
 
-def partition_by_bucket_range(dflat, modulo, n_parts, out=None, max_rows_per_pass=0):
+def partition_by_bucket_range(dflat, modulo, n_parts, out=None, max_rows_per_pass=0, group_bits=0):
     """Stable partition of device FlatKmers columns by owning part.  Returns (DeviceFlatKmers, part_start[n_parts+1]).
     `out`: columns to write into (at least dflat.n records, not overlapping dflat) instead of a fresh allocation.
-    Any number of records (2^31 and more go through several passes, `max_rows_per_pass` at a time; 0: the default)."""
+    Any number of records (2^31 and more go through several passes, `max_rows_per_pass` at a time; 0: the default).
+    group_bits = g > 0: the records of a part additionally leave grouped by the top g bits of their bucket's offset in
+    the part (what `DeviceIndex.build(group_start=...)` takes one sort pass less for); the returned table then has
+    (n_parts << g) + 1 entries, entry p << g | group = first row of that group of part p."""
     _lib.require_device()
     if out is None:
         out = DeviceFlatKmers.allocate(dflat.n)
     else:
         assert out.hashes.n >= dflat.n
         out.n = dflat.n
-    start = (C.c_int64 * (n_parts + 1))()
-    _lib.check(_lib.load().gki_partition_by_bucket_range_chunked(
+    start = (C.c_int64 * ((n_parts << group_bits) + 1))()
+    _lib.check(_lib.load().gki_partition_by_bucket_range_grouped(
         dflat.hashes.ptr, dflat.nodes.ptr, dflat.ref_offsets.ptr, dflat.allele_frequencies.ptr, dflat.n, int(modulo),
-        int(n_parts), int(max_rows_per_pass), out.hashes.ptr, out.nodes.ptr, out.ref_offsets.ptr, out.allele_frequencies.ptr, start))
+        int(n_parts), int(group_bits), int(max_rows_per_pass), out.hashes.ptr, out.nodes.ptr, out.ref_offsets.ptr,
+        out.allele_frequencies.ptr, start))
     return out, [int(x) for x in start]
 
 
@@ -222,17 +234,29 @@ class PartitionedDeviceIndex:
         return sum(p.n for p in self.parts)
 
     @classmethod
-    def build(cls, dflat, modulo=452930477, n_parts=8, skip_frequencies=False):
-        part, start = partition_by_bucket_range(dflat, modulo, n_parts)
+    def build(cls, dflat, modulo=452930477, n_parts=8, skip_frequencies=False, grouped=True, out=None):
+        """Partition by bucket range, build every slice.  grouped: the partition also groups every slice's records by
+        the top bits of their key (as many as keep n_parts << bits within the partition pass's 1024 digits) and the slice
+        builds start from there -- one sort pass less per slice (DESIGN.md 4.3 "Grouped build").  `out`: columns for the
+        partitioned records (see `partition_by_bucket_range`)."""
+        g = max(0, 10 - max(0, (n_parts - 1).bit_length())) if grouped else 0
+        part, start = partition_by_bucket_range(dflat, modulo, n_parts, out=out, group_bits=g)
         parts = []
         for p in range(n_parts):
-            lo, hi = bucket_range(modulo, n_parts, p)
-            a, b = start[p], start[p + 1]
-            sl = DeviceFlatKmers(b - a, part.hashes.view(a, b - a), part.nodes.view(a, b - a),
-                                 part.ref_offsets.view(a, b - a), part.allele_frequencies.view(a, b - a))
-            parts.append(DeviceIndex.build(sl, modulo, skip_frequencies, bucket_begin=lo, n_buckets=hi - lo))
-        part.free()
+            parts.append(cls.build_slice(part, start, modulo, n_parts, p, g, skip_frequencies))
+        if out is None:
+            part.free()
         return cls(modulo, parts)
+
+    @staticmethod
+    def build_slice(part, start, modulo, n_parts, p, group_bits, skip_frequencies=False):
+        """The DeviceIndex of slice p from the partitioned records (`part`, `start` of partition_by_bucket_range)."""
+        lo, hi = bucket_range(modulo, n_parts, p)
+        a, b = start[p << group_bits], start[(p + 1) << group_bits]
+        sl = DeviceFlatKmers(b - a, part.hashes.view(a, b - a), part.nodes.view(a, b - a),
+                             part.ref_offsets.view(a, b - a), part.allele_frequencies.view(a, b - a))
+        groups = [x - a for x in start[p << group_bits:((p + 1) << group_bits) + 1]] if group_bits else None
+        return DeviceIndex.build(sl, modulo, skip_frequencies, bucket_begin=lo, n_buckets=hi - lo, group_start=groups)
 
     def count_nodes(self, queries, n_nodes, max_hits=10, counts=None):
         own = not isinstance(queries, _lib.DeviceArray)

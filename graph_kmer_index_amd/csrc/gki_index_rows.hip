@@ -23,6 +23,7 @@
 // the result equals the first form's (and the oracle's stable build) element by element.
 #include "gki_common.h"
 #include <math.h>
+#include <vector>
 
 int gki_frequencies_for_rows(const int64_t *d_row_begin, const int64_t *d_row_end, int n_ranges, uint64_t modulo,
                              uint64_t bucket_begin, const void *d_hashes_to_index, const void *d_n_kmers,
@@ -49,6 +50,10 @@ constexpr int MAXB = 1 << MAXB_BITS;          // digits of one partition pass
 #define GKI_GROUP_THREADS 512
 #endif
 constexpr int GROUP_CAP = GKI_GROUP_CAP;          // rows a group may hold to be finished in LDS
+// ... and in the grouped build (records arriving grouped by the top bits of their key, gki_index_build_range_grouped): one
+// workgroup per CU finishes 4096 rows, two more key bits than the 1024-row finish resolves, so that ONE partition pass is
+// left between the grouping and the finish (DESIGN.md 4.3 "Grouped build")
+constexpr int GROUP_CAP_BIG = 4096;
 constexpr int GROUP_LMAX = GKI_GROUP_LMAX;        // low key bits resolved in LDS
 constexpr int GROUP_THREADS = GKI_GROUP_THREADS;
 constexpr int SMALL_BUCKET = 24;              // as in gki_index.hip: buckets up to this size count frequencies per lane
@@ -59,13 +64,19 @@ struct KeyRule {
     GkiMod mod;
     uint64_t bucket_begin, n_buckets;       // build: key = kmer % modulo - bucket_begin, must be < n_buckets
     int n_parts;                            // > 0: key = owning part; part_begin[n_parts + 1] on the device
-    const uint32_t *part_begin;
+    int sub_bits;                           // > 0 (with parts): key = part << sub_bits | the top sub_bits bits of the bucket's
+    const uint32_t *part_begin;             //   offset in its part, i.e. (bucket - part_begin[part]) >> sub_shift[part]
+    const uint32_t *sub_shift;              //   [n_parts] on the device
 };
 constexpr int MAX_PARTS = 256;
+constexpr int PB_WORDS = 2 * MAX_PARTS + 1; // LDS copy: part_begin[0 .. n_parts], then sub_shift[0 .. n_parts)
 
 // the part table into LDS (PART rule only); callers synchronise before the first key_of
 __device__ __forceinline__ void stage_parts(const KeyRule &k, uint32_t *s_pb) {
-    if (k.n_parts > 0) for (int p = threadIdx.x; p <= k.n_parts; p += blockDim.x) s_pb[p] = k.part_begin[p];
+    if (k.n_parts > 0) {
+        for (int p = threadIdx.x; p <= k.n_parts; p += blockDim.x) s_pb[p] = k.part_begin[p];
+        if (k.sub_bits > 0) for (int p = threadIdx.x; p < k.n_parts; p += blockDim.x) s_pb[MAX_PARTS + 1 + p] = k.sub_shift[p];
+    }
 }
 // *bad: the bucket lies outside the slice (the build refuses such input); the key is then 0, never out of range
 __device__ __forceinline__ uint32_t key_of(const KeyRule &k, const uint32_t *s_pb, uint64_t kmer, bool *bad) {
@@ -74,6 +85,7 @@ __device__ __forceinline__ uint32_t key_of(const KeyRule &k, const uint32_t *s_p
         int p = (int)__umul64hi(b * (uint64_t)k.n_parts, k.mod.inv);    // floor(b * n_parts / modulo), or one or two short
         while (p + 1 < k.n_parts && s_pb[p + 1] <= (uint32_t)b) p++;
         while (p > 0 && s_pb[p] > (uint32_t)b) p--;
+        if (k.sub_bits > 0) return ((uint32_t)p << k.sub_bits) | (((uint32_t)b - s_pb[p]) >> s_pb[MAX_PARTS + 1 + p]);
         return (uint32_t)p;
     }
     const uint64_t rel = b - k.bucket_begin;
@@ -81,7 +93,14 @@ __device__ __forceinline__ uint32_t key_of(const KeyRule &k, const uint32_t *s_p
     return (uint32_t)rel;
 }
 
+// Tiles of a SEGMENTED pass (the grouped build: the records arrive grouped by the top bits of their key and every group is
+// sorted on its own, so no tile may straddle two groups): where the tile's rows are and where its histogram column is.
+// The histogram of such a pass is laid out group by group, inside a group digit-major like the plain one, so that ONE
+// exclusive scan over all of it still yields every run's first output row.
+struct TileDesc { int64_t row0, tiles_before; int32_t n, stride, t, pad; };   // histogram column: (tiles_before * bins + t) + digit * stride
+
 struct PartArgs {
+    const TileDesc *tiles;         // NULL: tile t is rows [t * TILE, +TILE), its histogram column offs[d * n_tiles + t]
     const uint32_t *keys_in;                                                                          // !SRC_COLS
     const uint64_t *c_kmers; const uint32_t *c_nodes; const uint64_t *c_refs; const uint32_t *c_af;   // SRC_COLS: the key follows
     KeyRule rule;                                                                                     //   from the k-mer by `rule`
@@ -122,25 +141,28 @@ __device__ __forceinline__ void tile_hist_add(uint32_t *h, uint32_t dig, bool va
 
 template <int THREADS, int RI>
 __global__ __launch_bounds__(THREADS) void k_digit_hist(const uint32_t *__restrict__ keys, int64_t n, int shift, int bits,
-                                                        uint32_t *__restrict__ hist, int64_t n_tiles, int xcd_tiles) {
+                                                        uint32_t *__restrict__ hist, int64_t n_tiles, int xcd_tiles,
+                                                        const TileDesc *__restrict__ tiles) {
     __shared__ uint32_t h[MAXB];
     const int64_t tile = tile_of_block(n_tiles, xcd_tiles);
     if (tile >= n_tiles) return;
     const int bins = 1 << bits;
     for (int d = threadIdx.x; d < bins; d += THREADS) h[d] = 0;
     __syncthreads();
-    const int64_t base = tile * (THREADS * RI);
+    int64_t base = tile * (THREADS * RI), obase = tile, ostride = n_tiles;
+    int64_t n_here = n - base < THREADS * RI ? n - base : THREADS * RI;
+    if (tiles) { const TileDesc td = tiles[tile]; base = td.row0; n_here = td.n; obase = td.tiles_before * bins + td.t; ostride = td.stride; }
     const uint32_t mask = (uint32_t)bins - 1u;
     uint32_t key[RI];
 #pragma unroll
     for (int r = 0; r < RI; r++) {
-        const int64_t i = base + r * THREADS + threadIdx.x;
-        key[r] = i < n ? keys[i] : 0u;
+        const int e = r * THREADS + threadIdx.x;
+        key[r] = e < n_here ? keys[base + e] : 0u;
     }
 #pragma unroll
-    for (int r = 0; r < RI; r++) tile_hist_add<THREADS>(h, (key[r] >> shift) & mask, base + r * THREADS + threadIdx.x < n, bits);
+    for (int r = 0; r < RI; r++) tile_hist_add<THREADS>(h, (key[r] >> shift) & mask, r * THREADS + threadIdx.x < n_here, bits);
     __syncthreads();
-    for (int d = threadIdx.x; d < bins; d += THREADS) hist[(int64_t)d * n_tiles + tile] = h[d];
+    for (int d = threadIdx.x; d < bins; d += THREADS) hist[obase + (int64_t)d * ostride] = h[d];
 }
 
 // Exclusive scan of v over the THREADS threads of the block (lds: THREADS / 64 + 1 words)
@@ -196,15 +218,16 @@ __global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
     __shared__ uint32_t s_dstart[MAXB];
     __shared__ uint32_t s_toff[MAXB];
     __shared__ uint32_t s_scan[W + 1];
-    __shared__ uint32_t s_pb[SRC_COLS ? MAX_PARTS + 1 : 1];
-    __shared__ int64_t s_dbase[DST_COLS ? MAX_PARTS : 1];
+    __shared__ uint32_t s_pb[SRC_COLS ? PB_WORDS : 1];
+    __shared__ int64_t s_dbase[DST_COLS ? (THREADS >= 512 ? MAXB : MAX_PARTS) : 1];        // (1024 digits only on the large tile)
     const int64_t tile = tile_of_block(a.n_tiles, a.xcd_tiles);
     if (tile >= a.n_tiles) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bins = 1 << a.bits;
     const uint32_t mask = (uint32_t)bins - 1u;
-    const int64_t tile_base = tile * TILE;
-    const int n_here = (int)((a.n - tile_base) < TILE ? (a.n - tile_base) : TILE);
+    int64_t tile_base = tile * TILE, obase = tile, ostride = a.n_tiles;
+    int n_here = (int)((a.n - tile_base) < TILE ? (a.n - tile_base) : TILE);
+    if (a.tiles) { const TileDesc td = a.tiles[tile]; tile_base = td.row0; n_here = td.n; obase = td.tiles_before * bins + td.t; ostride = td.stride; }
 
     // (1) everything this thread will need from global memory, issued up front
     uint32_t key[RI], dig[RI];
@@ -221,7 +244,7 @@ __global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
                                 ((uint64_t)(a.carry_index ? (uint32_t)(tile_base + e) : a.c_af[tile_base + e]) << 32)) : 0ull;
         }
         stage_parts(a.rule, s_pb);
-        if (DST_COLS) for (int d = threadIdx.x; d < bins && d < MAX_PARTS; d += THREADS) s_dbase[d] = a.dbase ? a.dbase[d] : 0;
+        if (DST_COLS) for (int d = threadIdx.x; d < bins; d += THREADS) s_dbase[d] = a.dbase ? a.dbase[d] : 0;
     } else {
 #pragma unroll
         for (int r = 0; r < RI; r++) {
@@ -279,7 +302,7 @@ __global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
             if (d < bins) {
                 s_dstart[d] = ex;
                 // DST_COLS: relative to the digit's first run (the caller's dbase[d] is where that one goes)
-                s_toff[d] = a.offs[(int64_t)d * a.n_tiles + tile] - (DST_COLS ? a.offs[(int64_t)d * a.n_tiles] : 0u) - ex;
+                s_toff[d] = a.offs[obase + (int64_t)d * ostride] - (DST_COLS ? a.offs[(int64_t)d * a.n_tiles] : 0u) - ex;
                 ex += tot[c];
             }
         }
@@ -427,7 +450,7 @@ struct FinishArgs {
 //    (wave, round, lane) order, match-any by ballots inside the wave, per-wave bucket counts, exclusive offsets over the
 //    waves -- whose cost does not grow with the bucket.  With the loop, a wave waited for its longest bucket (15-20 rows)
 //    three times over (rank, same k-mer, earlier duplicate): 12.2 ms per 3.95e8 rows against 4.3 ms per 3.1e8 sparse ones.
-template <bool WRANK>
+template <bool WRANK, int GROUP_CAP = GKI_GROUP_CAP>
 __global__ __launch_bounds__(GROUP_THREADS) void k_group_finish(FinishArgs a) {
     constexpr int NB = 1 << GROUP_LMAX, RI = GROUP_CAP / GROUP_THREADS, W = GROUP_THREADS / 64, SLICE = GROUP_CAP / W;
     constexpr int C = NB / GROUP_THREADS > 0 ? NB / GROUP_THREADS : 1;      // buckets per thread: b = i * THREADS + thread
@@ -700,33 +723,35 @@ int key_bits(uint64_t max_key) {
 template <int THREADS, int RI>
 __global__ __launch_bounds__(THREADS) void k_kmer_digit_hist(const uint64_t *__restrict__ kmers, int64_t n, KeyRule rule, int shift, int bits,
                                                              uint32_t *__restrict__ hist, int64_t n_tiles, int xcd_tiles,
-                                                             int *__restrict__ out_of_range) {
+                                                             const TileDesc *__restrict__ tiles, int *__restrict__ out_of_range) {
     __shared__ uint32_t h[MAXB];
-    __shared__ uint32_t s_pb[MAX_PARTS + 1];
+    __shared__ uint32_t s_pb[PB_WORDS];
     const int64_t tile = tile_of_block(n_tiles, xcd_tiles);
     if (tile >= n_tiles) return;
     const int bins = 1 << bits;
     for (int d = threadIdx.x; d < bins; d += THREADS) h[d] = 0;
     stage_parts(rule, s_pb);
     __syncthreads();
-    const int64_t base = tile * (THREADS * RI);
+    int64_t base = tile * (THREADS * RI), obase = tile, ostride = n_tiles;
+    int64_t n_here = n - base < THREADS * RI ? n - base : THREADS * RI;
+    if (tiles) { const TileDesc td = tiles[tile]; base = td.row0; n_here = td.n; obase = td.tiles_before * bins + td.t; ostride = td.stride; }
     const uint32_t mask = (uint32_t)bins - 1u;
     uint64_t km[RI];
 #pragma unroll
     for (int r = 0; r < RI; r++) {
-        const int64_t i = base + r * THREADS + threadIdx.x;
-        km[r] = i < n ? kmers[i] : 0ull;
+        const int e = r * THREADS + threadIdx.x;
+        km[r] = e < n_here ? kmers[base + e] : 0ull;
     }
     bool bad = false;
 #pragma unroll
     for (int r = 0; r < RI; r++) {
-        const bool valid = base + r * THREADS + threadIdx.x < n;
+        const bool valid = r * THREADS + threadIdx.x < n_here;
         const uint32_t key = valid ? key_of(rule, s_pb, km[r], &bad) : 0u;
         tile_hist_add<THREADS>(h, (key >> shift) & mask, valid, bits);
     }
     if (bad) *out_of_range = 1;
     __syncthreads();
-    for (int d = threadIdx.x; d < bins; d += THREADS) hist[(int64_t)d * n_tiles + tile] = h[d];
+    for (int d = threadIdx.x; d < bins; d += THREADS) hist[obase + (int64_t)d * ostride] = h[d];
 }
 
 // Tile shape of the partition passes.  4096-row tiles (one workgroup of 512 threads per CU, 144 KB of LDS) give every
@@ -762,28 +787,59 @@ __global__ __launch_bounds__(THREADS) void k_kmer_digit_hist(const uint64_t *__r
 
 // The row-carrying build.  Returns GKI_OK with *done = 1 when it built the index, *done = 0 when the input is outside
 // its domain (a group too large to stream with one workgroup) and the caller should use the pair-sorting form.
+//
+// Grouped build (group_bits > 0, h_group_start[2^group_bits + 1]): the records arrive grouped by the top group_bits bits of
+// their key -- group g = key >> (key bits - group_bits) holds rows [h_group_start[g], h_group_start[g + 1]), as
+// gki_partition_by_bucket_range_grouped leaves them.  Those bits are sorted already; the passes sort the bits between
+// them and the finish, every group on its own (segmented tiles), and the finish takes 4096-row groups: for the slices
+// of a whole-genome index (26 key bits, 7 records per bucket) that is 7 bits grouped + ONE pass of 10 + 9 in LDS, where
+// the ungrouped build needs two passes of 10 + 9 and 7 in LDS.
 int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
                          uint64_t modulo, uint64_t bucket_begin, uint64_t n_buckets, int skip_frequencies,
+                         int group_bits, const int64_t *h_group_start,
                          void *d_hashes_to_index, void *d_n_kmers, void *d_out_kmers, void *d_out_nodes,
                          void *d_out_ref_offsets, void *d_out_af32, void *d_out_frequencies, void *d_out_permutation, int *done) {
     constexpr int THREADS = GKI_PT_THREADS, RI = GKI_PT_RI, TILE = THREADS * RI;
     *done = 0;
     hipStream_t s = 0;
     const int kb = key_bits(n_buckets - 1);
+    const bool grouped = group_bits > 0;
+    const int group_shift = grouped ? (kb > group_bits ? kb - group_bits : 0) : kb;     // key bits below the grouping
+    const int cap = grouped ? GROUP_CAP_BIG : GROUP_CAP;
     // L: low key bits resolved inside LDS -- the largest for which an average group and GKI_GROUP_SIGMAS deviations fit
     const double density = (double)n / (double)n_buckets;
     int L = kb < GROUP_LMAX ? kb : GROUP_LMAX;
     while (L > 0) {
         const double rows = density * (double)(1ull << L);
-        if (rows + GKI_GROUP_SIGMAS * sqrt(rows) <= (double)GROUP_CAP) break;
+        if (rows + GKI_GROUP_SIGMAS * sqrt(rows) <= (double)cap) break;
         L--;
     }
     const bool wrank = GKI_FINISH_WRANK < 0 ? density >= GKI_FINISH_WRANK_DENSITY : GKI_FINISH_WRANK != 0;
-    const int top = kb - L;                                   // bits the partition passes sort on
+    const int top = group_shift > L ? group_shift - L : 0;    // bits the partition passes sort on
     const int n_pass = top > 0 ? (top + MAXB_BITS - 1) / MAXB_BITS : 1;   // top == 0: one pass of one digit, which only packs the rows
     if (n_pass > 3) return GKI_OK;
     const int64_t n_groups = (int64_t)(((n_buckets - 1) >> L) + 1);
-    const int64_t n_tiles = ceil_div(n, TILE);
+    // tiles: plain, or cut at the group bounds
+    std::vector<TileDesc> h_tiles;
+    int64_t n_tiles = ceil_div(n, TILE);
+    if (grouped) {
+        const int64_t n_seg = (int64_t)1 << group_bits;
+        if (h_group_start[0] != 0 || h_group_start[n_seg] != n) return gki_set_error(GKI_ERR_BAD_ARG, "group_start must run from 0 to n");
+        int64_t t_before = 0;
+        for (int64_t g = 0; g < n_seg; g++) {
+            const int64_t a0 = h_group_start[g], a1 = h_group_start[g + 1];
+            if (a1 < a0) return gki_set_error(GKI_ERR_BAD_ARG, "group_start must not decrease");
+            const int64_t nt = ceil_div(a1 - a0, TILE);
+            for (int64_t t = 0; t < nt; t++) {
+                TileDesc td;
+                td.row0 = a0 + t * TILE; td.n = (int32_t)((a1 - td.row0) < TILE ? (a1 - td.row0) : TILE);
+                td.tiles_before = t_before; td.t = (int32_t)t; td.stride = (int32_t)nt; td.pad = 0;
+                h_tiles.push_back(td);
+            }
+            t_before += nt;
+        }
+        n_tiles = (int64_t)h_tiles.size();
+    }
     const int64_t hist_n = (int64_t)MAXB * n_tiles;
     const int64_t tmp_bytes = gki_scan_tmp_bytes(hist_n);
     uint64_t *rows[2] = {nullptr, nullptr};
@@ -794,13 +850,19 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
     void *tmp = nullptr;
     const uint32_t large_cap = 1u << 16;
     const uint32_t big_cap = (uint32_t)(n / SMALL_BUCKET + 1);
+    TileDesc *d_tiles = nullptr;
     KeyRule rule;
-    rule.mod = gki_mod_of(modulo); rule.bucket_begin = bucket_begin; rule.n_buckets = n_buckets; rule.n_parts = 0; rule.part_begin = nullptr;
+    rule.mod = gki_mod_of(modulo); rule.bucket_begin = bucket_begin; rule.n_buckets = n_buckets; rule.n_parts = 0; rule.sub_bits = 0;
+    rule.part_begin = nullptr; rule.sub_shift = nullptr;
     int rc = GKI_OK;
 #define HIP_G(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = gki_set_error(GKI_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); goto done; } } while (0)
     {
         HIP_G(gki_dev_malloc((void **)&stats, 64));
         HIP_G(hipMemsetAsync(stats, 0, 64, s));
+        if (grouped) {
+            HIP_G(gki_dev_malloc((void **)&d_tiles, h_tiles.size() * sizeof(TileDesc) + 32));
+            HIP_G(hipMemcpyAsync(d_tiles, h_tiles.data(), h_tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, s));
+        }
         for (int i = 0; i < (n_pass > 1 ? 2 : 1); i++) {
             HIP_G(gki_dev_malloc((void **)&rows[i], (size_t)n * 24));
             HIP_G(gki_dev_malloc((void **)&keys[i], (size_t)n * 4));
@@ -826,14 +888,15 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
             const unsigned xgrid = (unsigned)(xcd_tiles * 8);
             if (p == 0)
                 hipLaunchKernelGGL((k_kmer_digit_hist<THREADS, RI>), dim3(xgrid), dim3(THREADS), 0, s, (const uint64_t *)d_kmers,
-                                   n, rule, shift, bits, hist, n_tiles, xcd_tiles, (int *)(stats + 3));
+                                   n, rule, shift, bits, hist, n_tiles, xcd_tiles, d_tiles, (int *)(stats + 3));
             else
                 hipLaunchKernelGGL((k_digit_hist<THREADS, RI>), dim3(xgrid), dim3(THREADS), 0, s, cur_keys, n, shift, bits,
-                                   hist, n_tiles, xcd_tiles);
+                                   hist, n_tiles, xcd_tiles, d_tiles);
             HIP_G(hipGetLastError());
             rc = gki_scan_u32_to_u32(hist, bins_n, offs, tmp, tmp_bytes, s);
             if (rc != GKI_OK) goto done;
             PartArgs a;
+            a.tiles = d_tiles;
             a.keys_in = cur_keys; a.c_kmers = (const uint64_t *)d_kmers; a.c_nodes = (const uint32_t *)d_nodes;
             a.c_refs = (const uint64_t *)d_ref_offsets; a.c_af = (const uint32_t *)d_af32; a.rule = rule; a.rows_in = cur_rows;
             a.n = n; a.n_tiles = n_tiles; a.shift = shift; a.bits = bits; a.offs = offs; a.carry_index = d_out_permutation != nullptr;
@@ -849,7 +912,7 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
         hipLaunchKernelGGL(k_group_bounds, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s, cur_keys, n, L, gbegin, gend);
         HIP_G(hipGetLastError());
         hipLaunchKernelGGL(k_group_scan, dim3(stream_grid(n_groups, 256)), dim3(256), 0, s, gbegin, gend, n_groups,
-                           (uint32_t)GROUP_CAP, stats, large, large_cap);
+                           (uint32_t)cap, stats, large, large_cap);
         HIP_G(hipGetLastError());
         unsigned int h_stats[4] = {0, 0, 0, 0};
         HIP_G(hipMemcpyAsync(h_stats, stats, 16, hipMemcpyDeviceToHost, s));
@@ -865,8 +928,10 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
         f.o_perm = (uint32_t *)d_out_permutation; f.af_in = (const uint32_t *)d_af32;
         f.big_buckets = big; f.n_big = stats + 2; f.big_cap = big_cap;
         f.xcd_groups = (int)ceil_div(n_groups, 8);
-        if (wrank) hipLaunchKernelGGL(k_group_finish<true>, dim3((unsigned)(f.xcd_groups * 8)), dim3(GROUP_THREADS), 0, s, f);
-        else hipLaunchKernelGGL(k_group_finish<false>, dim3((unsigned)(f.xcd_groups * 8)), dim3(GROUP_THREADS), 0, s, f);
+        if (grouped && wrank) hipLaunchKernelGGL((k_group_finish<true, GROUP_CAP_BIG>), dim3((unsigned)(f.xcd_groups * 8)), dim3(GROUP_THREADS), 0, s, f);
+        else if (grouped) hipLaunchKernelGGL((k_group_finish<false, GROUP_CAP_BIG>), dim3((unsigned)(f.xcd_groups * 8)), dim3(GROUP_THREADS), 0, s, f);
+        else if (wrank) hipLaunchKernelGGL((k_group_finish<true>), dim3((unsigned)(f.xcd_groups * 8)), dim3(GROUP_THREADS), 0, s, f);
+        else hipLaunchKernelGGL((k_group_finish<false>), dim3((unsigned)(f.xcd_groups * 8)), dim3(GROUP_THREADS), 0, s, f);
         HIP_G(hipGetLastError());
         if (h_stats[1] > 0) {
             const unsigned n_large = h_stats[1];
@@ -897,6 +962,7 @@ done:
     for (int i = 0; i < 2; i++) { (void)gki_dev_free(rows[i]); (void)gki_dev_free(keys[i]); }
     (void)gki_dev_free(hist); (void)gki_dev_free(offs); (void)gki_dev_free(tmp); (void)gki_dev_free(gbegin); (void)gki_dev_free(gend);
     (void)gki_dev_free(large); (void)gki_dev_free(big); (void)gki_dev_free(stats); (void)gki_dev_free(rng);
+    if (d_tiles) { (void)hipStreamSynchronize(s); (void)gki_dev_free(d_tiles); }     // (the upload read h_tiles asynchronously)
 #undef HIP_G
     return rc;
 }
@@ -912,38 +978,58 @@ namespace {
 constexpr int MAX_CHUNKS = 16;
 struct ChunkOffs { const uint32_t *offs[MAX_CHUNKS]; int64_t n_tiles[MAX_CHUNKS]; int64_t hist_n[MAX_CHUNKS]; int n_chunks; };
 
-// start[p] = first output row of part p (start[n_parts] = n); dbase[c * bins + d] = first output row of chunk c's part d
-__global__ void k_part_bases(ChunkOffs co, int n_parts, int bins, int64_t *__restrict__ start, int64_t *__restrict__ dbase) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int64_t at = 0;
-    for (int d = 0; d < bins; d++) {
-        if (d <= n_parts) start[d] = at;
-        for (int c = 0; c < co.n_chunks; c++) {
-            const int64_t first = co.offs[c][(int64_t)d * co.n_tiles[c]];
-            const int64_t next = co.offs[c][(int64_t)(d + 1) * co.n_tiles[c]];        // d + 1 == bins: the scan's total
-            dbase[c * bins + d] = at;
-            at += next - first;
-        }
+// start[d] = first output row of digit d (start[n_digits] = n); dbase[c * bins + d] = first output row of chunk c's digit d.
+// One block, one thread per digit (bins <= 1024).
+__global__ __launch_bounds__(1024) void k_part_bases(ChunkOffs co, int n_digits, int bins, int64_t *__restrict__ start, int64_t *__restrict__ dbase) {
+    __shared__ int64_t sh[1024];
+    const int d = threadIdx.x;
+    int64_t cnt[MAX_CHUNKS], tot = 0;
+#pragma unroll
+    for (int c = 0; c < MAX_CHUNKS; c++) {
+        cnt[c] = 0;
+        if (c < co.n_chunks && d < bins)
+            cnt[c] = (int64_t)co.offs[c][(int64_t)(d + 1) * co.n_tiles[c]] - (int64_t)co.offs[c][(int64_t)d * co.n_tiles[c]];   // d + 1 == bins: the scan's total
+        tot += cnt[c];
     }
-    for (int d = bins; d <= n_parts; d++) start[d] = at;
-    if (n_parts < bins) start[n_parts] = at;            // (digits >= n_parts hold nothing)
+    sh[d] = tot;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int64_t v = d >= off ? sh[d - off] : 0;
+        __syncthreads();
+        sh[d] += v;
+        __syncthreads();
+    }
+    int64_t at = sh[d] - tot;
+    if (d <= n_digits) start[d] = at;
+    if (d == 1023 && n_digits == 1024) start[1024] = sh[1023];
+    if (d < bins) {
+#pragma unroll
+        for (int c = 0; c < MAX_CHUNKS; c++)
+            if (c < co.n_chunks) { dbase[c * bins + d] = at; at += cnt[c]; }
+    }
 }
 }  // namespace
 
-int gki_partition_columns_by_part(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
-                                  uint64_t modulo, int n_parts, int64_t max_rows_per_pass, void *d_out_kmers, void *d_out_nodes,
-                                  void *d_out_ref_offsets, void *d_out_af32, int64_t *h_part_start) {
-    constexpr int THREADS = GKI_PR_THREADS, RI = 8, TILE = THREADS * RI;
+template <int THREADS>
+static int partition_columns_by_part(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
+                                     uint64_t modulo, int n_parts, int sub_bits, int64_t max_rows_per_pass, void *d_out_kmers,
+                                     void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32, int64_t *h_part_start) {
+    constexpr int RI = 8, TILE = THREADS * RI;
     hipStream_t s = 0;
+    const int n_digits = n_parts << sub_bits;
     int bits = 0;
-    while ((1 << bits) < n_parts) bits++;
+    while ((1 << bits) < n_digits) bits++;
     const int bins = 1 << bits;
     int64_t chunk_rows = (((int64_t)1 << 31) - 1) / TILE * TILE;
     if (max_rows_per_pass > 0 && max_rows_per_pass < chunk_rows) chunk_rows = ceil_div(max_rows_per_pass, TILE) * TILE;
     const int n_chunks = (int)ceil_div(n, chunk_rows);
     if (n_chunks > MAX_CHUNKS) return gki_set_error(GKI_ERR_OVERFLOW, "%lld records: partition at most %lld at a time", (long long)n, (long long)(chunk_rows * MAX_CHUNKS));
-    uint32_t h_pb[MAX_PARTS + 1];
+    uint32_t h_pb[PB_WORDS];
     for (int p = 0; p <= n_parts; p++) h_pb[p] = (uint32_t)(modulo * (uint64_t)p / (uint64_t)n_parts);
+    for (int p = 0; p < n_parts; p++) {
+        const int kbp = h_pb[p + 1] > h_pb[p] ? key_bits((uint64_t)(h_pb[p + 1] - h_pb[p]) - 1) : 0;
+        h_pb[MAX_PARTS + 1 + p] = (uint32_t)(kbp > sub_bits ? kbp - sub_bits : 0);
+    }
     uint32_t *hist = nullptr, *offs[MAX_CHUNKS] = {nullptr}, *pb = nullptr;
     int64_t *pstart = nullptr, *dbase = nullptr;
     int *bad = nullptr;
@@ -951,7 +1037,7 @@ int gki_partition_columns_by_part(const void *d_kmers, const void *d_nodes, cons
     ChunkOffs co;
     co.n_chunks = n_chunks;
     KeyRule rule;
-    rule.mod = gki_mod_of(modulo); rule.bucket_begin = 0; rule.n_buckets = modulo; rule.n_parts = n_parts;
+    rule.mod = gki_mod_of(modulo); rule.bucket_begin = 0; rule.n_buckets = modulo; rule.n_parts = n_parts; rule.sub_bits = sub_bits;
     int rc = GKI_OK;
 #define HIP_G(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = gki_set_error(GKI_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); goto done; } } while (0)
     {
@@ -959,12 +1045,12 @@ int gki_partition_columns_by_part(const void *d_kmers, const void *d_nodes, cons
         const int64_t tmp_bytes = gki_scan_tmp_bytes((int64_t)bins * max_tiles);
         HIP_G(gki_dev_malloc((void **)&hist, (size_t)bins * max_tiles * 4));
         HIP_G(gki_dev_malloc(&tmp, (size_t)tmp_bytes));
-        HIP_G(gki_dev_malloc((void **)&pb, (MAX_PARTS + 1) * 4));
-        HIP_G(gki_dev_malloc((void **)&pstart, (MAX_PARTS + 1) * 8));
+        HIP_G(gki_dev_malloc((void **)&pb, PB_WORDS * 4));
+        HIP_G(gki_dev_malloc((void **)&pstart, (size_t)(1024 + 1) * 8));
         HIP_G(gki_dev_malloc((void **)&dbase, (size_t)n_chunks * bins * 8));
         HIP_G(gki_dev_malloc((void **)&bad, 16));
-        HIP_G(hipMemcpyAsync(pb, h_pb, (size_t)(n_parts + 1) * 4, hipMemcpyHostToDevice, s));
-        rule.part_begin = pb;
+        HIP_G(hipMemcpyAsync(pb, h_pb, PB_WORDS * 4, hipMemcpyHostToDevice, s));
+        rule.part_begin = pb; rule.sub_shift = pb + MAX_PARTS + 1;
         for (int c = 0; c < n_chunks; c++) {
             const int64_t c0 = (int64_t)c * chunk_rows, nc = (n - c0) < chunk_rows ? (n - c0) : chunk_rows;
             const int64_t n_tiles = ceil_div(nc, TILE), hist_n = (int64_t)bins * n_tiles;
@@ -973,16 +1059,17 @@ int gki_partition_columns_by_part(const void *d_kmers, const void *d_nodes, cons
             co.offs[c] = offs[c];
             const int xcd_tiles = (int)ceil_div(n_tiles, 8);
             hipLaunchKernelGGL((k_kmer_digit_hist<THREADS, RI>), dim3((unsigned)(xcd_tiles * 8)), dim3(THREADS), 0, s, (const uint64_t *)d_kmers + c0,
-                               nc, rule, 0, bits, hist, n_tiles, xcd_tiles, bad);
+                               nc, rule, 0, bits, hist, n_tiles, xcd_tiles, (const TileDesc *)nullptr, bad);
             HIP_G(hipGetLastError());
             rc = gki_scan_u32_to_u32(hist, hist_n, offs[c], tmp, tmp_bytes, s);
             if (rc != GKI_OK) goto done;
         }
-        hipLaunchKernelGGL(k_part_bases, dim3(1), dim3(64), 0, s, co, n_parts, bins, pstart, dbase);
+        hipLaunchKernelGGL(k_part_bases, dim3(1), dim3(1024), 0, s, co, n_digits, bins, pstart, dbase);
         HIP_G(hipGetLastError());
         for (int c = 0; c < n_chunks; c++) {
             const int64_t c0 = (int64_t)c * chunk_rows, nc = (n - c0) < chunk_rows ? (n - c0) : chunk_rows;
             PartArgs a;
+            a.tiles = nullptr;
             a.keys_in = nullptr; a.c_kmers = (const uint64_t *)d_kmers + c0; a.c_nodes = (const uint32_t *)d_nodes + c0;
             a.c_refs = (const uint64_t *)d_ref_offsets + c0; a.c_af = (const uint32_t *)d_af32 + c0; a.rule = rule; a.rows_in = nullptr;
             a.n = nc; a.n_tiles = co.n_tiles[c]; a.shift = 0; a.bits = bits; a.offs = offs[c]; a.rows_out = nullptr; a.keys_out = nullptr;
@@ -992,7 +1079,7 @@ int gki_partition_columns_by_part(const void *d_kmers, const void *d_nodes, cons
             hipLaunchKernelGGL((k_partition_rows<THREADS, RI, true, true>), dim3((unsigned)(a.xcd_tiles * 8)), dim3(THREADS), 0, s, a);
             HIP_G(hipGetLastError());
         }
-        HIP_G(hipMemcpyAsync(h_part_start, pstart, (size_t)(n_parts + 1) * 8, hipMemcpyDeviceToHost, s));
+        HIP_G(hipMemcpyAsync(h_part_start, pstart, (size_t)(n_digits + 1) * 8, hipMemcpyDeviceToHost, s));
         HIP_G(hipStreamSynchronize(s));
     }
 done:
@@ -1001,4 +1088,17 @@ done:
     for (int c = 0; c < n_chunks; c++) (void)gki_dev_free(offs[c]);
 #undef HIP_G
     return rc;
+}
+
+// sub_bits > 0: grouped -- part p's records leave grouped by the top sub_bits bits of (bucket - part_begin[p]); h_part_start has
+// (n_parts << sub_bits) + 1 entries, entry p << sub_bits | g = first row of group g of part p.  Up to 256 digits go through
+// 2048-row tiles (two workgroups per CU), more through 4096-row tiles (longer runs per digit).
+int gki_partition_columns_by_part(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
+                                  uint64_t modulo, int n_parts, int sub_bits, int64_t max_rows_per_pass, void *d_out_kmers,
+                                  void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32, int64_t *h_part_start) {
+    if ((n_parts << sub_bits) <= MAX_PARTS)
+        return partition_columns_by_part<GKI_PR_THREADS>(d_kmers, d_nodes, d_ref_offsets, d_af32, n, modulo, n_parts, sub_bits, max_rows_per_pass,
+                                                         d_out_kmers, d_out_nodes, d_out_ref_offsets, d_out_af32, h_part_start);
+    return partition_columns_by_part<512>(d_kmers, d_nodes, d_ref_offsets, d_af32, n, modulo, n_parts, sub_bits, max_rows_per_pass,
+                                          d_out_kmers, d_out_nodes, d_out_ref_offsets, d_out_af32, h_part_start);
 }

@@ -314,6 +314,24 @@ int gki_index_build_range(const void *d_kmers, const void *d_nodes, const void *
                           void *d_hashes_to_index, void *d_n_kmers,
                           void *d_out_kmers, void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32,
                           void *d_out_frequencies, void *d_out_permutation);
+/* Grouped partition and build: one sort pass less per slice on ONE GPU (the slices of a whole-genome index: 26 key bits at
+ * 7 records per bucket = 7 bits grouped + one pass of 10 + 9 in LDS, against two passes without the grouping).
+ * gki_partition_by_bucket_range_grouped: as _chunked, and the records of part p additionally leave grouped (stably) by
+ *   the top group_bits bits of their key in that part (key = bucket - part begin; "top bits" = key >> (bits of the part's
+ *   largest key - group_bits), 0 when the key has fewer bits): h_start[(n_parts << group_bits) + 1], entry
+ *   p << group_bits | g = first row of group g of part p.  n_parts << group_bits <= 1024.  group_bits = 0: _chunked.
+ * gki_index_build_range_grouped: gki_index_build_range for records that arrive so grouped: h_group_start[2^group_bits + 1]
+ *   = the part's slice of that table, relative to the part's first row.  Same outputs, element by element. */
+int gki_partition_by_bucket_range_grouped(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets,
+                                          const void *d_af32, int64_t n, uint64_t modulo, int n_parts, int group_bits,
+                                          int64_t max_rows_per_pass, void *d_out_kmers, void *d_out_nodes,
+                                          void *d_out_ref_offsets, void *d_out_af32, int64_t *h_start);
+int gki_index_build_range_grouped(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32,
+                                  int64_t n, uint64_t modulo, uint64_t bucket_begin, uint64_t n_buckets,
+                                  int skip_frequencies, int group_bits, const int64_t *h_group_start,
+                                  void *d_hashes_to_index, void *d_n_kmers,
+                                  void *d_out_kmers, void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32,
+                                  void *d_out_frequencies, void *d_out_permutation);
 /* The build has two forms with identical results.  gki_index_build(_range) runs the row-carrying form (the 24-byte
  * payload travels with its key through stable partition passes, the last bits are sorted inside LDS; no random access)
  * and hands over to the pair-sorting form (stable LSD sort of (bucket, index) pairs, then one gather of the payload)

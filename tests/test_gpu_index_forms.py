@@ -138,3 +138,82 @@ def test_wave_prefix_sum_on_the_dpp_path_equals_the_shuffle_form():
     bad = C.c_int64(-1)
     _lib.check(_lib.load().gki_selftest_wave_scan(C.byref(bad)))
     assert bad.value == 0
+
+
+def _group_ids(buckets, lo, hi, g):
+    """Group of every bucket of the part [lo, hi) under the rule of gki_partition_by_bucket_range_grouped."""
+    kb = int(hi - lo - 1).bit_length()
+    return (buckets - np.uint64(lo)) >> np.uint64(max(0, kb - g))
+
+
+@pytest.mark.parametrize("n,modulo,n_parts,g,n_distinct", [
+    (600000, 100003, 8, 7, 250000),     # 6 per bucket (ballot ranking, 4096-row finish groups), k-mers repeated: 1024 digits
+    (500000, 452930477, 8, 7, 400000),  # default modulo, sparse: one partition pass inside the groups, nearly empty finish groups
+    (300000, 65537, 3, 4, 200000),      # parts that are no power of two, few groups
+    (200000, 1009, 4, 6, 900),          # more groups than buckets per part: groups of single buckets, 200 records per bucket
+    (50000, 999983, 1, 10, 40000),      # one part cut into 1024 groups
+    (7, 4, 2, 2, 5),                    # seven records
+])
+def test_grouped_partition_and_grouped_build_equal_the_oracle(n, modulo, n_parts, g, n_distinct):
+    """The single-GPU whole-genome build: the partition pass groups every part's records by the top bits of their key
+    (gki_partition_by_bucket_range_grouped) and the slice builds start from that grouping with one pass less
+    (gki_index_build_range_grouped).  The partition must be the stable partition by (part, group); every slice must equal
+    the oracle's stable build cut at the slice's bucket range, element by element."""
+    from graph_kmer_index_amd.collision_free_kmer_index import partition_by_bucket_range, PartitionedDeviceIndex
+    kmers, nodes, refs, af = _records(n, n_distinct, seed=n + g)
+    full = oracle.index_build(kmers, nodes, refs, af, modulo=modulo)
+    buckets = kmers % np.uint64(modulo)
+    d = DeviceFlatKmers.from_flat_kmers(FlatKmers(kmers, nodes, refs, af))
+    part, start = partition_by_bucket_range(d, modulo, n_parts, group_bits=g, max_rows_per_pass=150000)
+    begins = np.array([bucket_range(modulo, n_parts, p)[0] for p in range(n_parts)], dtype=np.uint64)
+    owner = np.searchsorted(begins, buckets, side="right") - 1
+    digit = np.zeros(n, dtype=np.int64)
+    for p in range(n_parts):
+        lo, hi = bucket_range(modulo, n_parts, p)
+        sel = owner == p
+        digit[sel] = (p << g) | _group_ids(buckets[sel], lo, hi, g).astype(np.int64)
+    order = np.argsort(digit, kind="stable")
+    got = part.to_flat_kmers()
+    for name, col in (("_hashes", kmers), ("_nodes", nodes), ("_ref_offsets", refs), ("_allele_frequencies", af)):
+        assert np.array_equal(getattr(got, name), col[order]), name
+    assert start == np.concatenate([[0], np.cumsum(np.bincount(digit, minlength=n_parts << g))]).tolist()
+    sorted_buckets = np.sort(buckets, kind="stable")
+    for p in range(n_parts):
+        lo, hi = bucket_range(modulo, n_parts, p)
+        for skip in (False, True):
+            dev = PartitionedDeviceIndex.build_slice(part, start, modulo, n_parts, p, g, skip_frequencies=skip)
+            first = int(np.searchsorted(sorted_buckets, lo))
+            m = dev.n
+            assert m == int((owner == p).sum())
+            for name, attr in (("_kmers", "kmers"), ("_nodes", "nodes"), ("_ref_offsets", "ref_offsets"),
+                               ("_allele_frequencies", "allele_frequencies")):
+                assert np.array_equal(getattr(dev, attr).to_host(m), full[name][first:first + m]), (p, name)
+            if not skip:
+                assert np.array_equal(dev.frequencies.to_host(m), full["_frequencies"][first:first + m]), p
+            nk = dev.n_kmers.to_host()
+            assert np.array_equal(nk, full["_n_kmers"][lo:hi])
+            h2i = dev.hashes_to_index.to_host()
+            assert np.array_equal(h2i[nk > 0], full["_hashes_to_index"][lo:hi][nk > 0] - first)
+            assert not h2i[nk == 0].any()
+            dev.free()
+    part.free()
+    d.free()
+
+
+def test_partitioned_index_grouped_and_plain_count_the_same_nodes():
+    from graph_kmer_index_amd.collision_free_kmer_index import PartitionedDeviceIndex
+    n, modulo = 400000, 200003
+    kmers, nodes, refs, af = _records(n, 150000, seed=21)
+    nodes = nodes % np.uint32(5000)
+    d = DeviceFlatKmers.from_flat_kmers(FlatKmers(kmers, nodes, refs, af))
+    queries = np.concatenate([kmers[::7], np.random.default_rng(3).integers(0, 4 ** 31, size=5000, dtype=np.uint64)])
+    want = None
+    for grouped in (True, False):
+        idx = PartitionedDeviceIndex.build(d, modulo, n_parts=8, grouped=grouped)
+        assert idx.n == n
+        got = idx.count_nodes(queries, 5000, max_hits=2 ** 40).to_host()
+        if want is None:
+            want = got
+        assert got.sum() > 0 and np.array_equal(got, want)
+        idx.free()
+    d.free()
