@@ -455,24 +455,27 @@ def full_index_record(lib, _lib, g, k, cp, out, max_variant_nodes, modulo, n_sli
     nothing to exchange: round 3 timed a device copy per slice as a stand-in for the all-to-all of configs[3]; that
     exchange is `sharded_build`'s subject (N > 1), not this record's."""
     from graph_kmer_index_amd.flat_kmers import DeviceFlatKmers
-    from graph_kmer_index_amd.collision_free_kmer_index import PartitionedDeviceIndex, bucket_range, partition_by_bucket_range
+    from graph_kmer_index_amd.collision_free_kmer_index import (PartitionedDeviceIndex, DeviceRows, partition_rows_by_bucket_range,
+                                                                partition_by_bucket_range)
     def sync():
         _lib.check(lib.gki_device_synchronize())
     n = out.n
     MASK = (1 << 64) - 1
     cols = ("hashes", "nodes", "ref_offsets", "allele_frequencies")
     W = n_slices
-    G = 10 - (W - 1).bit_length()          # the partition pass also groups every slice by the top G bits of its keys (1024 digits)
+    G = int(os.environ.get("GKI_BENCH_GROUP_BITS", "0"))     # > 0: the grouped flow (rows between partition and build, DESIGN.md 4.3)
     kw = dict(only_save_one_node_per_kmer=True, max_variant_nodes=max_variant_nodes)
     from graph_kmer_index_amd import DenseKmerFinder
     finder = DenseKmerFinder(g, k, critical_graph_paths=cp, **kw)
     finder._params()
     if finder._count(layout=1) != n:
         raise _lib.GkiError(2, "full_index: the graph holds %d records, the step wrote %d" % (finder._count(layout=1), n))
-    parts = DeviceFlatKmers.allocate(n)                   # the partitioned records: 24 B x n beside the step's own columns
+    parts = DeviceRows(n) if G else DeviceFlatKmers.allocate(n)      # the partitioned records beside the step's own columns
     # everything once untimed: sizes the library's memory pool (hipMalloc / hipFree of tens of GB cost seconds on this stack,
     # DESIGN.md section 6 "Device memory pool"; the index_build record measures its third build for the same reason)
-    _, start = partition_by_bucket_range(out, modulo, W, out=parts, group_bits=G)
+    do_partition = (lambda: partition_rows_by_bucket_range(out, modulo, W, group_bits=G, out=parts)) if G else \
+        (lambda: partition_by_bucket_range(out, modulo, W, out=parts))
+    _, start = do_partition()
     biggest = max(range(W), key=lambda p: start[(p + 1) << G] - start[p << G])
     sl = PartitionedDeviceIndex.build_slice(parts, start, modulo, W, biggest, G)
     sl.free()
@@ -485,7 +488,7 @@ def full_index_record(lib, _lib, g, k, cp, out, max_variant_nodes, modulo, n_sli
     want = [getattr(out, c).checksum(n) for c in cols]
     sync()
     t = time.perf_counter()
-    _, start = partition_by_bucket_range(out, modulo, W, out=parts, group_bits=G)
+    _, start = do_partition()
     sync()
     t_part = time.perf_counter() - t
     got = [(0, 0)] * 4
@@ -508,14 +511,14 @@ def full_index_record(lib, _lib, g, k, cp, out, max_variant_nodes, modulo, n_sli
     parts.free()
     total = sum(sizes)
     dt = t_find + t_part + t_build
-    # as implemented, per record: the step 25 B; partition 8 R (histogram) + 24 R + 24 W; slice build: histogram 8 R, ONE
-    # partition pass 24 R + 28 W, group bounds 4 R, finish 28 R + 26 W
-    moved = (BYTES_PER_RECORD + 56 + 118) * total + 8 * modulo
+    # as implemented, per record: the step 25 B; partition 8 R (histogram) + 24 R + 24 W; slice build: histogram 8 R, first pass
+    # 24 R + 28 W, second 4 R + 28 R + 28 W, group bounds 4 R, finish 28 R + 26 W  (grouped: 60 + 118)
+    moved = (BYTES_PER_RECORD + (60 + 118 if G else 56 + 178)) * total + 8 * modulo
     rec = {"records": int(total), "slices": W, "records_per_slice": sizes, "exceeds_int32_directory": bool(total >= 2 ** 31),
            "find_ms": 1e3 * t_find, "partition_ms": 1e3 * t_part, "build_slices_ms": 1e3 * t_build,
            "build_ms_per_slice": [round(x, 2) for x in build_ms], "ms": 1e3 * dt, "records_per_s": total / dt,
            "roofline": index_roofline(total, modulo, nonempty, dt, hashing=True),
-           "roofline_at_the_two_passes_run": index_roofline(total, modulo, nonempty, dt, hashing=True, passes=2),
+           "roofline_at_the_passes_run": index_roofline(total, modulo, nonempty, dt, hashing=True, passes=2 if G else 3),
            "group_bits": G,
            "bytes_moved_model": int(moved), "achieved_GBps_as_implemented": moved / dt / 1e9,
            "frac_of_hbm_peak_as_implemented": moved / dt / 1e9 / HBM_PEAK_GBS,
@@ -526,10 +529,10 @@ def full_index_record(lib, _lib, g, k, cp, out, max_variant_nodes, modulo, n_sli
            "equals_step_output": bool(total == n),
            "payload_equals_flat_multiset": [tuple(w) for w in want] == [tuple(x) for x in got],
            "timed": "wall clock, device synchronised per phase: the whole graph enumerated and hashed (gki_finder_count + "
-                    "gki_finder_emit_flat), its records partitioned by bucket range into %d slices and, inside a slice, grouped by the top "
-                    "%d bits of the key (gki_partition_by_bucket_range_grouped, one call), every slice built with frequencies from that "
-                    "grouping (gki_index_build_range_grouped: one partition pass + finish); hashed AND indexed, end to end; "
-                    "checksums of the slices outside the timed phases" % (W, G)}
+                    "gki_finder_emit_flat), its records partitioned by bucket range into %d slices (gki_partition_by_bucket_range, one "
+                    "call; group_bits %d > 0: grouped and left as rows, gki_partition_rows_by_bucket_range), every slice built with "
+                    "frequencies (gki_index_build_range / _from_rows); hashed AND indexed, end to end; checksums of the slices outside "
+                    "the timed phases" % (W, G)}
     log("full index: %d records in %d slices: find %.1f + partition %.1f + build %.1f = %.1f ms" % (total, W, 1e3 * t_find, 1e3 * t_part, 1e3 * t_build, 1e3 * dt))
     return rec
 

@@ -106,6 +106,9 @@ SYMBOLS = {
     "gki_index_build_range": (_I32, [_P, _P, _P, _P, _I64, _U64, _U64, _U64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gki_index_build_range_grouped": (_I32, [_P, _P, _P, _P, _I64, _U64, _U64, _U64, _I32, _I32, C.POINTER(_I64),
                                              _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gki_partition_rows_by_bucket_range": (_I32, [_P, _P, _P, _P, _I64, _U64, _I32, _I32, _I64, _P, _P, C.POINTER(_I64)]),
+    "gki_index_build_range_from_rows": (_I32, [_P, _P, _I64, _U64, _U64, _U64, _I32, _I32, C.POINTER(_I64),
+                                               _P, _P, _P, _P, _P, _P, _P]),
     "gki_index_build_pairs": (_I32, [_P, _P, _P, _P, _I64, _U64, _U64, _U64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gki_reverse_index_build": (_I32, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
     "gki_index_lookup_count": (_I32, [C.POINTER(IndexView), _P, _I64, _I64, _P, C.POINTER(_I64)]),

@@ -64,6 +64,26 @@ class DeviceIndex:
             _lib.check(fn(*head, *tail))
         return out
 
+    @classmethod
+    def build_from_rows(cls, rows, keys, n, modulo, skip_frequencies=False, bucket_begin=0, n_buckets=None, group_start=None):
+        """gki_index_build_range_from_rows: one part of `partition_rows_by_bucket_range` (views of its rows and keys)."""
+        _lib.require_device()
+        na = max(n, 1)
+        nb = int(modulo if n_buckets is None else n_buckets)
+        out = cls(n, modulo, _lib.DeviceArray(nb, np.int32), _lib.DeviceArray(nb, np.uint32),
+                  _lib.DeviceArray(na, np.uint64), _lib.DeviceArray(na, np.uint32), _lib.DeviceArray(na, np.uint64),
+                  _lib.DeviceArray(na, np.float32), _lib.DeviceArray(na, np.uint16), bucket_begin, nb)
+        group_bits, bounds = 0, None
+        if group_start is not None:
+            group_bits = (len(group_start) - 1).bit_length() - 1
+            assert len(group_start) == (1 << group_bits) + 1
+            bounds = (C.c_int64 * len(group_start))(*[int(x) for x in group_start])
+        _lib.check(_lib.load().gki_index_build_range_from_rows(
+            rows.ptr, keys.ptr, int(n), int(modulo), int(bucket_begin), nb, int(bool(skip_frequencies)), group_bits, bounds,
+            out.hashes_to_index.ptr, out.n_kmers.ptr, out.kmers.ptr, out.nodes.ptr, out.ref_offsets.ptr,
+            out.allele_frequencies.ptr, out.frequencies.ptr))
+        return out
+
     def lookup_positions(self, queries, max_hits=10, use_probe_table=True):
         """Batched CollisionFreeKmerIndex.get: (hit_start int64[q+1], position int64[hits] into the payload
         arrays, query index int64[hits]) as NumPy arrays.  use_probe_table=False probes the reference-layout arrays
@@ -220,6 +240,35 @@ def partition_by_bucket_range(dflat, modulo, n_parts, out=None, max_rows_per_pas
     return out, [int(x) for x in start]
 
 
+class DeviceRows:
+    """Records partitioned by bucket range and kept as 24-byte rows + 32-bit keys between the partition and the slice
+    builds (gki_partition_rows_by_bucket_range -> gki_index_build_range_from_rows): the intermediate of the single-GPU
+    whole-genome build, not a FlatKmers."""
+
+    def __init__(self, n, rows=None, keys=None):
+        self.n = int(n)
+        self.rows = rows if rows is not None else _lib.DeviceArray(3 * max(self.n, 1), np.uint64)
+        self.keys = keys if keys is not None else _lib.DeviceArray(max(self.n, 1), np.uint32)
+
+    def free(self):
+        self.rows.free()
+        self.keys.free()
+
+
+def partition_rows_by_bucket_range(dflat, modulo, n_parts, group_bits=0, out=None, max_rows_per_pass=0):
+    """partition_by_bucket_range with the partitioned records left as rows (DeviceRows).  Returns (DeviceRows, start)."""
+    _lib.require_device()
+    if out is None:
+        out = DeviceRows(dflat.n)
+    assert out.keys.n >= dflat.n and out.rows.n >= 3 * dflat.n
+    out.n = dflat.n
+    start = (C.c_int64 * ((n_parts << group_bits) + 1))()
+    _lib.check(_lib.load().gki_partition_rows_by_bucket_range(
+        dflat.hashes.ptr, dflat.nodes.ptr, dflat.ref_offsets.ptr, dflat.allele_frequencies.ptr, dflat.n, int(modulo),
+        int(n_parts), int(group_bits), int(max_rows_per_pass), out.rows.ptr, out.keys.ptr, start))
+    return out, [int(x) for x in start]
+
+
 class PartitionedDeviceIndex:
     """A CollisionFreeKmerIndex cut into bucket-range slices, each a DeviceIndex with its own directory slice
     (SURVEY.md 8f-1).  On one GPU the slices sit side by side (no 2^31 limit on the total); across GPUs each rank
@@ -234,13 +283,18 @@ class PartitionedDeviceIndex:
         return sum(p.n for p in self.parts)
 
     @classmethod
-    def build(cls, dflat, modulo=452930477, n_parts=8, skip_frequencies=False, grouped=True, out=None):
+    def build(cls, dflat, modulo=452930477, n_parts=8, skip_frequencies=False, grouped=False, out=None):
         """Partition by bucket range, build every slice.  grouped: the partition also groups every slice's records by
-        the top bits of their key (as many as keep n_parts << bits within the partition pass's 1024 digits) and the slice
-        builds start from there -- one sort pass less per slice (DESIGN.md 4.3 "Grouped build").  `out`: columns for the
-        partitioned records (see `partition_by_bucket_range`)."""
+        the top bits of their key (as many as keep n_parts << bits within the partition pass's 1024 digits), leaves them
+        as rows, and the slice builds start from there -- one sort pass less per slice, paid for by a partition pass
+        that is as much slower (1024 digits instead of 8): measured equal end to end on the 3 Gbp graph, hence not the
+        default (DESIGN.md 4.3 "Grouped build").  `out`: where the partitioned records go (DeviceFlatKmers, or
+        DeviceRows when grouped)."""
         g = max(0, 10 - max(0, (n_parts - 1).bit_length())) if grouped else 0
-        part, start = partition_by_bucket_range(dflat, modulo, n_parts, out=out, group_bits=g)
+        if grouped:
+            part, start = partition_rows_by_bucket_range(dflat, modulo, n_parts, group_bits=g, out=out)
+        else:
+            part, start = partition_by_bucket_range(dflat, modulo, n_parts, out=out)
         parts = []
         for p in range(n_parts):
             parts.append(cls.build_slice(part, start, modulo, n_parts, p, g, skip_frequencies))
@@ -250,12 +304,16 @@ class PartitionedDeviceIndex:
 
     @staticmethod
     def build_slice(part, start, modulo, n_parts, p, group_bits, skip_frequencies=False):
-        """The DeviceIndex of slice p from the partitioned records (`part`, `start` of partition_by_bucket_range)."""
+        """The DeviceIndex of slice p from the partitioned records: `part` a DeviceFlatKmers (partition_by_bucket_range)
+        or a DeviceRows (partition_rows_by_bucket_range), `start` the table that call returned."""
         lo, hi = bucket_range(modulo, n_parts, p)
         a, b = start[p << group_bits], start[(p + 1) << group_bits]
+        groups = [x - a for x in start[p << group_bits:((p + 1) << group_bits) + 1]] if group_bits else None
+        if isinstance(part, DeviceRows):
+            return DeviceIndex.build_from_rows(part.rows.view(3 * a, 3 * (b - a)), part.keys.view(a, b - a), b - a, modulo,
+                                               skip_frequencies, lo, hi - lo, groups)
         sl = DeviceFlatKmers(b - a, part.hashes.view(a, b - a), part.nodes.view(a, b - a),
                              part.ref_offsets.view(a, b - a), part.allele_frequencies.view(a, b - a))
-        groups = [x - a for x in start[p << group_bits:((p + 1) << group_bits) + 1]] if group_bits else None
         return DeviceIndex.build(sl, modulo, skip_frequencies, bucket_begin=lo, n_buckets=hi - lo, group_start=groups)
 
     def count_nodes(self, queries, n_nodes, max_hits=10, counts=None):

@@ -15,12 +15,13 @@
 
 int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
                          uint64_t modulo, uint64_t bucket_begin, uint64_t n_buckets, int skip_frequencies,
-                         int group_bits, const int64_t *h_group_start,
+                         int group_bits, const int64_t *h_group_start, const void *d_rows_in, const void *d_keys_in,
                          void *d_hashes_to_index, void *d_n_kmers, void *d_out_kmers, void *d_out_nodes,
                          void *d_out_ref_offsets, void *d_out_af32, void *d_out_frequencies, void *d_out_permutation, int *done);
 int gki_partition_columns_by_part(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
                                   uint64_t modulo, int n_parts, int sub_bits, int64_t max_rows_per_pass, void *d_out_kmers,
-                                  void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32, int64_t *h_part_start);
+                                  void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32, void *d_out_rows, void *d_out_keys,
+                                  int64_t *h_part_start);
 int gki_frequencies_for_rows(const int64_t *d_row_begin, const int64_t *d_row_end, int n_ranges, uint64_t modulo,
                              uint64_t bucket_begin, const void *d_hashes_to_index, const void *d_n_kmers,
                              const void *d_kmers, const void *d_refs, void *d_freq, int64_t n, hipStream_t s);
@@ -656,7 +657,7 @@ int gki_index_build_range_grouped(const void *d_kmers, const void *d_nodes, cons
         // (it sorts on the whole key: a grouping of the input is of no use to it and does no harm)
         int done = 0;
         GKI_TRY(gki_index_build_rows(d_kmers, d_nodes, d_ref_offsets, d_af32, n, modulo, bucket_begin, n_buckets, skip_frequencies,
-                                     group_bits, h_group_start, d_hashes_to_index, d_n_kmers, d_out_kmers, d_out_nodes,
+                                     group_bits, h_group_start, nullptr, nullptr, d_hashes_to_index, d_n_kmers, d_out_kmers, d_out_nodes,
                                      d_out_ref_offsets, d_out_af32, d_out_frequencies, d_out_permutation, &done));
         if (done) return GKI_OK;
     }
@@ -694,7 +695,51 @@ int gki_partition_by_bucket_range_grouped(const void *d_kmers, const void *d_nod
     if (n <= 0) return GKI_OK;
     // stable passes of the row-carrying build's partition kernel, columns in, columns out (gki_index_rows.hip)
     return gki_partition_columns_by_part(d_kmers, d_nodes, d_ref_offsets, d_af32, n, modulo, n_parts, group_bits, max_rows_per_pass,
-                                         d_out_kmers, d_out_nodes, d_out_ref_offsets, d_out_af32, h_start);
+                                         d_out_kmers, d_out_nodes, d_out_ref_offsets, d_out_af32, nullptr, nullptr, h_start);
+}
+
+int gki_partition_rows_by_bucket_range(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32,
+                                       int64_t n, uint64_t modulo, int n_parts, int group_bits, int64_t max_rows_per_pass,
+                                       void *d_rows, void *d_keys, int64_t *h_start) {
+    if (modulo == 0 || modulo > 0xFFFFFFFFull) return gki_set_error(GKI_ERR_BAD_ARG, "modulo must be in 1..2^32-1");
+    if (n_parts < 1 || n_parts > 256) return gki_set_error(GKI_ERR_BAD_ARG, "n_parts must be in 1..256");
+    if (group_bits < 0 || (n_parts << group_bits) > 1024) return gki_set_error(GKI_ERR_BAD_ARG, "n_parts << group_bits must not exceed 1024");
+    if (!d_rows || !d_keys) return gki_set_error(GKI_ERR_BAD_ARG, "rows and keys buffers are needed");
+    for (int p = 0; p <= (n_parts << group_bits); p++) h_start[p] = 0;
+    if (n <= 0) return GKI_OK;
+    return gki_partition_columns_by_part(d_kmers, d_nodes, d_ref_offsets, d_af32, n, modulo, n_parts, group_bits, max_rows_per_pass,
+                                         nullptr, nullptr, nullptr, nullptr, d_rows, d_keys, h_start);
+}
+
+int gki_index_build_range_from_rows(const void *d_rows, const void *d_keys, int64_t n, uint64_t modulo, uint64_t bucket_begin,
+                                    uint64_t n_buckets, int skip_frequencies, int group_bits, const int64_t *h_group_start,
+                                    void *d_hashes_to_index, void *d_n_kmers, void *d_out_kmers, void *d_out_nodes,
+                                    void *d_out_ref_offsets, void *d_out_af32, void *d_out_frequencies) {
+    if (modulo == 0 || modulo > 0xFFFFFFFFull) return gki_set_error(GKI_ERR_BAD_ARG, "modulo must be in 1..2^32-1");
+    if (n_buckets == 0 || bucket_begin + n_buckets > modulo)
+        return gki_set_error(GKI_ERR_BAD_ARG, "bucket range [%llu, +%llu) outside [0, modulo)", (unsigned long long)bucket_begin,
+                             (unsigned long long)n_buckets);
+    if (group_bits < 0 || group_bits > 10 || (group_bits > 0 && !h_group_start))
+        return gki_set_error(GKI_ERR_BAD_ARG, "group_bits must be in 0..10, with the group bounds when > 0");
+    if (n >= (1ll << 31))
+        return gki_set_error(GKI_ERR_OVERFLOW, "%lld records: the reference's directory is int32 "
+                             "(collision_free_kmer_index.py:453); shard the build", (long long)n);
+    hipStream_t s = 0;
+    if (n <= 0) {
+        HIP_TRY(hipMemsetAsync(d_hashes_to_index, 0, (size_t)n_buckets * 4, s));       // :453
+        HIP_TRY(hipMemsetAsync(d_n_kmers, 0, (size_t)n_buckets * 4, s));               // :456
+        HIP_TRY(hipStreamSynchronize(s));
+        return GKI_OK;
+    }
+    if (!d_rows || !d_keys) return gki_set_error(GKI_ERR_BAD_ARG, "rows and keys are needed");
+    int done = 0;
+    GKI_TRY(gki_index_build_rows(nullptr, nullptr, nullptr, nullptr, n, modulo, bucket_begin, n_buckets, skip_frequencies, group_bits,
+                                 h_group_start, d_rows, d_keys, d_hashes_to_index, d_n_kmers, d_out_kmers, d_out_nodes,
+                                 d_out_ref_offsets, d_out_af32, d_out_frequencies, nullptr, &done));
+    if (!done)
+        return gki_set_error(GKI_ERR_BAD_ARG, "the records are outside the row-carrying build's domain (a group of neighbouring buckets with "
+                             "more than 2^22 records): build this slice from its columns (gki_index_build_range)");
+    return GKI_OK;
 }
 
 int gki_partition_by_bucket_range_chunked(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32,

@@ -54,6 +54,7 @@ constexpr int GROUP_CAP = GKI_GROUP_CAP;          // rows a group may hold to be
 // workgroup per CU finishes 4096 rows, two more key bits than the 1024-row finish resolves, so that ONE partition pass is
 // left between the grouping and the finish (DESIGN.md 4.3 "Grouped build")
 constexpr int GROUP_CAP_BIG = 4096;
+constexpr int GROUP_THREADS_BIG = 1024;           // sixteen waves: the one workgroup a CU holds has to hide its own latencies
 constexpr int GROUP_LMAX = GKI_GROUP_LMAX;        // low key bits resolved in LDS
 constexpr int GROUP_THREADS = GKI_GROUP_THREADS;
 constexpr int SMALL_BUCKET = 24;              // as in gki_index.hip: buckets up to this size count frequencies per lane
@@ -78,18 +79,22 @@ __device__ __forceinline__ void stage_parts(const KeyRule &k, uint32_t *s_pb) {
         if (k.sub_bits > 0) for (int p = threadIdx.x; p < k.n_parts; p += blockDim.x) s_pb[MAX_PARTS + 1 + p] = k.sub_shift[p];
     }
 }
-// *bad: the bucket lies outside the slice (the build refuses such input); the key is then 0, never out of range
-__device__ __forceinline__ uint32_t key_of(const KeyRule &k, const uint32_t *s_pb, uint64_t kmer, bool *bad) {
+// The key the passes sort on (returned) and the key that travels with the row (*stored): the same for the build; for the
+// part rule the former is the part (with its group), the latter the bucket's offset in its part -- the key of that part's
+// slice build.  *bad: the bucket lies outside the slice (the build refuses such input); the key is then 0, never out of range
+__device__ __forceinline__ uint32_t key_of(const KeyRule &k, const uint32_t *s_pb, uint64_t kmer, bool *bad, uint32_t *stored) {
     const uint64_t b = gki_mod(k.mod, kmer);                            // collision_free_kmer_index.py:433
     if (k.n_parts > 0) {
         int p = (int)__umul64hi(b * (uint64_t)k.n_parts, k.mod.inv);    // floor(b * n_parts / modulo), or one or two short
         while (p + 1 < k.n_parts && s_pb[p + 1] <= (uint32_t)b) p++;
         while (p > 0 && s_pb[p] > (uint32_t)b) p--;
-        if (k.sub_bits > 0) return ((uint32_t)p << k.sub_bits) | (((uint32_t)b - s_pb[p]) >> s_pb[MAX_PARTS + 1 + p]);
+        *stored = (uint32_t)b - s_pb[p];
+        if (k.sub_bits > 0) return ((uint32_t)p << k.sub_bits) | (*stored >> s_pb[MAX_PARTS + 1 + p]);
         return (uint32_t)p;
     }
     const uint64_t rel = b - k.bucket_begin;
-    if (rel >= k.n_buckets) { *bad = true; return 0u; }
+    if (rel >= k.n_buckets) { *bad = true; *stored = 0u; return 0u; }
+    *stored = (uint32_t)rel;
     return (uint32_t)rel;
 }
 
@@ -219,7 +224,8 @@ __global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
     __shared__ uint32_t s_toff[MAXB];
     __shared__ uint32_t s_scan[W + 1];
     __shared__ uint32_t s_pb[SRC_COLS ? PB_WORDS : 1];
-    __shared__ int64_t s_dbase[DST_COLS ? (THREADS >= 512 ? MAXB : MAX_PARTS) : 1];        // (1024 digits only on the large tile)
+    __shared__ int64_t s_dbase[SRC_COLS ? (THREADS >= 512 ? MAXB : MAX_PARTS) : 1];        // (1024 digits only on the large tile)
+    __shared__ uint16_t s_dig[SRC_COLS ? TILE : 1];    // by slot: the digit (with the part rule it does not follow from the stored key)
     const int64_t tile = tile_of_block(a.n_tiles, a.xcd_tiles);
     if (tile >= a.n_tiles) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
                                 ((uint64_t)(a.carry_index ? (uint32_t)(tile_base + e) : a.c_af[tile_base + e]) << 32)) : 0ull;
         }
         stage_parts(a.rule, s_pb);
-        if (DST_COLS) for (int d = threadIdx.x; d < bins; d += THREADS) s_dbase[d] = a.dbase ? a.dbase[d] : 0;
+        for (int d = threadIdx.x; d < bins; d += THREADS) s_dbase[d] = a.dbase ? a.dbase[d] : 0;
     } else {
 #pragma unroll
         for (int r = 0; r < RI; r++) {
@@ -268,8 +274,9 @@ __global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
         bool bad = false;                                       // (the histogram kernel has reported it)
 #pragma unroll
         for (int r = 0; r < RI; r++) {
-            key[r] = valid[r] ? key_of(a.rule, s_pb, w0[r], &bad) : 0u;
-            dig[r] = (key[r] >> a.shift) & mask;
+            key[r] = 0u;
+            const uint32_t sort_key = valid[r] ? key_of(a.rule, s_pb, w0[r], &bad, &key[r]) : 0u;
+            dig[r] = (sort_key >> a.shift) & mask;
         }
     }
 
@@ -302,7 +309,8 @@ __global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
             if (d < bins) {
                 s_dstart[d] = ex;
                 // DST_COLS: relative to the digit's first run (the caller's dbase[d] is where that one goes)
-                s_toff[d] = a.offs[obase + (int64_t)d * ostride] - (DST_COLS ? a.offs[(int64_t)d * a.n_tiles] : 0u) - ex;
+                // with dbase: relative to the digit's first run (the caller's dbase[d] is where that one goes)
+                s_toff[d] = a.offs[obase + (int64_t)d * ostride] - (SRC_COLS && a.dbase ? a.offs[(int64_t)d * a.n_tiles] : 0u) - ex;
                 ex += tot[c];
             }
         }
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
         if (valid[r]) {
             const uint32_t slot = s_dstart[dig[r]] + s_wcnt[wave][dig[r]] + rank[r];
             s_keys[slot] = key[r];
-            if (SRC_COLS) { s_rows[slot * 3 + 0] = w0[r]; s_rows[slot * 3 + 1] = w1[r]; s_rows[slot * 3 + 2] = w2[r]; }
+            if (SRC_COLS) { s_dig[slot] = (uint16_t)dig[r]; s_rows[slot * 3 + 0] = w0[r]; s_rows[slot * 3 + 1] = w1[r]; s_rows[slot * 3 + 2] = w2[r]; }
             else s_dest[wave * SLICE + r * 64 + lane] = (uint16_t)slot;
         }
     }
@@ -337,7 +345,7 @@ __global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
         for (int r = 0; r < RI; r++) {
             const int p = r * THREADS + threadIdx.x;
             if (p < n_here) {
-                const uint32_t d = (s_keys[p] >> a.shift) & mask;
+                const uint32_t d = s_dig[p];
                 const int64_t row = s_dbase[d] + (int64_t)(uint32_t)(s_toff[d] + (uint32_t)p);
                 const uint64_t w2 = s_rows[p * 3 + 2];
                 a.o_kmers[row] = s_rows[p * 3]; a.o_refs[row] = s_rows[p * 3 + 1];
@@ -352,8 +360,8 @@ __global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
         const int j = r * THREADS + threadIdx.x;
         if (j < 3 * n_here) {
             const int p = j / 3;
-            const uint32_t d = (s_keys[p] >> a.shift) & mask;
-            int64_t row = (int64_t)(uint32_t)(s_toff[d] + (uint32_t)p);
+            const uint32_t d = SRC_COLS ? (uint32_t)s_dig[p] : ((s_keys[p] >> a.shift) & mask);
+            int64_t row = (SRC_COLS ? s_dbase[d] : 0) + (int64_t)(uint32_t)(s_toff[d] + (uint32_t)p);
 #if defined(GKI_TUNING) && defined(GKI_DBG_PART)        // where does the pass's time go: 1 = the sorted tile leaves in one piece
             row = tile_base + p;                          // (same LDS work, sequential stores; results wrong), 2 = no stores
             if (GKI_DBG_PART == 2 && row >= 0) continue;
@@ -366,8 +374,8 @@ __global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
         const int p = r * THREADS + threadIdx.x;
         if (p < n_here) {
             const uint32_t k = s_keys[p];
-            const uint32_t d = (k >> a.shift) & mask;
-            int64_t row = (int64_t)(uint32_t)(s_toff[d] + (uint32_t)p);
+            const uint32_t d = SRC_COLS ? (uint32_t)s_dig[p] : ((k >> a.shift) & mask);
+            int64_t row = (SRC_COLS ? s_dbase[d] : 0) + (int64_t)(uint32_t)(s_toff[d] + (uint32_t)p);
 #if defined(GKI_TUNING) && defined(GKI_DBG_PART)
             row = tile_base + p;
             if (GKI_DBG_PART == 2 && row >= 0) continue;
@@ -381,20 +389,28 @@ __global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
 // Four keys per lane (one 16-byte load), the key before a lane's four from the lane below (the first lane of a wave loads
 // it): a boundary between rows i - 1 and i ends the group of i - 1 and begins the group of i.  Round 3's form (one key per
 // lane, 2048 grid-stride workgroups) ran at 1.4 TB/s: 1.09 ms per 3.95e8 keys.
-__global__ __launch_bounds__(256) void k_group_bounds(const uint32_t *__restrict__ keys, int64_t n, int L,
-                                                      uint32_t *__restrict__ gbegin, uint32_t *__restrict__ gend) {
+// A key at or beyond key_limit (keys handed in by a caller, gki_index_build_range_from_rows) is flagged and counted as the
+// last valid key: the group tables are never indexed out of range.
+__global__ __launch_bounds__(256) void k_group_bounds(const uint32_t *__restrict__ keys, int64_t n, int L, uint32_t key_limit,
+                                                      uint32_t *__restrict__ gbegin, uint32_t *__restrict__ gend, int *__restrict__ bad) {
     const int lane = threadIdx.x & 63;
     const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     uint32_t g[4] = {0, 0, 0, 0};
+    uint32_t k4[4] = {0, 0, 0, 0};
     if (base + 3 < n) {
         const uint4 v = *reinterpret_cast<const uint4 *>(keys + base);
-        g[0] = v.x >> L; g[1] = v.y >> L; g[2] = v.z >> L; g[3] = v.w >> L;
+        k4[0] = v.x; k4[1] = v.y; k4[2] = v.z; k4[3] = v.w;
     } else {
 #pragma unroll
-        for (int t = 0; t < 4; t++) if (base + t < n) g[t] = keys[base + t] >> L;
+        for (int t = 0; t < 4; t++) if (base + t < n) k4[t] = keys[base + t];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        if (k4[t] >= key_limit) { *bad = 1; k4[t] = key_limit - 1u; }
+        g[t] = k4[t] >> L;
     }
     uint32_t before = __shfl_up(g[3], 1, 64);
-    if (lane == 0 && base > 0 && base < n) before = keys[base - 1] >> L;
+    if (lane == 0 && base > 0 && base < n) { const uint32_t kb = keys[base - 1]; before = (kb < key_limit ? kb : key_limit - 1u) >> L; }
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         const int64_t i = base + t;
@@ -450,7 +466,7 @@ struct FinishArgs {
 //    (wave, round, lane) order, match-any by ballots inside the wave, per-wave bucket counts, exclusive offsets over the
 //    waves -- whose cost does not grow with the bucket.  With the loop, a wave waited for its longest bucket (15-20 rows)
 //    three times over (rank, same k-mer, earlier duplicate): 12.2 ms per 3.95e8 rows against 4.3 ms per 3.1e8 sparse ones.
-template <bool WRANK, int GROUP_CAP = GKI_GROUP_CAP>
+template <bool WRANK, int GROUP_CAP = GKI_GROUP_CAP, int GROUP_THREADS = GKI_GROUP_THREADS>
 __global__ __launch_bounds__(GROUP_THREADS) void k_group_finish(FinishArgs a) {
     constexpr int NB = 1 << GROUP_LMAX, RI = GROUP_CAP / GROUP_THREADS, W = GROUP_THREADS / 64, SLICE = GROUP_CAP / W;
     constexpr int C = NB / GROUP_THREADS > 0 ? NB / GROUP_THREADS : 1;      // buckets per thread: b = i * THREADS + thread
@@ -746,7 +762,8 @@ __global__ __launch_bounds__(THREADS) void k_kmer_digit_hist(const uint64_t *__r
 #pragma unroll
     for (int r = 0; r < RI; r++) {
         const bool valid = r * THREADS + threadIdx.x < n_here;
-        const uint32_t key = valid ? key_of(rule, s_pb, km[r], &bad) : 0u;
+        uint32_t stored;
+        const uint32_t key = valid ? key_of(rule, s_pb, km[r], &bad, &stored) : 0u;
         tile_hist_add<THREADS>(h, (key >> shift) & mask, valid, bits);
     }
     if (bad) *out_of_range = 1;
@@ -796,12 +813,17 @@ __global__ __launch_bounds__(THREADS) void k_kmer_digit_hist(const uint64_t *__r
 // the ungrouped build needs two passes of 10 + 9 and 7 in LDS.
 int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
                          uint64_t modulo, uint64_t bucket_begin, uint64_t n_buckets, int skip_frequencies,
-                         int group_bits, const int64_t *h_group_start,
+                         int group_bits, const int64_t *h_group_start, const void *d_rows_in, const void *d_keys_in,
                          void *d_hashes_to_index, void *d_n_kmers, void *d_out_kmers, void *d_out_nodes,
                          void *d_out_ref_offsets, void *d_out_af32, void *d_out_frequencies, void *d_out_permutation, int *done) {
     constexpr int THREADS = GKI_PT_THREADS, RI = GKI_PT_RI, TILE = THREADS * RI;
     *done = 0;
     hipStream_t s = 0;
+    // d_rows_in / d_keys_in: the records arrive as 24-byte rows with their keys (gki_partition_rows_by_bucket_range) instead of
+    // as four columns: the first pass is then a pass like every other, or -- when the grouping left nothing to sort above the
+    // finish -- there is none
+    const bool from_rows = d_rows_in != nullptr;
+    if (from_rows && d_out_permutation) return gki_set_error(GKI_ERR_BAD_ARG, "a build from rows has no permutation to give");
     const int kb = key_bits(n_buckets - 1);
     const bool grouped = group_bits > 0;
     const int group_shift = grouped ? (kb > group_bits ? kb - group_bits : 0) : kb;     // key bits below the grouping
@@ -816,7 +838,7 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
     }
     const bool wrank = GKI_FINISH_WRANK < 0 ? density >= GKI_FINISH_WRANK_DENSITY : GKI_FINISH_WRANK != 0;
     const int top = group_shift > L ? group_shift - L : 0;    // bits the partition passes sort on
-    const int n_pass = top > 0 ? (top + MAXB_BITS - 1) / MAXB_BITS : 1;   // top == 0: one pass of one digit, which only packs the rows
+    const int n_pass = top > 0 ? (top + MAXB_BITS - 1) / MAXB_BITS : (from_rows ? 0 : 1);   // top == 0: one pass of one digit, which only packs the rows
     if (n_pass > 3) return GKI_OK;
     const int64_t n_groups = (int64_t)(((n_buckets - 1) >> L) + 1);
     // tiles: plain, or cut at the group bounds
@@ -863,7 +885,7 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
             HIP_G(gki_dev_malloc((void **)&d_tiles, h_tiles.size() * sizeof(TileDesc) + 32));
             HIP_G(hipMemcpyAsync(d_tiles, h_tiles.data(), h_tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, s));
         }
-        for (int i = 0; i < (n_pass > 1 ? 2 : 1); i++) {
+        for (int i = 0; i < (n_pass > 1 ? 2 : n_pass); i++) {
             HIP_G(gki_dev_malloc((void **)&rows[i], (size_t)n * 24));
             HIP_G(gki_dev_malloc((void **)&keys[i], (size_t)n * 4));
         }
@@ -877,8 +899,8 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
         HIP_G(hipMemsetAsync(gbegin, 0, (size_t)n_groups * 4, s));
         HIP_G(hipMemsetAsync(gend, 0, (size_t)n_groups * 4, s));
         // partition passes on the top bits, least significant digit first, each stable
-        const uint64_t *cur_rows = nullptr;
-        const uint32_t *cur_keys = nullptr;
+        const uint64_t *cur_rows = (const uint64_t *)d_rows_in;
+        const uint32_t *cur_keys = (const uint32_t *)d_keys_in;
         int shift = L;
         for (int p = 0; p < n_pass; p++) {
             const int bits = (top - (shift - L) + (n_pass - p) - 1) / (n_pass - p);       // remaining bits spread evenly (an odd bit
@@ -886,7 +908,7 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
             const int64_t bins_n = ((int64_t)1 << bits) * n_tiles;
             const int xcd_tiles = (int)ceil_div(n_tiles, 8);
             const unsigned xgrid = (unsigned)(xcd_tiles * 8);
-            if (p == 0)
+            if (p == 0 && !from_rows)
                 hipLaunchKernelGGL((k_kmer_digit_hist<THREADS, RI>), dim3(xgrid), dim3(THREADS), 0, s, (const uint64_t *)d_kmers,
                                    n, rule, shift, bits, hist, n_tiles, xcd_tiles, d_tiles, (int *)(stats + 3));
             else
@@ -903,13 +925,14 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
             a.rows_out = rows[p & 1]; a.keys_out = keys[p & 1];
             a.o_kmers = nullptr; a.o_nodes = nullptr; a.o_refs = nullptr; a.o_af = nullptr; a.dbase = nullptr;
             a.xcd_tiles = xcd_tiles;
-            if (p == 0) hipLaunchKernelGGL((k_partition_rows<THREADS, RI, true>), dim3(xgrid), dim3(THREADS), 0, s, a);
+            if (p == 0 && !from_rows) hipLaunchKernelGGL((k_partition_rows<THREADS, RI, true>), dim3(xgrid), dim3(THREADS), 0, s, a);
             else hipLaunchKernelGGL((k_partition_rows<THREADS, RI, false>), dim3(xgrid), dim3(THREADS), 0, s, a);
             HIP_G(hipGetLastError());
             cur_rows = a.rows_out; cur_keys = a.keys_out;
             shift += bits;
         }
-        hipLaunchKernelGGL(k_group_bounds, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s, cur_keys, n, L, gbegin, gend);
+        hipLaunchKernelGGL(k_group_bounds, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s, cur_keys, n, L, (uint32_t)n_buckets, gbegin, gend,
+                           (int *)(stats + 3));
         HIP_G(hipGetLastError());
         hipLaunchKernelGGL(k_group_scan, dim3(stream_grid(n_groups, 256)), dim3(256), 0, s, gbegin, gend, n_groups,
                            (uint32_t)cap, stats, large, large_cap);
@@ -928,8 +951,8 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
         f.o_perm = (uint32_t *)d_out_permutation; f.af_in = (const uint32_t *)d_af32;
         f.big_buckets = big; f.n_big = stats + 2; f.big_cap = big_cap;
         f.xcd_groups = (int)ceil_div(n_groups, 8);
-        if (grouped && wrank) hipLaunchKernelGGL((k_group_finish<true, GROUP_CAP_BIG>), dim3((unsigned)(f.xcd_groups * 8)), dim3(GROUP_THREADS), 0, s, f);
-        else if (grouped) hipLaunchKernelGGL((k_group_finish<false, GROUP_CAP_BIG>), dim3((unsigned)(f.xcd_groups * 8)), dim3(GROUP_THREADS), 0, s, f);
+        if (grouped && wrank) hipLaunchKernelGGL((k_group_finish<true, GROUP_CAP_BIG, GROUP_THREADS_BIG>), dim3((unsigned)(f.xcd_groups * 8)), dim3(GROUP_THREADS_BIG), 0, s, f);
+        else if (grouped) hipLaunchKernelGGL((k_group_finish<false, GROUP_CAP_BIG, GROUP_THREADS_BIG>), dim3((unsigned)(f.xcd_groups * 8)), dim3(GROUP_THREADS_BIG), 0, s, f);
         else if (wrank) hipLaunchKernelGGL((k_group_finish<true>), dim3((unsigned)(f.xcd_groups * 8)), dim3(GROUP_THREADS), 0, s, f);
         else hipLaunchKernelGGL((k_group_finish<false>), dim3((unsigned)(f.xcd_groups * 8)), dim3(GROUP_THREADS), 0, s, f);
         HIP_G(hipGetLastError());
@@ -1013,7 +1036,8 @@ __global__ __launch_bounds__(1024) void k_part_bases(ChunkOffs co, int n_digits,
 template <int THREADS>
 static int partition_columns_by_part(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
                                      uint64_t modulo, int n_parts, int sub_bits, int64_t max_rows_per_pass, void *d_out_kmers,
-                                     void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32, int64_t *h_part_start) {
+                                     void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32, void *d_out_rows, void *d_out_keys,
+                                     int64_t *h_part_start) {
     constexpr int RI = 8, TILE = THREADS * RI;
     hipStream_t s = 0;
     const int n_digits = n_parts << sub_bits;
@@ -1076,7 +1100,11 @@ static int partition_columns_by_part(const void *d_kmers, const void *d_nodes, c
             a.o_kmers = (uint64_t *)d_out_kmers; a.o_nodes = (uint32_t *)d_out_nodes; a.o_refs = (uint64_t *)d_out_ref_offsets;
             a.o_af = (uint32_t *)d_out_af32; a.dbase = dbase + (int64_t)c * bins; a.carry_index = 0;
             a.xcd_tiles = (int)ceil_div(a.n_tiles, 8);
-            hipLaunchKernelGGL((k_partition_rows<THREADS, RI, true, true>), dim3((unsigned)(a.xcd_tiles * 8)), dim3(THREADS), 0, s, a);
+            if (d_out_rows) {               // rows + keys out (the key: the bucket's offset in its part)
+                a.rows_out = (uint64_t *)d_out_rows; a.keys_out = (uint32_t *)d_out_keys;
+                hipLaunchKernelGGL((k_partition_rows<THREADS, RI, true, false>), dim3((unsigned)(a.xcd_tiles * 8)), dim3(THREADS), 0, s, a);
+            } else
+                hipLaunchKernelGGL((k_partition_rows<THREADS, RI, true, true>), dim3((unsigned)(a.xcd_tiles * 8)), dim3(THREADS), 0, s, a);
             HIP_G(hipGetLastError());
         }
         HIP_G(hipMemcpyAsync(h_part_start, pstart, (size_t)(n_digits + 1) * 8, hipMemcpyDeviceToHost, s));
@@ -1091,14 +1119,18 @@ done:
 }
 
 // sub_bits > 0: grouped -- part p's records leave grouped by the top sub_bits bits of (bucket - part_begin[p]); h_part_start has
-// (n_parts << sub_bits) + 1 entries, entry p << sub_bits | g = first row of group g of part p.  Up to 256 digits go through
-// 2048-row tiles (two workgroups per CU), more through 4096-row tiles (longer runs per digit).
+// (n_parts << sub_bits) + 1 entries, entry p << sub_bits | g = first row of group g of part p.  Columns out: up to 256 digits
+// go through 2048-row tiles (two workgroups per CU), more through 4096-row tiles.  Rows out (d_out_rows / d_out_keys instead of
+// the four columns: 24-byte rows and the bucket's offset in its part as the key): 4096-row tiles -- a run of four ROWS is
+// 96 + 16 contiguous bytes where four records of four columns are runs of 32, 32, 16 and 16 (1024 digits into columns: 98 ms per
+// 3.16e9 records, into rows 61).
 int gki_partition_columns_by_part(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
                                   uint64_t modulo, int n_parts, int sub_bits, int64_t max_rows_per_pass, void *d_out_kmers,
-                                  void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32, int64_t *h_part_start) {
-    if ((n_parts << sub_bits) <= MAX_PARTS)
+                                  void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32, void *d_out_rows, void *d_out_keys,
+                                  int64_t *h_part_start) {
+    if (!d_out_rows && (n_parts << sub_bits) <= MAX_PARTS)
         return partition_columns_by_part<GKI_PR_THREADS>(d_kmers, d_nodes, d_ref_offsets, d_af32, n, modulo, n_parts, sub_bits, max_rows_per_pass,
-                                                         d_out_kmers, d_out_nodes, d_out_ref_offsets, d_out_af32, h_part_start);
+                                                         d_out_kmers, d_out_nodes, d_out_ref_offsets, d_out_af32, nullptr, nullptr, h_part_start);
     return partition_columns_by_part<512>(d_kmers, d_nodes, d_ref_offsets, d_af32, n, modulo, n_parts, sub_bits, max_rows_per_pass,
-                                          d_out_kmers, d_out_nodes, d_out_ref_offsets, d_out_af32, h_part_start);
+                                          d_out_kmers, d_out_nodes, d_out_ref_offsets, d_out_af32, d_out_rows, d_out_keys, h_part_start);
 }

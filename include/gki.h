@@ -332,6 +332,22 @@ int gki_index_build_range_grouped(const void *d_kmers, const void *d_nodes, cons
                                   void *d_hashes_to_index, void *d_n_kmers,
                                   void *d_out_kmers, void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32,
                                   void *d_out_frequencies, void *d_out_permutation);
+/* The same pair with the partitioned records kept as ROWS between the two calls -- what the whole-genome index on one GPU
+ * uses (collision_free_kmer_index.PartitionedDeviceIndex): with hundreds of digits a run of a few records is one
+ * contiguous piece as rows and four short ones as columns.
+ * gki_partition_rows_by_bucket_range: d_rows uint64[3 * n] (per record: k-mer, ref offset, node | allele frequency bits
+ *   << 32), d_keys uint32[n] (the bucket's offset in its part), both device buffers of the caller; h_start as above.
+ * gki_index_build_range_from_rows: the slice build from one part's rows and keys (pointers into those buffers at the
+ *   part's first record, n = its records, h_group_start relative to it).  No permutation output.  A key outside
+ *   [0, n_buckets) is GKI_ERR_BAD_ARG. */
+int gki_partition_rows_by_bucket_range(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets,
+                                       const void *d_af32, int64_t n, uint64_t modulo, int n_parts, int group_bits,
+                                       int64_t max_rows_per_pass, void *d_rows, void *d_keys, int64_t *h_start);
+int gki_index_build_range_from_rows(const void *d_rows, const void *d_keys, int64_t n, uint64_t modulo,
+                                    uint64_t bucket_begin, uint64_t n_buckets, int skip_frequencies, int group_bits,
+                                    const int64_t *h_group_start, void *d_hashes_to_index, void *d_n_kmers,
+                                    void *d_out_kmers, void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32,
+                                    void *d_out_frequencies);
 /* The build has two forms with identical results.  gki_index_build(_range) runs the row-carrying form (the 24-byte
  * payload travels with its key through stable partition passes, the last bits are sorted inside LDS; no random access)
  * and hands over to the pair-sorting form (stable LSD sort of (bucket, index) pairs, then one gather of the payload)

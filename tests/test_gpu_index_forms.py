@@ -159,7 +159,8 @@ def test_grouped_partition_and_grouped_build_equal_the_oracle(n, modulo, n_parts
     (gki_partition_by_bucket_range_grouped) and the slice builds start from that grouping with one pass less
     (gki_index_build_range_grouped).  The partition must be the stable partition by (part, group); every slice must equal
     the oracle's stable build cut at the slice's bucket range, element by element."""
-    from graph_kmer_index_amd.collision_free_kmer_index import partition_by_bucket_range, PartitionedDeviceIndex
+    from graph_kmer_index_amd.collision_free_kmer_index import (partition_by_bucket_range, partition_rows_by_bucket_range,
+                                                                PartitionedDeviceIndex)
     kmers, nodes, refs, af = _records(n, n_distinct, seed=n + g)
     full = oracle.index_build(kmers, nodes, refs, af, modulo=modulo)
     buckets = kmers % np.uint64(modulo)
@@ -177,11 +178,19 @@ def test_grouped_partition_and_grouped_build_equal_the_oracle(n, modulo, n_parts
     for name, col in (("_hashes", kmers), ("_nodes", nodes), ("_ref_offsets", refs), ("_allele_frequencies", af)):
         assert np.array_equal(getattr(got, name), col[order]), name
     assert start == np.concatenate([[0], np.cumsum(np.bincount(digit, minlength=n_parts << g))]).tolist()
+    # the same partition with the records left as rows: row = (k-mer, ref offset, node | allele frequency bits << 32), key =
+    # the bucket's offset in its part
+    rows, start_r = partition_rows_by_bucket_range(d, modulo, n_parts, group_bits=g, max_rows_per_pass=150000)
+    assert start_r == start
+    r = rows.rows.to_host(3 * n).reshape(n, 3)
+    assert np.array_equal(r[:, 0], kmers[order]) and np.array_equal(r[:, 1], refs[order])
+    assert np.array_equal(r[:, 2], nodes[order].astype(np.uint64) | (af[order].view(np.uint32).astype(np.uint64) << np.uint64(32)))
+    assert np.array_equal(rows.keys.to_host(n), (buckets - begins[owner])[order].astype(np.uint32))
     sorted_buckets = np.sort(buckets, kind="stable")
     for p in range(n_parts):
         lo, hi = bucket_range(modulo, n_parts, p)
-        for skip in (False, True):
-            dev = PartitionedDeviceIndex.build_slice(part, start, modulo, n_parts, p, g, skip_frequencies=skip)
+        for skip, src in ((False, part), (True, part), (False, rows), (True, rows)):
+            dev = PartitionedDeviceIndex.build_slice(src, start, modulo, n_parts, p, g, skip_frequencies=skip)
             first = int(np.searchsorted(sorted_buckets, lo))
             m = dev.n
             assert m == int((owner == p).sum())
@@ -196,6 +205,17 @@ def test_grouped_partition_and_grouped_build_equal_the_oracle(n, modulo, n_parts
             assert np.array_equal(h2i[nk > 0], full["_hashes_to_index"][lo:hi][nk > 0] - first)
             assert not h2i[nk == 0].any()
             dev.free()
+    # rows without a grouping (group_bits = 0): the build from rows sorts everything itself
+    if n_parts > 1:
+        plain_rows, plain_start = partition_rows_by_bucket_range(d, modulo, n_parts)
+        dev = PartitionedDeviceIndex.build_slice(plain_rows, plain_start, modulo, n_parts, 1, 0)
+        lo, hi = bucket_range(modulo, n_parts, 1)
+        first = int(np.searchsorted(sorted_buckets, lo))
+        assert np.array_equal(dev.kmers.to_host(dev.n), full["_kmers"][first:first + dev.n])
+        assert np.array_equal(dev.frequencies.to_host(dev.n), full["_frequencies"][first:first + dev.n])
+        dev.free()
+        plain_rows.free()
+    rows.free()
     part.free()
     d.free()
 
