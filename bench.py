@@ -47,6 +47,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s
 XGMI_LINK_GBS = 153.0            # per direction and link (7 links per GPU, fully connected)
 BYTES_PER_RECORD = 25            # 1 B of node sequence read + 24 B FlatKmers row written
 PMC_FILE = "profiles/r03_pmc_3gbp.json"
+FULL_INDEX_GROUP_BITS = 0         # --full-index-group-bits
 
 
 def pmc_traffic(n_ref_bases, n_sites, k):
@@ -463,7 +464,7 @@ def full_index_record(lib, _lib, g, k, cp, out, max_variant_nodes, modulo, n_sli
     MASK = (1 << 64) - 1
     cols = ("hashes", "nodes", "ref_offsets", "allele_frequencies")
     W = n_slices
-    G = int(os.environ.get("GKI_BENCH_GROUP_BITS", "0"))     # > 0: the grouped flow (rows between partition and build)
+    G = FULL_INDEX_GROUP_BITS              # > 0: the grouped flow (rows between partition and build)
     kw = dict(only_save_one_node_per_kmer=True, max_variant_nodes=max_variant_nodes)
     from graph_kmer_index_amd import DenseKmerFinder
     finder = DenseKmerFinder(g, k, critical_graph_paths=cp, **kw)
@@ -730,11 +731,15 @@ def main():
     ap.add_argument("--reads", type=float, default=1e8, help="reads of the read_mapping record, BASELINE configs[4]: 1e8 "
                     "(0: skip the secondary records)")
     ap.add_argument("--no-full-index", action="store_true", help="skip the full_index record (N=1)")
+    ap.add_argument("--full-index-group-bits", type=int, default=0,
+                    help="full_index through the grouped flow: the partition also groups every slice by this many top key bits (7)")
     ap.add_argument("--no-sharded-build", action="store_true", help="skip the sharded_build record (N>1)")
     ap.add_argument("--sharded-build-budget", type=float, default=600.0, help="seconds the sharded_build record may take before "
                     "rank 0 prints the line without it")
     ap.add_argument("--modulo", type=int, default=452930477)
     args = ap.parse_args()
+    global FULL_INDEX_GROUP_BITS
+    FULL_INDEX_GROUP_BITS = args.full_index_group_bits
     if args.nested > 0:
         args.max_variant_nodes = max(args.max_variant_nodes, 8)
 

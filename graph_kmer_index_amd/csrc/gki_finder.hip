@@ -1470,6 +1470,11 @@ static int launch_interior(gki_finder *f, const DevGraph &d, const FindArgs &a, 
 template <int FMT>
 static int emit_impl(gki_finder *f, typename OutSel<FMT>::T out) {
     if (!f->counted) return gki_set_error(GKI_ERR_STATE, "gki_finder_emit_* called before gki_finder_count");
+    if (f->deep.cap > 0 && !f->deep.base) {                       // a second emit after one count: the arena again
+        const int64_t bytes = f->deep.lanes * (int64_t)f->deep.cap * DA_CELL;
+        HIP_TRY(gki_dev_malloc((void **)&f->deep.base, (size_t)bytes));
+        f->deep_bytes = bytes;
+    }
     const DevGraph &d = f->g->d;
     hipStream_t s = f->stream, s2 = f->stream2;
     const FindArgs a = f->args;
@@ -1640,7 +1645,9 @@ int gki_finder_count(gki_finder *f, const gki_find_params *p, int64_t *n_records
         if (p->d_lossy_crit) f->lossy_cur = p->d_lossy_crit;
         else HIP_TRY(hipMemcpyAsync(f->lossy, p->h_lossy_crit, (size_t)d.n_nodes * 2, hipMemcpyHostToDevice, s));
     }
-    f->deep.cap = 0;                  // the product kernels first; a window deeper than their stacks sends the pass round again
+    // the product kernels first; a window deeper than their stacks sends the pass round again.  The slow path's arena of an
+    // earlier run (up to 14 GB) went back to the pool when that run's emit completed (gki_finder_synchronize).
+    f->deep.cap = 0;
     int64_t *tot = f->h_totals;       // pinned host memory: the two small copies are true async DMAs
     unsigned long long bsum = 0;
     for (;;) {
@@ -1768,6 +1775,10 @@ int gki_finder_emit_v2(gki_finder *f, void *d_hashes, void *d_start_nodes, void 
 int gki_finder_synchronize(gki_finder *f) {
     HIP_TRY(hipStreamSynchronize(f->stream));
     HIP_TRY(hipStreamSynchronize(f->stream2));
+    if (f->deep.base) {                                           // the emit kernels are done with the slow path's stacks
+        (void)gki_dev_free(f->deep.base);
+        f->deep.base = nullptr; f->deep_bytes = 0;                // (cap stays: a second emit of this run allocates them again)
+    }
     if (f->emit_pending) {
         f->emit_pending = false;
         const int64_t word = f->h_totals[5] & 0xFFFFFFFFll;

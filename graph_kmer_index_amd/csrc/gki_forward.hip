@@ -45,9 +45,6 @@ __device__ __forceinline__ void put_record(const FwdOut &out, int64_t idx, uint6
 #ifndef GKI_FWD_SCRIPT
 #define GKI_FWD_SCRIPT 1
 #endif
-#ifndef GKI_FWD_EARLY_EDGES
-#define GKI_FWD_EARLY_EDGES 0
-#endif
 constexpr int FW_SLOTS = 4, FW_SN = 5, FW_ENTRY_U4 = 3;
 __device__ __forceinline__ void script_write(uint4 *e, uint64_t h, double maf, int32_t q, int off, int lw, uint32_t first, const int32_t *nodes) {
     const uint64_t mb = (uint64_t)__double_as_longlong(maf);
@@ -176,11 +173,6 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
             { const int32_t cj = cur[j]; q = g.edges[cj]; cur[j] = cj + 1; }
         }
         const NodeWalk wq = g.walk[q];
-#if GKI_FWD_EARLY_EDGES
-        // q's successor range asked for together with its record (both need only q) instead of behind the "first k-mer
-        // finished?" branch: three dependent round trips per descent instead of four.  Off: not measured yet.
-        const int32_t q_e0 = (int32_t)g.edge_start[q], q_e1 = (int32_t)g.edge_start[q + 1];
-#endif
         if (forced[j]) {
         } else if (vc[j] >= M && !wq.is_ref) {
             continue;                                                   // :397-403 only the linear-ref successor
@@ -249,11 +241,9 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
             count += one_node ? 1u : (uint32_t)Lw;
             continue;
         }
-#if GKI_FWD_EARLY_EDGES
-        cur[L] = q_e0; end[L] = q_e1;
-#else
+        // (q's successor range asked for together with its record, ahead of the "first k-mer finished?" branch -- three
+        // dependent round trips per descent instead of four -- measured no different: profiles/r04_forward_early_edges_ab.txt)
         cur[L] = (int32_t)g.edge_start[q]; end[L] = (int32_t)g.edge_start[q + 1];
-#endif
         forced[L] = any_followed(g, follow, q) ? 1 : 0;
         last[L] = INT_MIN;
         if (!EMIT && !forced[L] && vc[L] >= M) check_one_ref_successor(g, q, err);
