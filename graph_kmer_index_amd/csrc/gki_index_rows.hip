@@ -65,6 +65,7 @@ struct KeyRule {
     GkiMod mod;
     uint64_t bucket_begin, n_buckets;       // build: key = kmer % modulo - bucket_begin, must be < n_buckets
     int n_parts;                            // > 0: key = owning part; part_begin[n_parts + 1] on the device
+    float parts_per_bucket;                 //   n_parts / modulo: the part of bucket b is b * this, give or take one
     int sub_bits;                           // > 0 (with parts): key = part << sub_bits | the top sub_bits bits of the bucket's
     const uint32_t *part_begin;             //   offset in its part, i.e. (bucket - part_begin[part]) >> sub_shift[part]
     const uint32_t *sub_shift;              //   [n_parts] on the device
@@ -85,8 +86,9 @@ __device__ __forceinline__ void stage_parts(const KeyRule &k, uint32_t *s_pb) {
 __device__ __forceinline__ uint32_t key_of(const KeyRule &k, const uint32_t *s_pb, uint64_t kmer, bool *bad, uint32_t *stored) {
     const uint64_t b = gki_mod(k.mod, kmer);                            // collision_free_kmer_index.py:433
     if (k.n_parts > 0) {
-        int p = (int)__umul64hi(b * (uint64_t)k.n_parts, k.mod.inv);    // floor(b * n_parts / modulo), or one or two short
-        while (p + 1 < k.n_parts && s_pb[p + 1] <= (uint32_t)b) p++;
+        int p = (int)((float)(uint32_t)b * k.parts_per_bucket);         // floor(b * n_parts / modulo), give or take one (24-bit
+        p = p < k.n_parts ? p : k.n_parts - 1;                          // mantissa: three instructions where the exact quotient
+        while (p + 1 < k.n_parts && s_pb[p + 1] <= (uint32_t)b) p++;    // by multiply-high took sixteen)
         while (p > 0 && s_pb[p] > (uint32_t)b) p--;
         *stored = (uint32_t)b - s_pb[p];
         if (k.sub_bits > 0) return ((uint32_t)p << k.sub_bits) | (*stored >> s_pb[MAX_PARTS + 1 + p]);
@@ -131,17 +133,22 @@ __device__ __forceinline__ int64_t tile_of_block(int64_t n_tiles, int xcd_tiles)
 // first output row).  Blocks take their tiles XCD-major like the partition kernel: a digit's entries of consecutive tiles
 // share 32-byte sectors, and with tiles dealt round-robin over the eight XCDs every sector was written 4 bytes at a time
 // through eight L2s that do not merge each other's partial lines.
-// Few digits (the bucket-range partition: <= 16 parts): counted by ballots, one add per wave and digit -- LDS atomics of
-// 4096 rows on 8 addresses serialise.
-template <int THREADS>
-__device__ __forceinline__ void tile_hist_add(uint32_t *h, uint32_t dig, bool valid, int bits) {
-    if (bits <= 4) {
-        const int lane = threadIdx.x & 63;
-        for (int d = 0; d < (1 << bits); d++) {
-            const uint32_t c = (uint32_t)__popcll(__ballot(valid && dig == (uint32_t)d));
-            if (lane == 0 && c) atomicAdd(&h[d], c);
-        }
-    } else if (valid) atomicAdd(&h[dig], 1u);
+// Few digits (the bucket-range partition: <= 16 parts): every lane counts its own records in packed 8-bit counters (a shift
+// and an add per record), the wave sums a digit's counters by a DPP scan, one LDS add per wave and digit -- LDS atomics of
+// 4096 rows on 8 addresses serialise, and a ballot per record and digit is 48 instructions per record (the histogram of
+// the 3.16e9-record partition ran at 1.6 TB/s: ALU-bound).  RI <= 255.
+struct FewDigits { uint64_t lo, hi; };                // digits 0-7, 8-15
+__device__ __forceinline__ void few_add(FewDigits &c, uint32_t dig, bool valid) {
+    const uint64_t one = valid ? 1ull << ((dig & 7u) * 8u) : 0ull;
+    if (dig & 8u) c.hi += one; else c.lo += one;
+}
+__device__ __forceinline__ void few_flush(const FewDigits &c, uint32_t *h, int bins) {
+    const int lane = threadIdx.x & 63;
+    for (int d = 0; d < bins; d++) {
+        const uint32_t v = (uint32_t)(((d & 8) ? c.hi : c.lo) >> ((d & 7) * 8)) & 0xFFu;
+        const uint32_t tot = (uint32_t)gki_lane_value((int)gki_wave_incl_sum(v), 63);
+        if (lane == 0 && tot) atomicAdd(&h[d], tot);
+    }
 }
 
 template <int THREADS, int RI>
@@ -164,8 +171,15 @@ __global__ __launch_bounds__(THREADS) void k_digit_hist(const uint32_t *__restri
         const int e = r * THREADS + threadIdx.x;
         key[r] = e < n_here ? keys[base + e] : 0u;
     }
+    if (bits <= 4) {
+        FewDigits c = {0ull, 0ull};
 #pragma unroll
-    for (int r = 0; r < RI; r++) tile_hist_add<THREADS>(h, (key[r] >> shift) & mask, r * THREADS + threadIdx.x < n_here, bits);
+        for (int r = 0; r < RI; r++) few_add(c, (key[r] >> shift) & mask, r * THREADS + threadIdx.x < n_here);
+        few_flush(c, h, bins);
+    } else {
+#pragma unroll
+        for (int r = 0; r < RI; r++) if (r * THREADS + threadIdx.x < n_here) atomicAdd(&h[(key[r] >> shift) & mask], 1u);
+    }
     __syncthreads();
     for (int d = threadIdx.x; d < bins; d += THREADS) hist[obase + (int64_t)d * ostride] = h[d];
 }
@@ -219,7 +233,9 @@ __global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
     __shared__ __attribute__((aligned(16))) uint64_t s_rows[TILE * 3];
     __shared__ uint32_t s_keys[TILE];
     __shared__ uint16_t s_dest[SRC_COLS ? 1 : TILE];
-    __shared__ uint16_t s_wcnt[W][MAXB];
+    // the per-wave digit counts live under the staging rows: dead (a barrier ago) before the first payload word lands
+    static_assert((size_t)TILE * 24 >= (size_t)W * MAXB * 2, "the per-wave digit counts fit under the rows");
+    uint16_t (*const s_wcnt)[MAXB] = reinterpret_cast<uint16_t (*)[MAXB]>(s_rows);     // [W][MAXB]
     __shared__ uint32_t s_dstart[MAXB];
     __shared__ uint32_t s_toff[MAXB];
     __shared__ uint32_t s_scan[W + 1];
@@ -268,7 +284,7 @@ __global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
             w2[r] = j + 2 * TILE < 3 * n_here ? src[j + 2 * TILE] : 0ull;
         }
     }
-    for (int d = threadIdx.x; d < W * MAXB; d += THREADS) (&s_wcnt[0][0])[d] = 0;
+    for (int d = threadIdx.x; d < W * MAXB / 2; d += THREADS) reinterpret_cast<uint32_t *>(s_rows)[d] = 0;          // s_wcnt
     __syncthreads();
     if (SRC_COLS) {
         bool bad = false;                                       // (the histogram kernel has reported it)
@@ -318,16 +334,24 @@ __global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
     __syncthreads();
 
     // (4) destination slot of every row of the tile; (5) payload words into their rows' slots
+    uint32_t slot[RI];
 #pragma unroll
     for (int r = 0; r < RI; r++) {
+        slot[r] = 0;
         if (valid[r]) {
-            const uint32_t slot = s_dstart[dig[r]] + s_wcnt[wave][dig[r]] + rank[r];
-            s_keys[slot] = key[r];
-            if (SRC_COLS) { s_dig[slot] = (uint16_t)dig[r]; s_rows[slot * 3 + 0] = w0[r]; s_rows[slot * 3 + 1] = w1[r]; s_rows[slot * 3 + 2] = w2[r]; }
-            else s_dest[wave * SLICE + r * 64 + lane] = (uint16_t)slot;
+            slot[r] = s_dstart[dig[r]] + s_wcnt[wave][dig[r]] + rank[r];
+            s_keys[slot[r]] = key[r];
+            if (SRC_COLS) s_dig[slot[r]] = (uint16_t)dig[r];
+            else s_dest[wave * SLICE + r * 64 + lane] = (uint16_t)slot[r];
         }
     }
-    __syncthreads();
+    __syncthreads();                                            // (the digit counts under s_rows are dead from here on)
+    if (SRC_COLS) {
+#pragma unroll
+        for (int r = 0; r < RI; r++)
+            if (valid[r]) { s_rows[slot[r] * 3 + 0] = w0[r]; s_rows[slot[r] * 3 + 1] = w1[r]; s_rows[slot[r] * 3 + 2] = w2[r]; }
+        __syncthreads();
+    }
     if (!SRC_COLS) {
 #pragma unroll
         for (int r = 0; r < RI; r++) {
@@ -759,13 +783,16 @@ __global__ __launch_bounds__(THREADS) void k_kmer_digit_hist(const uint64_t *__r
         km[r] = e < n_here ? kmers[base + e] : 0ull;
     }
     bool bad = false;
+    FewDigits c = {0ull, 0ull};
 #pragma unroll
     for (int r = 0; r < RI; r++) {
         const bool valid = r * THREADS + threadIdx.x < n_here;
         uint32_t stored;
         const uint32_t key = valid ? key_of(rule, s_pb, km[r], &bad, &stored) : 0u;
-        tile_hist_add<THREADS>(h, (key >> shift) & mask, valid, bits);
+        if (bits <= 4) few_add(c, (key >> shift) & mask, valid);
+        else if (valid) atomicAdd(&h[(key >> shift) & mask], 1u);
     }
+    if (bits <= 4) few_flush(c, h, bins);
     if (bad) *out_of_range = 1;
     __syncthreads();
     for (int d = threadIdx.x; d < bins; d += THREADS) hist[obase + (int64_t)d * ostride] = h[d];
@@ -875,7 +902,7 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
     TileDesc *d_tiles = nullptr;
     KeyRule rule;
     rule.mod = gki_mod_of(modulo); rule.bucket_begin = bucket_begin; rule.n_buckets = n_buckets; rule.n_parts = 0; rule.sub_bits = 0;
-    rule.part_begin = nullptr; rule.sub_shift = nullptr;
+    rule.part_begin = nullptr; rule.sub_shift = nullptr; rule.parts_per_bucket = 0.f;
     int rc = GKI_OK;
 #define HIP_G(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = gki_set_error(GKI_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); goto done; } } while (0)
     {
@@ -1062,6 +1089,7 @@ static int partition_columns_by_part(const void *d_kmers, const void *d_nodes, c
     co.n_chunks = n_chunks;
     KeyRule rule;
     rule.mod = gki_mod_of(modulo); rule.bucket_begin = 0; rule.n_buckets = modulo; rule.n_parts = n_parts; rule.sub_bits = sub_bits;
+    rule.parts_per_bucket = (float)((double)n_parts / (double)modulo);
     int rc = GKI_OK;
 #define HIP_G(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = gki_set_error(GKI_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); goto done; } } while (0)
     {

@@ -321,3 +321,66 @@ def test_assertion_after_a_lossy_restart():
         g = GraphArrays.from_dicts(seqs, edges, lin, af)
         seen[run_case(g, int(rng.integers(3, 24)), int(rng.choice([1, 2, 3, 4])), bool(rng.integers(0, 2)))] += 1
     assert seen["ok"] > 30 and seen["assert"] > 30, seen
+
+
+def test_host_and_device_forms_of_the_per_run_tables_agree():
+    """gki_find_params takes the four per-run tables (lossy restarts, topological ranks, node flags, only_store_nodes) as
+    host arrays, uploaded by every count, or as device pointers (what the Python finder hands in since round 4, uploaded
+    once): chunked runs over nested graphs with a store filter and shuffled node ids give the same counts and the same
+    records either way, and a finder's second count uploads nothing new."""
+    import ctypes as C
+    lib = _lib.load()
+
+    def emit_flat(f, n):
+        cols = [_lib.DeviceArray(max(n, 1), dt) for dt in (np.uint64, np.uint32, np.uint64, np.float32)]
+        _lib.check(lib.gki_finder_emit_flat(f._finder_handle(), *[c.ptr for c in cols]))
+        _lib.check(lib.gki_finder_synchronize(f._finder_handle()))
+        return [c.to_host(n) for c in cols]
+
+    rng = np.random.default_rng(404)
+    n_cases = 0
+    for i in range(40):
+        seqs, edges, lin, af = nested_bubble_graph(rng, n_var=int(rng.integers(3, 9)), min_ref=1, max_ref=12, p_nest=0.6, p_chain=0.3)
+        if i % 2:                                            # node ids that do not grow along the edges: the rank table
+            ids = sorted(seqs)
+            perm = dict(zip(ids, rng.permutation(ids).tolist()))
+            seqs = {perm[a]: b for a, b in seqs.items()}
+            edges = {perm[a]: [perm[x] for x in b] for a, b in edges.items()}
+            lin = [perm[a] for a in lin]
+        g = GraphArrays.from_dicts(seqs, edges, lin)
+        k = int(rng.integers(3, 8))
+        try:
+            cp = CriticalGraphPaths.from_graph(g, k)
+        except Exception:
+            continue
+        if len(cp.nodes) < 3:
+            continue
+        store = set(rng.choice(sorted(seqs), size=max(1, len(seqs) // 2), replace=False).tolist()) if i % 3 == 0 else None
+        a, b = 1, len(cp.nodes) - 1
+        try:
+            f = DenseKmerFinder(g, k, critical_graph_paths=cp, max_variant_nodes=int(rng.integers(1, 5)), only_store_nodes=store,
+                                start_at_critical_path_number=a, stop_at_critical_path_number=b)
+            p = f._params()
+        except (ValueError, AssertionError, RecursionError):
+            continue
+        if p is None:
+            continue
+        lossy, rank, flags, st = p._keep[:4]
+        n_dev, n_host = C.c_int64(0), C.c_int64(0)
+        rc_dev = _lib.load().gki_finder_count(f._finder_handle(), C.byref(p), C.byref(n_dev))
+        cols_dev = emit_flat(f, n_dev.value) if rc_dev == 0 else None
+        general = bool(p.d_node_flags)
+        q = _lib.FindParams(p.k, p.max_variant_nodes, p.one_node_per_kmer, p.layout, p.node_begin, p.off_begin, p.node_end, p.off_end,
+                            _lib.hptr(lossy), _lib.hptr(rank), _lib.hptr(flags) if general else None, _lib.hptr(st))
+        rc_host = _lib.load().gki_finder_count(f._finder_handle(), C.byref(q), C.byref(n_host))
+        assert rc_dev == rc_host and n_dev.value == n_host.value, (i, rc_dev, rc_host)
+        if rc_host == 0:
+            cols_host = emit_flat(f, n_host.value)
+            for x, y in zip(cols_dev, cols_host):
+                assert np.array_equal(x, y)
+            n_cases += 1
+        tables = dict(f.__dict__.get("_resident_tables", {}))
+        f._params_cache = None
+        f._params()                                           # the same chunk again: the same device copies
+        assert {k_: id(v[1]) for k_, v in f.__dict__.get("_resident_tables", {}).items()} == {k_: id(v[1]) for k_, v in tables.items()}
+    assert n_cases >= 10
