@@ -46,14 +46,14 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 XGMI_LINK_GBS = 153.0            # per direction and link (7 links per GPU, fully connected)
 BYTES_PER_RECORD = 25            # 1 B of node sequence read + 24 B FlatKmers row written
-PMC_FILE = "profiles/r03_pmc_3gbp.json"
+PMC_FILE = "profiles/r04_pmc_3gbp.json"
 FULL_INDEX_GROUP_BITS = 0         # --full-index-group-bits
 
 
 def pmc_traffic(n_ref_bases, n_sites, k):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (collected with
     tools/collect_pmc.sh on the same workload; counters cannot be read from inside this process)."""
-    for name in (PMC_FILE, "profiles/r02_final_pmc_3gbp.json"):
+    for name in (PMC_FILE, "profiles/r03_pmc_3gbp.json"):
         try:
             with open(os.path.join(ROOT, name)) as fh:
                 d = json.load(fh)
@@ -885,6 +885,9 @@ def main():
                 res["value_hashed_and_indexed"] = fi["records_per_s"]
                 res["hashed_and_indexed_roofline_frac"] = fi["roofline"]["frac"]
         res["cpu_baseline"] = cpu
+        res["cpu_baselines_note"] = ("`cpu_baseline` (beside `value`) is the oracle on ALL host cores (`cores` in the object); the "
+                                     "`cpu_baseline` objects inside index_build / read_mapping / early_stop_search are the oracle on "
+                                     "ONE core: compare ratios across records only after scaling by `cores`")
     if world > 1 and plain and not args.no_sharded_build:
         # The exchange has never run between real GPUs (one GPU per builder box): if a rank fails or a collective never
         # returns, the headline line must still come out.  A watchdog prints it (rank 0) and ends the rank.
