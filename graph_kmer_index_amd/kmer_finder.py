@@ -90,13 +90,15 @@ def classify_nodes(g, k, max_variant_nodes, only_follow_nodes=None, critical_nod
 
 def _resident(owner, table):
     """The device copy of a host table, uploaded once per (owner, table object): `owner` (a graph or a finder) keeps the
-    last few, each together with the host array it mirrors (so that the identity stays valid)."""
+    last few, each together with the host array it mirrors (so that the identity stays valid).  A copy that falls out of
+    the cache is NOT freed here: run parameters that still point at it hold a reference (`FindParams._keep`), and the
+    buffer goes back to the pool with the last of them."""
     _lib.require_device()
     cache = owner.__dict__.setdefault("_resident_tables", {})
     hit = cache.get(id(table))
     if hit is None or hit[0] is not table:
         if len(cache) >= 6:
-            cache.pop(next(iter(cache)))[1].free()
+            cache.pop(next(iter(cache)))
         hit = cache[id(table)] = (table, _lib.DeviceArray.from_host(np.ascontiguousarray(table)))
     return hit[1]
 

@@ -113,3 +113,28 @@ def test_forward_search_kernel_runs_at_full_occupancy(forward_asm):
         if name.split("(")[0].startswith("k_forward<") and name.split("(")[0].split(",")[1].strip() == "true":
             continue                  # the slow path
         assert not re.findall(r"\n\s*flat_(load|store|atomic)", body), name
+
+
+@pytest.fixture(scope="module")
+def index_rows_asm(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("codegen_ix") / "gki_index_rows.s")
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "--cuda-device-only", "-S",
+                    os.path.join(CSRC, "gki_index_rows.hip"), "-o", out], check=True, stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def test_footprints_of_the_index_build_kernels(index_rows_asm):
+    """the finish runs four workgroups of 512 threads per CU (<= 40 KB of LDS, <= 64 VGPRs), the bucket-range
+    partition two workgroups of 256 threads on 2048-row tiles (<= 80 KB), the build's passes one workgroup on a 4096-row
+    tile (<= 160 KB), the 4096-row finish of the grouped build sixteen waves (<= 128 VGPRs); nothing spills."""
+    r = _resources(index_rows_asm)
+    assert all(v["scratch"] == 0 for v in r.values()), {k: v["scratch"] for k, v in r.items() if v["scratch"]}
+    for name in ("k_group_finish<true, 1024, 512>", "k_group_finish<false, 1024, 512>"):
+        assert r[name]["lds"] <= 40960 and r[name]["vgpr"] <= 64, (name, r[name])
+    for name in ("k_group_finish<true, 4096, 1024>", "k_group_finish<false, 4096, 1024>"):
+        assert r[name]["lds"] <= 163840 and r[name]["vgpr"] <= 128, (name, r[name])
+    assert r["k_partition_rows<256, 8, true, true>"]["lds"] <= 81920 and r["k_partition_rows<256, 8, true, true>"]["vgpr"] <= 128
+    for name in ("k_partition_rows<512, 8, true, false>", "k_partition_rows<512, 8, false, false>", "k_partition_rows<512, 8, true, true>"):
+        assert r[name]["lds"] <= 163840 and r[name]["vgpr"] <= 256, (name, r[name])
+    for name in ("k_kmer_digit_hist<512, 8>", "k_kmer_digit_hist<256, 8>", "k_digit_hist<512, 8>"):
+        assert r[name]["vgpr"] <= 64 and r[name]["lds"] <= 16384, (name, r[name])      # 8 waves per SIMD; the LDS leaves the thread limit (4 x 512) in charge
