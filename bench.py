@@ -66,6 +66,19 @@ def pmc_traffic(n_ref_bases, n_sites, k):
     return None, None
 
 
+def pmc_index_traffic(shape, n):
+    """HBM bytes per build of the index kernels from the committed PMC summary (tools/collect_pmc_index.sh, random records
+    of the same shape: `sparse` = the variant index, `dense` = one slice of the whole-genome index), or (None, None)."""
+    try:
+        with open(os.path.join(ROOT, "profiles/r04_pmc_index.json")) as fh:
+            d = json.load(fh)
+        if abs(d[shape]["records"] - n) > 0.02 * n:
+            return None, None
+        return d[shape]["traffic_bytes_per_build"], "profiles/r04_pmc_index.json @ %s (%s, %d random records)" % (d.get("commit"), shape, d[shape]["records"])
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def index_roofline(n, n_buckets, nonempty, seconds, hashing, passes=1):
     """SURVEY.md 8(d)'s ALGORITHMIC bytes of the index build: every 24-byte row read and written once per sort pass (the
     lower bound is one pass; the implementation's count is stated beside it), the frequency column 2 B per record, the
@@ -352,7 +365,8 @@ def secondary_records(lib, _lib, g, k, cp, finder, out, n_reads, cpu2, max_varia
                    "form": "row-carrying: 2 stable partition passes (10 + 9 bits) + in-LDS finish on 10 bits",
                    "frequencies": True, "bytes_moved_model": int(moved), "bytes_per_record_model": per_record,
                    "achieved_GBps": moved / dt / 1e9, "frac_of_hbm_peak": moved / dt / 1e9 / HBM_PEAK_GBS,
-                   "roofline": index_roofline(nb, modulo, nonempty, dt, hashing=False),
+                   "roofline": dict(index_roofline(nb, modulo, nonempty, dt, hashing=False),
+                                    **dict(zip(("traffic", "traffic_source"), pmc_index_traffic("sparse", nb)))),
                    "timed": "wall clock around DeviceIndex.build incl. its allocations, device synchronised",
                    "ms_in_device_allocator": (pool1[2] - pool0[2]) + (pool1[3] - pool0[3]),
                    "cpu_baseline": cpu2.get("index_build")}

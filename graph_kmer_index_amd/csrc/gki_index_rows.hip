@@ -409,6 +409,175 @@ __global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
     }
 }
 
+// The same pass with the sorted tile staged through LDS in NCH parts: the keys of the whole tile are ranked at once (every
+// row knows its slot in the sorted tile and its output row), the payload waits in registers and goes through a staging
+// buffer of TILE / NCH rows, one slot range of the sorted tile after the other.  LDS per workgroup drops from 131-141 KB to
+// 64-72 KB: TWO workgroups of 4096-row tiles per CU, one loading while the other stores, with the runs of a 4096-row tile
+// (2048-row tiles bought the overlap with runs half as long: no gain, profiles/r03_index_tile_ab.txt; 8192-row tiles staged
+// in four parts bought longer runs without the overlap: -2 %, profiles/r04_partition_staged_tile_ab.txt).  The ranking
+// scratch (per-wave digit counts, digit starts, run offsets) lives under the staging buffer: dead before the first payload
+// word lands.  The build's passes since round 4 (GKI_PT_NCH); -DGKI_PT_NCH=1 rebuilds the one-workgroup kernel.
+template <int THREADS, int RI, bool SRC_COLS, int NCH>
+__global__ __launch_bounds__(THREADS, 4) void k_partition_rows_staged(PartArgs a) {
+    constexpr int TILE = THREADS * RI, W = THREADS / 64, SLICE = TILE / W, CH = TILE / NCH;
+    static_assert(TILE % NCH == 0 && (3 * RI) % NCH == 0 && TILE <= 65536, "slots are 16-bit; a part is a whole number of words per thread");
+    static_assert((size_t)CH * 24 >= (size_t)W * MAXB * 2 + (size_t)MAXB * 8, "the ranking scratch fits under the staging buffer");
+    __shared__ __attribute__((aligned(16))) uint64_t s_rows[CH * 3];
+    __shared__ uint32_t s_keys[TILE];             // by slot
+    __shared__ uint32_t s_out[TILE];              // by slot: the row of the output the slot goes to
+    __shared__ uint16_t s_dest[SRC_COLS ? 1 : TILE];   // by position: the row's slot
+    __shared__ uint32_t s_scan[W + 1];
+    __shared__ uint32_t s_pb[SRC_COLS ? PB_WORDS : 1];
+    uint16_t (*const s_wcnt)[MAXB] = reinterpret_cast<uint16_t (*)[MAXB]>(s_rows);                  // [W][MAXB]
+    uint32_t *const s_dstart = reinterpret_cast<uint32_t *>(s_rows) + (size_t)W * MAXB / 2;        // [MAXB]
+    uint32_t *const s_toff = s_dstart + MAXB;                                                       // [MAXB]
+    const int64_t tile = tile_of_block(a.n_tiles, a.xcd_tiles);
+    if (tile >= a.n_tiles) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bins = 1 << a.bits;
+    const uint32_t mask = (uint32_t)bins - 1u;
+    int64_t tile_base = tile * TILE, obase = tile, ostride = a.n_tiles;
+    int n_here = (int)((a.n - tile_base) < TILE ? (a.n - tile_base) : TILE);
+    if (a.tiles) { const TileDesc td = a.tiles[tile]; tile_base = td.row0; n_here = td.n; obase = td.tiles_before * bins + td.t; ostride = td.stride; }
+
+    // (1) everything from global memory, issued up front
+    uint32_t key[RI], dig[RI];
+    bool valid[RI];
+    uint64_t w0[RI], w1[RI], w2[RI];
+    if (SRC_COLS) {
+#pragma unroll
+        for (int r = 0; r < RI; r++) {
+            const int e = wave * SLICE + r * 64 + lane;
+            valid[r] = e < n_here;
+            w0[r] = valid[r] ? a.c_kmers[tile_base + e] : 0ull;
+            w1[r] = valid[r] ? a.c_refs[tile_base + e] : 0ull;
+            w2[r] = valid[r] ? ((uint64_t)a.c_nodes[tile_base + e] |
+                                ((uint64_t)(a.carry_index ? (uint32_t)(tile_base + e) : a.c_af[tile_base + e]) << 32)) : 0ull;
+        }
+        stage_parts(a.rule, s_pb);
+    } else {
+#pragma unroll
+        for (int r = 0; r < RI; r++) {
+            const int e = wave * SLICE + r * 64 + lane;
+            valid[r] = e < n_here;
+            key[r] = valid[r] ? a.keys_in[tile_base + e] : 0u;
+            dig[r] = valid[r] ? ((key[r] >> a.shift) & mask) : 0u;
+        }
+        const uint64_t *src = a.rows_in + tile_base * 3;
+#pragma unroll
+        for (int r = 0; r < RI; r++) {
+            const int j = r * THREADS + threadIdx.x;            // word j of the tile's 3 * n_here words
+            w0[r] = j < 3 * n_here ? src[j] : 0ull;
+            w1[r] = j + TILE < 3 * n_here ? src[j + TILE] : 0ull;
+            w2[r] = j + 2 * TILE < 3 * n_here ? src[j + 2 * TILE] : 0ull;
+        }
+    }
+    for (int d = threadIdx.x; d < W * MAXB / 2; d += THREADS) reinterpret_cast<uint32_t *>(s_rows)[d] = 0;      // s_wcnt
+    __syncthreads();
+    if (SRC_COLS) {
+        bool bad = false;                                       // (the histogram kernel has reported it)
+#pragma unroll
+        for (int r = 0; r < RI; r++) {
+            key[r] = 0u;
+            const uint32_t sort_key = valid[r] ? key_of(a.rule, s_pb, w0[r], &bad, &key[r]) : 0u;
+            dig[r] = (sort_key >> a.shift) & mask;
+        }
+    }
+    // (2) ranks inside the wave, digit counts per wave
+    uint32_t rank[RI];
+    wave_rank<RI>(dig, valid, a.bits, s_wcnt[wave], rank);
+    __syncthreads();
+    // (3) per digit: exclusive offsets over the waves, the digit's start in the sorted tile, and where its run goes
+    {
+        constexpr int C = MAXB / THREADS > 0 ? MAXB / THREADS : 1;      // digits per thread
+        uint32_t tot[C], sum = 0;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int d = threadIdx.x * C + c;
+            tot[c] = 0;
+            if (d < bins) {
+                uint32_t run = 0;
+#pragma unroll
+                for (int w = 0; w < W; w++) { const uint32_t x = s_wcnt[w][d]; s_wcnt[w][d] = (uint16_t)run; run += x; }
+                tot[c] = run;
+            }
+            sum += tot[c];
+        }
+        uint32_t total;
+        uint32_t ex = block_excl<THREADS>(sum, s_scan, &total);
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int d = threadIdx.x * C + c;
+            if (d < bins) {
+                s_dstart[d] = ex;
+                s_toff[d] = a.offs[obase + (int64_t)d * ostride] - ex;
+                ex += tot[c];
+            }
+        }
+    }
+    __syncthreads();
+    // (4) slot and output row of every row of the tile
+    uint32_t slot[RI];
+#pragma unroll
+    for (int r = 0; r < RI; r++) {
+        slot[r] = 0xFFFFFFFFu;
+        if (valid[r]) {
+            slot[r] = s_dstart[dig[r]] + s_wcnt[wave][dig[r]] + rank[r];
+            s_keys[slot[r]] = key[r];
+            s_out[slot[r]] = s_toff[dig[r]] + slot[r];
+            if (!SRC_COLS) s_dest[wave * SLICE + r * 64 + lane] = (uint16_t)slot[r];
+        }
+    }
+    __syncthreads();                                            // the ranking scratch is dead from here on
+    // the staging-buffer word of every payload word this thread holds (by position), 0xFFFFFFFF: none
+    uint32_t ws0[SRC_COLS ? 1 : RI], ws1[SRC_COLS ? 1 : RI], ws2[SRC_COLS ? 1 : RI];
+    if (!SRC_COLS) {
+#pragma unroll
+        for (int r = 0; r < RI; r++) {
+            const int j0 = r * THREADS + threadIdx.x, j1 = j0 + TILE, j2 = j0 + 2 * TILE;
+            ws0[r] = j0 < 3 * n_here ? (uint32_t)s_dest[j0 / 3] * 3u + (uint32_t)(j0 % 3) : 0xFFFFFFFFu;
+            ws1[r] = j1 < 3 * n_here ? (uint32_t)s_dest[j1 / 3] * 3u + (uint32_t)(j1 % 3) : 0xFFFFFFFFu;
+            ws2[r] = j2 < 3 * n_here ? (uint32_t)s_dest[j2 / 3] * 3u + (uint32_t)(j2 % 3) : 0xFFFFFFFFu;
+        }
+    }
+    // (5) + (6) per slot range of the sorted tile: payload words into the staging buffer, then out as runs
+    for (int c = 0; c < NCH; c++) {
+        const uint32_t lo = (uint32_t)(c * CH);
+        if ((int)lo >= n_here) break;                           // (uniform)
+        if (SRC_COLS) {
+#pragma unroll
+            for (int r = 0; r < RI; r++) {
+                const uint32_t q = slot[r] - lo;
+                if (q < (uint32_t)CH) { s_rows[q * 3 + 0] = w0[r]; s_rows[q * 3 + 1] = w1[r]; s_rows[q * 3 + 2] = w2[r]; }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RI; r++) {
+                const uint32_t q0 = ws0[r] - lo * 3u, q1 = ws1[r] - lo * 3u, q2 = ws2[r] - lo * 3u;
+                if (q0 < (uint32_t)(CH * 3)) s_rows[q0] = w0[r];
+                if (q1 < (uint32_t)(CH * 3)) s_rows[q1] = w1[r];
+                if (q2 < (uint32_t)(CH * 3)) s_rows[q2] = w2[r];
+            }
+        }
+        __syncthreads();
+        const int n_c = n_here - (int)lo < CH ? n_here - (int)lo : CH;
+#pragma unroll
+        for (int r = 0; r < 3 * RI / NCH; r++) {
+            const int j = r * THREADS + threadIdx.x;
+            if (j < 3 * n_c) {
+                const int p = j / 3;
+                a.rows_out[(int64_t)s_out[lo + p] * 3 + (j - p * 3)] = s_rows[j];
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < RI; r++) {
+        const int p = r * THREADS + threadIdx.x;
+        if (p < n_here) a.keys_out[(int64_t)s_out[p]] = s_keys[p];
+    }
+}
+
 // First row and one-past-last row of every group (group = key >> L) in the keys sorted by group; arrays zeroed before.
 // Four keys per lane (one 16-byte load), the key before a lane's four from the lane below (the first lane of a wave loads
 // it): a boundary between rows i - 1 and i ends the group of i - 1 and begins the group of i.  Round 3's form (one key per
@@ -806,6 +975,12 @@ __global__ __launch_bounds__(THREADS) void k_kmer_digit_hist(const uint64_t *__r
 #ifndef GKI_PT_RI
 #define GKI_PT_RI 8
 #endif
+// > 1: the build's passes run k_partition_rows_staged (the sorted tile staged through LDS in this many parts: 4 -> 64 KB of
+// LDS, two workgroups per CU); 1: k_partition_rows (one workgroup per CU).  Same box, alternating
+// (profiles/r04_partition_two_workgroups_ab.txt): first pass 7.75 -> 5.37 ms, second 6.36 -> 5.00 ms per 3.95e8 records.
+#ifndef GKI_PT_NCH
+#define GKI_PT_NCH 4
+#endif
 // tile of the bucket-range partition (<= 256 parts: its runs are long whatever the tile): 2048 rows, 72 KB of LDS, two
 // workgroups per CU -- one loads while the other stores: 50.1 -> 45.0 ms per 3.16e9 records, same box
 // (profiles/r04_full_index_ab.txt).  The build's 512- and 1024-way passes keep 4096-row tiles (longer runs matter more there).
@@ -952,8 +1127,13 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
             a.rows_out = rows[p & 1]; a.keys_out = keys[p & 1];
             a.o_kmers = nullptr; a.o_nodes = nullptr; a.o_refs = nullptr; a.o_af = nullptr; a.dbase = nullptr;
             a.xcd_tiles = xcd_tiles;
+#if GKI_PT_NCH > 1
+            if (p == 0 && !from_rows) hipLaunchKernelGGL((k_partition_rows_staged<THREADS, RI, true, GKI_PT_NCH>), dim3(xgrid), dim3(THREADS), 0, s, a);
+            else hipLaunchKernelGGL((k_partition_rows_staged<THREADS, RI, false, GKI_PT_NCH>), dim3(xgrid), dim3(THREADS), 0, s, a);
+#else
             if (p == 0 && !from_rows) hipLaunchKernelGGL((k_partition_rows<THREADS, RI, true>), dim3(xgrid), dim3(THREADS), 0, s, a);
             else hipLaunchKernelGGL((k_partition_rows<THREADS, RI, false>), dim3(xgrid), dim3(THREADS), 0, s, a);
+#endif
             HIP_G(hipGetLastError());
             cur_rows = a.rows_out; cur_keys = a.keys_out;
             shift += bits;
