@@ -510,7 +510,11 @@ __global__ __launch_bounds__(THREADS, 4) void k_partition_rows_staged(PartArgs a
             const int d = threadIdx.x * C + c;
             if (d < bins) {
                 s_dstart[d] = ex;
-                s_toff[d] = a.offs[obase + (int64_t)d * ostride] - ex;
+                // with dbase (the bucket-range partition into rows: the caller lays the digits of several chunks out behind
+                // each other) the run goes to dbase[d] + its offset among the chunk's runs of the digit; the output has
+                // fewer than 2^32 rows (checked by the host), so 32-bit arithmetic carries it
+                s_toff[d] = (SRC_COLS && a.dbase ? (uint32_t)a.dbase[d] - a.offs[(int64_t)d * a.n_tiles] : 0u) +
+                            a.offs[obase + (int64_t)d * ostride] - ex;
                 ex += tot[c];
             }
         }
@@ -1310,7 +1314,15 @@ static int partition_columns_by_part(const void *d_kmers, const void *d_nodes, c
             a.xcd_tiles = (int)ceil_div(a.n_tiles, 8);
             if (d_out_rows) {               // rows + keys out (the key: the bucket's offset in its part)
                 a.rows_out = (uint64_t *)d_out_rows; a.keys_out = (uint32_t *)d_out_keys;
-                hipLaunchKernelGGL((k_partition_rows<THREADS, RI, true, false>), dim3((unsigned)(a.xcd_tiles * 8)), dim3(THREADS), 0, s, a);
+                bool launched = false;
+                if constexpr (GKI_PT_NCH > 1 && THREADS == GKI_PT_THREADS) {
+                    if (n < ((int64_t)1 << 32)) {
+                        hipLaunchKernelGGL((k_partition_rows_staged<THREADS, RI, true, GKI_PT_NCH>), dim3((unsigned)(a.xcd_tiles * 8)), dim3(THREADS), 0, s, a);
+                        launched = true;
+                    }
+                }
+                if (!launched)
+                    hipLaunchKernelGGL((k_partition_rows<THREADS, RI, true, false>), dim3((unsigned)(a.xcd_tiles * 8)), dim3(THREADS), 0, s, a);
             } else
                 hipLaunchKernelGGL((k_partition_rows<THREADS, RI, true, true>), dim3((unsigned)(a.xcd_tiles * 8)), dim3(THREADS), 0, s, a);
             HIP_G(hipGetLastError());
