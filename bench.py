@@ -47,7 +47,8 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s
 XGMI_LINK_GBS = 153.0            # per direction and link (7 links per GPU, fully connected)
 BYTES_PER_RECORD = 25            # 1 B of node sequence read + 24 B FlatKmers row written
 PMC_FILE = "profiles/r04_pmc_3gbp.json"
-FULL_INDEX_GROUP_BITS = 0         # --full-index-group-bits
+FULL_INDEX_GROUP_BITS = 7         # --full-index-group-bits
+FULL_INDEX_ROWS = True             # --full-index-columns turns it off
 
 
 def pmc_traffic(n_ref_bases, n_sites, k):
@@ -485,15 +486,18 @@ def full_index_record(lib, _lib, g, k, cp, out, max_variant_nodes, modulo, n_sli
     finder._params()
     if finder._count(layout=1) != n:
         raise _lib.GkiError(2, "full_index: the graph holds %d records, the step wrote %d" % (finder._count(layout=1), n))
-    parts = DeviceRows(n) if G else DeviceFlatKmers.allocate(n)      # the partitioned records beside the step's own columns
+    ROWS = FULL_INDEX_ROWS or G > 0        # the partitioned records stay 24-byte rows + keys between the partition and the slice builds
+    parts = DeviceRows(n) if ROWS else DeviceFlatKmers.allocate(n)      # the partitioned records beside the step's own columns
     # everything once untimed: sizes the library's memory pool (hipMalloc / hipFree of tens of GB cost seconds on this stack,
     # DESIGN.md section 6 "Device memory pool"; the index_build record measures its third build for the same reason)
-    do_partition = (lambda: partition_rows_by_bucket_range(out, modulo, W, group_bits=G, out=parts)) if G else \
+    do_partition = (lambda: partition_rows_by_bucket_range(out, modulo, W, group_bits=G, out=parts)) if ROWS else \
         (lambda: partition_by_bucket_range(out, modulo, W, out=parts))
     _, start = do_partition()
     biggest = max(range(W), key=lambda p: start[(p + 1) << G] - start[p << G])
     sl = PartitionedDeviceIndex.build_slice(parts, start, modulo, W, biggest, G)
     sl.free()
+    out = finder.find_flat_on_device(out)        # (the find once untimed too: the timed one below then follows device work, not a pause)
+    finder.synchronize()
     sync()
     pool0 = _lib.pool_stats()
     t = time.perf_counter()
@@ -507,7 +511,7 @@ def full_index_record(lib, _lib, g, k, cp, out, max_variant_nodes, modulo, n_sli
     sync()
     t_part = time.perf_counter() - t
     got = [(0, 0)] * 4
-    sizes, build_ms, nonempty = [], [], 0
+    sizes, build_ms, directories = [], [], []
     t_build = 0.0
     for p in range(W):
         sync()
@@ -516,25 +520,33 @@ def full_index_record(lib, _lib, g, k, cp, out, max_variant_nodes, modulo, n_sli
         sync()
         build_ms.append(1e3 * (time.perf_counter() - t))
         t_build += time.perf_counter() - t
+        # between two slice builds only device work (the checksum kernels): a host-side pause here lets the clocks drop and
+        # the next build's first kernels pay for it (1.4 ms per slice when the non-empty buckets were counted on the host
+        # inside this loop).  The directories (226 MB each) are kept and counted after the last build.
         for i, colname in enumerate(("kmers", "nodes", "ref_offsets", "allele_frequencies")):
             s_, x_ = getattr(sl, colname).checksum(sl.n)
             got[i] = ((got[i][0] + s_) & MASK, got[i][1] ^ x_)
         sizes.append(sl.n)
-        nonempty += int(np.count_nonzero(sl.n_kmers.to_host()))
+        directories.append(sl.n_kmers)
+        sl.n_kmers = _lib.DeviceArray(1, np.uint32)
         sl.free()                    # checksummed and released before the next slice is built
+    nonempty = 0
+    for nk in directories:
+        nonempty += int(np.count_nonzero(nk.to_host()))
+        nk.free()
     pool1 = _lib.pool_stats()
     parts.free()
     total = sum(sizes)
     dt = t_find + t_part + t_build
-    # as implemented, per record: the step 25 B; partition 8 R (histogram) + 24 R + 24 W; slice build: histogram 8 R, first pass
-    # 24 R + 28 W, second 4 R + 28 R + 28 W, group bounds 4 R, finish 28 R + 26 W  (grouped: 60 + 118)
-    moved = (BYTES_PER_RECORD + (60 + 118 if G else 56 + 178)) * total + 8 * modulo
+    # as implemented, per record: the step 25 B; partition 8 R (histogram) + 24 R + 28 W (rows + keys; 24 W as columns); slice
+    # build: per pass 4 R (histogram; 8 R from k-mers) + 28 R + 28 W, two passes (one when grouped), group bounds 4 R, finish 28 R + 26 W
+    moved = (BYTES_PER_RECORD + (60 if ROWS else 56) + (118 if G else 178)) * total + 8 * modulo
     rec = {"records": int(total), "slices": W, "records_per_slice": sizes, "exceeds_int32_directory": bool(total >= 2 ** 31),
            "find_ms": 1e3 * t_find, "partition_ms": 1e3 * t_part, "build_slices_ms": 1e3 * t_build,
            "build_ms_per_slice": [round(x, 2) for x in build_ms], "ms": 1e3 * dt, "records_per_s": total / dt,
            "roofline": index_roofline(total, modulo, nonempty, dt, hashing=True),
            "roofline_at_the_passes_run": index_roofline(total, modulo, nonempty, dt, hashing=True, passes=2 if G else 3),
-           "group_bits": G,
+           "group_bits": G, "partitioned_records_as": "rows + keys" if ROWS else "four columns",
            "bytes_moved_model": int(moved), "achieved_GBps_as_implemented": moved / dt / 1e9,
            "frac_of_hbm_peak_as_implemented": moved / dt / 1e9 / HBM_PEAK_GBS,
            "device_allocator": {"hipMalloc_calls": pool1[0] - pool0[0], "hipFree_calls": pool1[1] - pool0[1],
@@ -745,15 +757,20 @@ def main():
     ap.add_argument("--reads", type=float, default=1e8, help="reads of the read_mapping record, BASELINE configs[4]: 1e8 "
                     "(0: skip the secondary records)")
     ap.add_argument("--no-full-index", action="store_true", help="skip the full_index record (N=1)")
-    ap.add_argument("--full-index-group-bits", type=int, default=0,
-                    help="full_index through the grouped flow: the partition also groups every slice by this many top key bits (7)")
+    ap.add_argument("--full-index-columns", action="store_true",
+                    help="full_index with the partitioned records as four columns (gki_partition_by_bucket_range -> gki_index_build_range) "
+                         "instead of rows + keys (gki_partition_rows_by_bucket_range -> gki_index_build_range_from_rows)")
+    ap.add_argument("--full-index-group-bits", type=int, default=7,
+                    help="full_index: the partition also groups every slice by this many top key bits (8 slices x 2^7 = the pass's 1024 "
+                         "digits) and the slice builds start from there with one pass less; 0: plain bucket-range partition")
     ap.add_argument("--no-sharded-build", action="store_true", help="skip the sharded_build record (N>1)")
     ap.add_argument("--sharded-build-budget", type=float, default=600.0, help="seconds the sharded_build record may take before "
                     "rank 0 prints the line without it")
     ap.add_argument("--modulo", type=int, default=452930477)
     args = ap.parse_args()
-    global FULL_INDEX_GROUP_BITS
+    global FULL_INDEX_GROUP_BITS, FULL_INDEX_ROWS
     FULL_INDEX_GROUP_BITS = args.full_index_group_bits
+    FULL_INDEX_ROWS = not args.full_index_columns
     if args.nested > 0:
         args.max_variant_nodes = max(args.max_variant_nodes, 8)
 

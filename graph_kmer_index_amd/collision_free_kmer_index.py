@@ -283,13 +283,12 @@ class PartitionedDeviceIndex:
         return sum(p.n for p in self.parts)
 
     @classmethod
-    def build(cls, dflat, modulo=452930477, n_parts=8, skip_frequencies=False, grouped=False, out=None):
-        """Partition by bucket range, build every slice.  grouped: the partition also groups every slice's records by
-        the top bits of their key (as many as keep n_parts << bits within the partition pass's 1024 digits), leaves them
-        as rows, and the slice builds start from there -- one sort pass less per slice, paid for by a partition pass
-        that is as much slower (1024 digits instead of 8): measured equal end to end on the 3 Gbp graph, hence not the
-        default (DESIGN.md 4.3 "Grouped build").  `out`: where the partitioned records go (DeviceFlatKmers, or
-        DeviceRows when grouped)."""
+    def build(cls, dflat, modulo=452930477, n_parts=8, skip_frequencies=False, grouped=True, out=None):
+        """Partition by bucket range, build every slice.  grouped (the default): the partition also groups every slice's
+        records by the top bits of their key (as many as keep n_parts << bits within the partition pass's 1024 digits)
+        and leaves them as rows + keys; the slice builds start from there with one sort pass less -- on the 3 Gbp graph
+        187 ms against 195 through four columns and a plain partition (DESIGN.md 4.3 "Grouped build").  `out`: where the
+        partitioned records go (DeviceRows when grouped, DeviceFlatKmers otherwise)."""
         g = max(0, 10 - max(0, (n_parts - 1).bit_length())) if grouped else 0
         if grouped:
             part, start = partition_rows_by_bucket_range(dflat, modulo, n_parts, group_bits=g, out=out)
