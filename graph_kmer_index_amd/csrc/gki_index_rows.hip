@@ -66,6 +66,7 @@ struct KeyRule {
     uint64_t bucket_begin, n_buckets;       // build: key = kmer % modulo - bucket_begin, must be < n_buckets
     int n_parts;                            // > 0: key = owning part; part_begin[n_parts + 1] on the device
     float parts_per_bucket;                 //   n_parts / modulo: the part of bucket b is b * this, give or take one
+    int parts_log2;                         //   >= 0: n_parts = 2^this, and part_begin[p] = (modulo * p) >> this needs no table
     int sub_bits;                           // > 0 (with parts): key = part << sub_bits | the top sub_bits bits of the bucket's
     const uint32_t *part_begin;             //   offset in its part, i.e. (bucket - part_begin[part]) >> sub_shift[part]
     const uint32_t *sub_shift;              //   [n_parts] on the device
@@ -88,7 +89,21 @@ __device__ __forceinline__ uint32_t key_of(const KeyRule &k, const uint32_t *s_p
     if (k.n_parts > 0) {
         int p = (int)((float)(uint32_t)b * k.parts_per_bucket);         // floor(b * n_parts / modulo), give or take one (24-bit
         p = p < k.n_parts ? p : k.n_parts - 1;                          // mantissa: three instructions where the exact quotient
-        while (p + 1 < k.n_parts && s_pb[p + 1] <= (uint32_t)b) p++;    // by multiply-high took sixteen)
+                                                                        // by multiply-high took sixteen)
+        if (k.parts_log2 >= 0) {
+            // a power of two of parts (the usual 8): the part bounds by a multiply and a shift, the group shift by a count
+            // of leading zeros -- no table in LDS (six LDS reads per record in a kernel that lives on LDS bandwidth)
+            uint32_t lo = (uint32_t)((k.mod.m * (uint64_t)p) >> k.parts_log2), hi = (uint32_t)((k.mod.m * (uint64_t)(p + 1)) >> k.parts_log2);
+            if ((uint32_t)b < lo) { p--; hi = lo; lo = (uint32_t)((k.mod.m * (uint64_t)p) >> k.parts_log2); }
+            else if ((uint32_t)b >= hi && p + 1 < k.n_parts) { p++; lo = hi; hi = (uint32_t)((k.mod.m * (uint64_t)(p + 1)) >> k.parts_log2); }
+            *stored = (uint32_t)b - lo;
+            if (k.sub_bits > 0) {
+                const int kbp = hi - lo > 1u ? 32 - __clz((int)(hi - lo - 1u)) : 0;       // bits of the part's largest key
+                return ((uint32_t)p << k.sub_bits) | (*stored >> (kbp > k.sub_bits ? kbp - k.sub_bits : 0));
+            }
+            return (uint32_t)p;
+        }
+        while (p + 1 < k.n_parts && s_pb[p + 1] <= (uint32_t)b) p++;
         while (p > 0 && s_pb[p] > (uint32_t)b) p--;
         *stored = (uint32_t)b - s_pb[p];
         if (k.sub_bits > 0) return ((uint32_t)p << k.sub_bits) | (*stored >> s_pb[MAX_PARTS + 1 + p]);
@@ -105,6 +120,18 @@ __device__ __forceinline__ uint32_t key_of(const KeyRule &k, const uint32_t *s_p
 // The histogram of such a pass is laid out group by group, inside a group digit-major like the plain one, so that ONE
 // exclusive scan over all of it still yields every run's first output row.
 struct TileDesc { int64_t row0, tiles_before; int32_t n, stride, t, pad; };   // histogram column: (tiles_before * bins + t) + digit * stride
+
+// the descriptors of one group's tiles: seg = (first row, one past the last row, tiles of the groups before) per group
+__global__ __launch_bounds__(256) void k_tile_descs(const int64_t *__restrict__ seg, int tile_rows, TileDesc *__restrict__ out) {
+    const int64_t a0 = seg[3 * blockIdx.x], a1 = seg[3 * blockIdx.x + 1], before = seg[3 * blockIdx.x + 2];
+    const int64_t nt = (a1 - a0 + tile_rows - 1) / tile_rows;
+    for (int64_t t = threadIdx.x; t < nt; t += 256) {
+        TileDesc td;
+        td.row0 = a0 + t * tile_rows; td.n = (int32_t)((a1 - td.row0) < tile_rows ? (a1 - td.row0) : tile_rows);
+        td.tiles_before = before; td.t = (int32_t)t; td.stride = (int32_t)nt; td.pad = 0;
+        out[before + t] = td;
+    }
+}
 
 struct PartArgs {
     const TileDesc *tiles;         // NULL: tile t is rows [t * TILE, +TILE), its histogram column offs[d * n_tiles + t]
@@ -1048,25 +1075,22 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
     if (n_pass > 3) return GKI_OK;
     const int64_t n_groups = (int64_t)(((n_buckets - 1) >> L) + 1);
     // tiles: plain, or cut at the group bounds
-    std::vector<TileDesc> h_tiles;
+    // (the descriptors are written on the device, k_tile_descs: the host hands over three numbers per group, not one
+    // record per tile -- 94 000 of them, 3 MB through pageable memory, per slice of the whole-genome index)
+    std::vector<int64_t> h_seg;                               // per group: first row, one past its last row, tiles before it
     int64_t n_tiles = ceil_div(n, TILE);
+    const int64_t n_seg = grouped ? (int64_t)1 << group_bits : 0;
     if (grouped) {
-        const int64_t n_seg = (int64_t)1 << group_bits;
         if (h_group_start[0] != 0 || h_group_start[n_seg] != n) return gki_set_error(GKI_ERR_BAD_ARG, "group_start must run from 0 to n");
         int64_t t_before = 0;
+        h_seg.resize((size_t)(3 * n_seg));
         for (int64_t g = 0; g < n_seg; g++) {
             const int64_t a0 = h_group_start[g], a1 = h_group_start[g + 1];
             if (a1 < a0) return gki_set_error(GKI_ERR_BAD_ARG, "group_start must not decrease");
-            const int64_t nt = ceil_div(a1 - a0, TILE);
-            for (int64_t t = 0; t < nt; t++) {
-                TileDesc td;
-                td.row0 = a0 + t * TILE; td.n = (int32_t)((a1 - td.row0) < TILE ? (a1 - td.row0) : TILE);
-                td.tiles_before = t_before; td.t = (int32_t)t; td.stride = (int32_t)nt; td.pad = 0;
-                h_tiles.push_back(td);
-            }
-            t_before += nt;
+            h_seg[(size_t)(3 * g)] = a0; h_seg[(size_t)(3 * g + 1)] = a1; h_seg[(size_t)(3 * g + 2)] = t_before;
+            t_before += ceil_div(a1 - a0, TILE);
         }
-        n_tiles = (int64_t)h_tiles.size();
+        n_tiles = t_before;
     }
     const int64_t hist_n = (int64_t)MAXB * n_tiles;
     const int64_t tmp_bytes = gki_scan_tmp_bytes(hist_n);
@@ -1079,17 +1103,21 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
     const uint32_t large_cap = 1u << 16;
     const uint32_t big_cap = (uint32_t)(n / SMALL_BUCKET + 1);
     TileDesc *d_tiles = nullptr;
+    int64_t *d_seg = nullptr;
     KeyRule rule;
     rule.mod = gki_mod_of(modulo); rule.bucket_begin = bucket_begin; rule.n_buckets = n_buckets; rule.n_parts = 0; rule.sub_bits = 0;
-    rule.part_begin = nullptr; rule.sub_shift = nullptr; rule.parts_per_bucket = 0.f;
+    rule.part_begin = nullptr; rule.sub_shift = nullptr; rule.parts_per_bucket = 0.f; rule.parts_log2 = -1;
     int rc = GKI_OK;
 #define HIP_G(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = gki_set_error(GKI_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); goto done; } } while (0)
     {
         HIP_G(gki_dev_malloc((void **)&stats, 64));
         HIP_G(hipMemsetAsync(stats, 0, 64, s));
         if (grouped) {
-            HIP_G(gki_dev_malloc((void **)&d_tiles, h_tiles.size() * sizeof(TileDesc) + 32));
-            HIP_G(hipMemcpyAsync(d_tiles, h_tiles.data(), h_tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, s));
+            HIP_G(gki_dev_malloc((void **)&d_tiles, (size_t)n_tiles * sizeof(TileDesc) + 32));
+            HIP_G(gki_dev_malloc((void **)&d_seg, h_seg.size() * 8));
+            HIP_G(hipMemcpyAsync(d_seg, h_seg.data(), h_seg.size() * 8, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_tile_descs, dim3((unsigned)n_seg), dim3(256), 0, s, d_seg, TILE, d_tiles);
+            HIP_G(hipGetLastError());
         }
         for (int i = 0; i < (n_pass > 1 ? 2 : n_pass); i++) {
             HIP_G(gki_dev_malloc((void **)&rows[i], (size_t)n * 24));
@@ -1196,7 +1224,7 @@ done:
     for (int i = 0; i < 2; i++) { (void)gki_dev_free(rows[i]); (void)gki_dev_free(keys[i]); }
     (void)gki_dev_free(hist); (void)gki_dev_free(offs); (void)gki_dev_free(tmp); (void)gki_dev_free(gbegin); (void)gki_dev_free(gend);
     (void)gki_dev_free(large); (void)gki_dev_free(big); (void)gki_dev_free(stats); (void)gki_dev_free(rng);
-    if (d_tiles) { (void)hipStreamSynchronize(s); (void)gki_dev_free(d_tiles); }     // (the upload read h_tiles asynchronously)
+    if (d_tiles) { (void)hipStreamSynchronize(s); (void)gki_dev_free(d_tiles); (void)gki_dev_free(d_seg); }   // (the upload read h_seg asynchronously)
 #undef HIP_G
     return rc;
 }
@@ -1274,6 +1302,8 @@ static int partition_columns_by_part(const void *d_kmers, const void *d_nodes, c
     KeyRule rule;
     rule.mod = gki_mod_of(modulo); rule.bucket_begin = 0; rule.n_buckets = modulo; rule.n_parts = n_parts; rule.sub_bits = sub_bits;
     rule.parts_per_bucket = (float)((double)n_parts / (double)modulo);
+    rule.parts_log2 = -1;
+    for (int l = 0; l <= 8; l++) if ((1 << l) == n_parts) rule.parts_log2 = l;
     int rc = GKI_OK;
 #define HIP_G(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = gki_set_error(GKI_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); goto done; } } while (0)
     {
