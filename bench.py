@@ -769,7 +769,7 @@ def main():
     ap.add_argument("--modulo", type=int, default=452930477)
     args = ap.parse_args()
     global FULL_INDEX_GROUP_BITS, FULL_INDEX_ROWS
-    FULL_INDEX_GROUP_BITS = args.full_index_group_bits
+    FULL_INDEX_GROUP_BITS = 0 if args.full_index_columns else args.full_index_group_bits      # (the grouping exists for rows only)
     FULL_INDEX_ROWS = not args.full_index_columns
     if args.nested > 0:
         args.max_variant_nodes = max(args.max_variant_nodes, 8)
