@@ -295,8 +295,19 @@ class PartitionedDeviceIndex:
         else:
             part, start = partition_by_bucket_range(dflat, modulo, n_parts, out=out)
         parts = []
-        for p in range(n_parts):
-            parts.append(cls.build_slice(part, start, modulo, n_parts, p, g, skip_frequencies))
+        try:
+            for p in range(n_parts):
+                parts.append(cls.build_slice(part, start, modulo, n_parts, p, g, skip_frequencies))
+        except _lib.GkiError as e:
+            # a slice outside the row-carrying build's domain (a handful of buckets holding millions of records): the build
+            # from columns can hand such a slice to the pair-sorting form, the build from rows cannot -- start over that way
+            for sl in parts:
+                sl.free()
+            if out is None:
+                part.free()
+            if not grouped or "domain" not in str(e):
+                raise
+            return cls.build(dflat, modulo, n_parts, skip_frequencies, grouped=False)
         if out is None:
             part.free()
         return cls(modulo, parts)

@@ -237,3 +237,27 @@ def test_partitioned_index_grouped_and_plain_count_the_same_nodes():
         assert got.sum() > 0 and np.array_equal(got, want)
         idx.free()
     d.free()
+
+
+def test_partitioned_index_with_a_giant_bucket_falls_back_to_columns():
+    """A slice whose records sit in a handful of buckets (4.3 million copies of one k-mer) is outside the row-carrying
+    build's domain; the build from columns hands it to the pair-sorting form, the build from rows cannot:
+    PartitionedDeviceIndex.build starts over through columns and still answers."""
+    from graph_kmer_index_amd.collision_free_kmer_index import PartitionedDeviceIndex
+    n = (1 << 22) + 50000
+    rng = np.random.default_rng(8)
+    kmers = np.full(n, 987654321987, dtype=np.uint64)
+    kmers[::500] = rng.integers(0, 4 ** 31, size=len(kmers[::500]), dtype=np.uint64)
+    nodes = rng.integers(0, 3000, size=n).astype(np.uint32)
+    refs = rng.integers(0, 40000, size=n).astype(np.uint64)
+    d = DeviceFlatKmers.from_flat_kmers(FlatKmers(kmers, nodes, refs, np.ones(n, np.float32)))
+    idx = PartitionedDeviceIndex.build(d, 1000003, n_parts=4, skip_frequencies=True)
+    assert idx.n == n
+    queries = np.unique(np.concatenate([kmers[::500][:2000], [np.uint64(987654321987)]]))
+    got = idx.count_nodes(queries, 3000, max_hits=2 ** 40).to_host()
+    want = np.zeros(3000, dtype=np.int64)
+    sel = np.isin(kmers, queries)
+    np.add.at(want, nodes[sel], 1)
+    assert np.array_equal(got.astype(np.int64), want)
+    idx.free()
+    d.free()
