@@ -58,10 +58,14 @@ __device__ __forceinline__ void script_write(uint4 *e, uint64_t h, double maf, i
 // its allele frequency); here the FW_SN stack slots are read at fixed indices and the FW_SN allele frequencies loaded side
 // by side -- two round trips whatever Lw is.  Slots beyond the path hold stale levels: replaced by the first node before
 // anything is indexed with them.
+// (the levels below the finished one come from the stack -- the low word of its (node, meta) entries --, the finished level's
+// node q is still in a register: nothing is stored for a level that ends its path)
 template <class NS>
-__device__ __forceinline__ bool short_path_facts(const DevGraph &g, NS &nd, int Lw, int32_t (&v)[FW_SN], int32_t &mn, double &maf) {
+__device__ __forceinline__ bool short_path_facts(const DevGraph &g, NS &nm, int Lw, int32_t q, int32_t (&v)[FW_SN], int32_t &mn, double &maf) {
 #pragma unroll
-    for (int r = 0; r < FW_SN; r++) v[r] = nd[r];
+    for (int r = 0; r < FW_SN; r++) v[r] = (int32_t)(uint32_t)nm[r];
+#pragma unroll
+    for (int r = 0; r < FW_SN; r++) if (r == Lw - 1) v[r] = q;
 #pragma unroll
     for (int r = 1; r < FW_SN; r++) if (r >= Lw) v[r] = v[0];
     double f[FW_SN];
@@ -96,7 +100,7 @@ __device__ __forceinline__ void check_one_ref_successor(const DevGraph &g, int32
 }
 
 // byte offset of every per-level array of the walk inside one (level, lane) cell of the slow path's arena (DeepArena)
-enum { FW_ND = 0, FW_CUR = 4, FW_END = 8, FW_LAST = 12, FW_HS = 16, FW_HAVE = 24, FW_FORCED = 25, FW_VC = 26, FW_CELL = 28 };
+enum { FW_NM = 0, FW_CE = 8, FW_HS = 16, FW_LAST = 24, FW_CELL = 28 };
 // A path that has not reached its first k-mer after this many descents below level FW_BUDGET_FROM belongs to an
 // exponential family (a run of insertion sites with no variant limit to cut it): the search from that position is wound
 // up and the call refused, as in the finder (csrc/gki_finder.hip, STEP_BUDGET).
@@ -111,42 +115,55 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
                              const DeepArena &da, int64_t lane_global, uint4 *script, uint32_t *used_out) {
     static_assert(!SCRIPT || (!EMIT && !DEEP), "the script is written by the product count kernel");
     uint32_t used = 0;                        // SCRIPT: entries written, 0xFF = this start position does not fit
-    typedef typename CountOf<DEEP>::T cnt_t;
-    typename StackOf<int32_t, FMAX, DEEP>::type nd, cur, end, last;
-    typename StackOf<uint8_t, FMAX, DEEP>::type have, forced;
-    typename StackOf<cnt_t, FMAX, DEEP>::type vc;
-    typename StackOf<uint64_t, FMAX, DEEP>::type hs;
-    bind(nd, da, FW_ND, lane_global); bind(cur, da, FW_CUR, lane_global); bind(end, da, FW_END, lane_global);
-    bind(last, da, FW_LAST, lane_global); bind(hs, da, FW_HS, lane_global); bind(have, da, FW_HAVE, lane_global);
-    bind(forced, da, FW_FORCED, lane_global); bind(vc, da, FW_VC, lane_global);
+    // per level: the node, its successor range (cur .. end), the hash so far, and ONE word for the bases collected (8 bits),
+    // "forced traversal" (8 bits) and the variant nodes on the path (16 bits) -- three separate arrays were three scratch
+    // stores per descent and three loads per turn; `last` (forced traversal only) is touched only when a follow set is given
+    // Three 64-bit words per level -- (node, meta), (cur, end), the hash so far -- where rounds 2-3 kept eight arrays: every
+    // descent was eight scratch stores and every turn of the loop five scratch loads; now three and two, and the level that
+    // completes a k-mer (every path's last) stores nothing at all.  3 Gbp graph, 3.43e7 start positions, same box:
+    // all-nodes 7.97 -> 7.39 ms with the meta word alone (profiles/r04_forward_packed_levels_ab.txt).
+    typename StackOf<int32_t, FMAX, DEEP>::type last;
+    typename StackOf<uint64_t, FMAX, DEEP>::type nm, ce, hs;
+    bind(nm, da, FW_NM, lane_global); bind(ce, da, FW_CE, lane_global); bind(hs, da, FW_HS, lane_global);
+    bind(last, da, FW_LAST, lane_global);
+#define FW_NODE_OF(x_) ((int32_t)(uint32_t)(x_))
+#define FW_META_OF(x_) ((uint32_t)((x_) >> 32))
+#define FW_CE(cur_, end_) ((uint64_t)(uint32_t)(cur_) | ((uint64_t)(uint32_t)(end_) << 32))
+#define FW_MK(have_, forced_, vc_) ((uint32_t)(have_) | ((uint32_t)(forced_) << 8) | ((uint32_t)(vc_) << 16))
+#define FW_HAVE_OF(m_) ((int)((m_) & 0xFFu))
+#define FW_FORCED_OF(m_) ((int)(((m_) >> 8) & 0xFFu))
+#define FW_VC_OF(m_) ((int)((m_) >> 16))
     const int cap = DEEP ? da.cap : FMAX;
     int steps_left = FW_BUDGET;
     uint32_t count = 0;
     const NodeWalk w0 = g.walk[n0];
     if (o0 < 0 || o0 > w0.size) { *count_out = 0; if (SCRIPT) *used_out = 0; return; }
     // level 0: the start node from offset o0 (an empty start node contributes no base)
-    int L = 0;
+    int L = 0, have0 = 0;
+    uint64_t h0 = 0;
     {
         const int avail = w0.size - o0;
         const int t = avail < k ? avail : k;
-        nd[0] = n0; vc[0] = (cnt_t)(w0.is_ref ? 0 : 1);
-        hs[0] = t > 0 ? gki_extract(g.seq2, w0.seq_start + o0, t) : 0ull;
-        have[0] = (uint8_t)t;
-        cur[0] = (int32_t)g.edge_start[n0]; end[0] = (int32_t)g.edge_start[n0 + 1];
-        forced[0] = any_followed(g, follow, n0) ? 1 : 0;
-        last[0] = INT_MIN;
-        L = 1;
-        if (t == k) { cur[0] = end[0]; }       // window complete inside the start node: handled below as a completion
-        else if (!EMIT && !forced[0] && vc[0] >= M) check_one_ref_successor(g, n0, err);
+        const int vc0 = w0.is_ref ? 0 : 1, forced0 = any_followed(g, follow, n0) ? 1 : 0;
+        h0 = t > 0 ? gki_extract(g.seq2, w0.seq_start + o0, t) : 0ull;
+        have0 = t;
+        if (t < k) {                           // (t == k: window complete inside the start node, handled below)
+            nm[0] = (uint64_t)(uint32_t)n0 | ((uint64_t)FW_MK(t, forced0, vc0) << 32);
+            hs[0] = h0;
+            ce[0] = FW_CE((int32_t)g.edge_start[n0], (int32_t)g.edge_start[n0 + 1]);
+            if (follow) last[0] = INT_MIN;
+            L = 1;
+            if (!EMIT && !forced0 && vc0 >= M) check_one_ref_successor(g, n0, err);
+        }
     }
     // completion inside the start node
-    if (have[0] == k) {
+    if (have0 == k) {
         if (EMIT) {
-            put_record<false>(out, idx, hs[0], n0, o0 + k - 1, n0, g.allele_freq[n0]);
+            put_record<false>(out, idx, h0, n0, o0 + k - 1, n0, g.allele_freq[n0]);
         }
         if (SCRIPT) {
             const int32_t one[FW_SN] = {n0, 0, 0, 0, 0};
-            script_write(script, hs[0], g.allele_freq[n0], n0, o0 + k - 1, 1, 0u, one);
+            script_write(script, h0, g.allele_freq[n0], n0, o0 + k - 1, 1, 0u, one);
             *used_out = 1;
         }
         *count_out = 1;
@@ -154,66 +171,71 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
     }
     while (L > 0) {
         const int j = L - 1;
-        if (cur[j] >= end[j]) { L--; continue; }
+        const uint64_t cej = ce[j];
+        const int32_t curj = (int32_t)(uint32_t)cej, endj = (int32_t)(uint32_t)(cej >> 32);
+        if (curj >= endj) { L--; continue; }
+        const uint64_t nmj = nm[j];
+        const uint32_t mj = FW_META_OF(nmj);
         int32_t q;
-        if (forced[j]) {
+        if (FW_FORCED_OF(mj)) {
             // :386-388 forced traversal: only the successors in the follow set.  The reference iterates a Python set
             // there, and CPython orders a set of small ints by hash & table mask, not by value (list({7, 8}) is
             // [8, 7]): among SEVERAL forced successors of one node the reference's order is an accident of the
             // interpreter and is not reproduced.  They are taken in ascending id here (deterministic); parity for
             // such nodes is on the multiset of records.  last[j] is the latest forced successor taken.
             q = INT_MAX;
-            for (int32_t e = (int32_t)g.edge_start[nd[j]]; e < end[j]; e++) {
+            for (int32_t e = (int32_t)g.edge_start[FW_NODE_OF(nmj)]; e < endj; e++) {
                 const int32_t c = g.edges[e];
                 if (follow[c] && c > last[j] && c < q) q = c;
             }
-            if (q == INT_MAX) { cur[j] = end[j]; continue; }
+            if (q == INT_MAX) { ce[j] = FW_CE(endj, endj); continue; }
             last[j] = q;
         } else {
-            { const int32_t cj = cur[j]; q = g.edges[cj]; cur[j] = cj + 1; }
+            q = g.edges[curj];
+            ce[j] = FW_CE(curj + 1, endj);
         }
         const NodeWalk wq = g.walk[q];
-        if (forced[j]) {
-        } else if (vc[j] >= M && !wq.is_ref) {
+        if (FW_FORCED_OF(mj)) {
+        } else if (FW_VC_OF(mj) >= M && !wq.is_ref) {
             continue;                                                   // :397-403 only the linear-ref successor
         }
         if (L >= cap - 1) { gki_raise(err, GKI_ERR_WINDOW_TOO_DEEP); continue; }
-        const int hv = have[j];
+        const int hv = FW_HAVE_OF(mj);
         const int t = wq.size < k - hv ? wq.size : k - hv;
-        nd[L] = q; vc[L] = (cnt_t)(vc[j] + (wq.is_ref ? 0 : 1));
-        hs[L] = hs[j] | (t > 0 ? gki_extract(g.seq2, wq.seq_start, t) << (2 * hv) : 0ull);
-        have[L] = (uint8_t)(hv + t);
+        const int vcL = FW_VC_OF(mj) + (wq.is_ref ? 0 : 1);
+        const uint64_t hL = hs[j] | (t > 0 ? gki_extract(g.seq2, wq.seq_start, t) << (2 * hv) : 0ull);
+        auto node_at = [&](int i) -> int32_t { return i == L ? q : FW_NODE_OF(nm[i]); };      // (level L itself is not stored)
         if (hv + t == k) {                          // first k-mer of this path: emit and stop (early stop, :326-330)
             const int Lw = L + 1;
             if (EMIT) {
                 int32_t v[FW_SN]; int32_t mn = INT_MAX; double maf = INFINITY;
                 bool asc = true;
                 const bool short_path = Lw <= FW_SN;
-                if (short_path) asc = short_path_facts(g, nd, Lw, v, mn, maf);
+                if (short_path) asc = short_path_facts(g, nm, Lw, q, v, mn, maf);
                 else {
-                    for (int i = 0; i < Lw; i++) { mn = nd[i] < mn ? nd[i] : mn; maf = fmin(maf, g.allele_freq[nd[i]]); }
-                    if (!one_node) for (int i = 1; i < Lw; i++) asc = asc && nd[i] > nd[i - 1];
+                    for (int i = 0; i < Lw; i++) { const int32_t ni = node_at(i); mn = ni < mn ? ni : mn; maf = fmin(maf, g.allele_freq[ni]); }
+                    if (!one_node) for (int i = 1; i < Lw; i++) asc = asc && node_at(i) > node_at(i - 1);
                 }
                 if (one_node) {
-                    put_record<true>(out, idx, hs[L], q, t - 1, mn, maf); idx++;
+                    put_record<true>(out, idx, hL, q, t - 1, mn, maf); idx++;
                 } else if (asc) {
                     // one record per distinct node, ascending (np.unique, kmer_finder.py:134).  Node ids usually grow along
                     // a forward path: then the path is the order (one pass instead of a selection per record)
                     if (short_path) {
 #pragma unroll
                         for (int r = 0; r < FW_SN; r++)
-                            if (r < Lw) { put_record<false>(out, idx, hs[L], q, t - 1, v[r], maf); idx++; }
+                            if (r < Lw) { put_record<false>(out, idx, hL, q, t - 1, v[r], maf); idx++; }
                     } else {
                         for (int r = 0; r < Lw; r++) {
-                            put_record<false>(out, idx, hs[L], q, t - 1, nd[r], maf); idx++;
+                            put_record<false>(out, idx, hL, q, t - 1, node_at(r), maf); idx++;
                         }
                     }
                 } else {
                     int32_t last = INT_MIN;
                     for (int r = 0; r < Lw; r++) {
                         int32_t best = INT_MAX;
-                        for (int i = 0; i < Lw; i++) if (nd[i] > last && nd[i] < best) best = nd[i];
-                        put_record<false>(out, idx, hs[L], q, t - 1, best, maf); idx++;
+                        for (int i = 0; i < Lw; i++) { const int32_t ni = node_at(i); if (ni > last && ni < best) best = ni; }
+                        put_record<false>(out, idx, hL, q, t - 1, best, maf); idx++;
                         last = best;
                     }
                 }
@@ -223,8 +245,8 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
                 if (fits) {
                     int32_t v[FW_SN]; int32_t mn = INT_MAX; double maf = INFINITY;
                     bool asc = true;
-                    if (Lw <= FW_SN) asc = short_path_facts(g, nd, Lw, v, mn, maf);
-                    else for (int i = 0; i < Lw; i++) { mn = nd[i] < mn ? nd[i] : mn; maf = fmin(maf, g.allele_freq[nd[i]]); }   // (one node per k-mer)
+                    if (Lw <= FW_SN) asc = short_path_facts(g, nm, Lw, q, v, mn, maf);
+                    else for (int i = 0; i < Lw; i++) { const int32_t ni = node_at(i); mn = ni < mn ? ni : mn; maf = fmin(maf, g.allele_freq[ni]); }   // (one node per k-mer)
                     fits = one_node || asc;
                     if (fits) {
                         int32_t ns[FW_SN] = {mn, 0, 0, 0, 0};
@@ -232,7 +254,7 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
 #pragma unroll
                             for (int r = 0; r < FW_SN; r++) ns[r] = r < Lw ? v[r] : 0;
                         }
-                        script_write(script + (size_t)used * FW_ENTRY_U4, hs[L], maf, q, t - 1, one_node ? 1 : Lw, count, ns);
+                        script_write(script + (size_t)used * FW_ENTRY_U4, hL, maf, q, t - 1, one_node ? 1 : Lw, count, ns);
                         used++;
                     }
                 }
@@ -243,10 +265,12 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
         }
         // (q's successor range asked for together with its record, ahead of the "first k-mer finished?" branch -- three
         // dependent round trips per descent instead of four -- measured no different: profiles/r04_forward_early_edges_ab.txt)
-        cur[L] = (int32_t)g.edge_start[q]; end[L] = (int32_t)g.edge_start[q + 1];
-        forced[L] = any_followed(g, follow, q) ? 1 : 0;
-        last[L] = INT_MIN;
-        if (!EMIT && !forced[L] && vc[L] >= M) check_one_ref_successor(g, q, err);
+        ce[L] = FW_CE((int32_t)g.edge_start[q], (int32_t)g.edge_start[q + 1]);
+        const int forcedL = any_followed(g, follow, q) ? 1 : 0;
+        nm[L] = (uint64_t)(uint32_t)q | ((uint64_t)FW_MK(hv + t, forcedL, vcL) << 32);
+        hs[L] = hL;
+        if (follow) last[L] = INT_MIN;
+        if (!EMIT && !forcedL && vcL >= M) check_one_ref_successor(g, q, err);
         L++;
         // (out of budget: the walk ends through its ordinary exit, see STEP_BUDGET in csrc/gki_finder.hip)
         if (L > FW_BUDGET_FROM && --steps_left < 0) { gki_raise_budget(err); L = 0; }

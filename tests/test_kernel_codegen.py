@@ -126,15 +126,21 @@ def index_rows_asm(tmp_path_factory):
 def test_footprints_of_the_index_build_kernels(index_rows_asm):
     """the finish runs four workgroups of 512 threads per CU (<= 40 KB of LDS, <= 64 VGPRs), the bucket-range
     partition two workgroups of 256 threads on 2048-row tiles (<= 80 KB), the build's passes one workgroup on a 4096-row
-    tile (<= 160 KB), the 4096-row finish of the grouped build sixteen waves (<= 128 VGPRs); nothing spills."""
+    tile staged in four parts (<= 80 KB: two workgroups per CU), the 4096-row finish of the grouped build sixteen waves
+    (<= 128 VGPRs)."""
     r = _resources(index_rows_asm)
-    assert all(v["scratch"] == 0 for v in r.values()), {k: v["scratch"] for k, v in r.items() if v["scratch"]}
+    # (the second pass holds a slot per payload word at the 128-VGPR cap of two workgroups per CU: three dwords spill)
+    assert all(v["scratch"] <= (16 if k.startswith("k_partition_rows_staged<512, 8, false") else 0) for k, v in r.items()), \
+        {k: v["scratch"] for k, v in r.items() if v["scratch"]}
+    # the build's passes: two workgroups of 512 threads per CU (<= 80 KB of LDS, <= 128 VGPRs)
+    for name in ("k_partition_rows_staged<512, 8, true, 4>", "k_partition_rows_staged<512, 8, false, 4>"):
+        assert r[name]["lds"] <= 81920 and r[name]["vgpr"] <= 128, (name, r[name])
     for name in ("k_group_finish<true, 1024, 512>", "k_group_finish<false, 1024, 512>"):
         assert r[name]["lds"] <= 40960 and r[name]["vgpr"] <= 64, (name, r[name])
     for name in ("k_group_finish<true, 4096, 1024>", "k_group_finish<false, 4096, 1024>"):
         assert r[name]["lds"] <= 163840 and r[name]["vgpr"] <= 128, (name, r[name])
     assert r["k_partition_rows<256, 8, true, true>"]["lds"] <= 81920 and r["k_partition_rows<256, 8, true, true>"]["vgpr"] <= 128
-    for name in ("k_partition_rows<512, 8, true, false>", "k_partition_rows<512, 8, false, false>", "k_partition_rows<512, 8, true, true>"):
+    for name in ("k_partition_rows<512, 8, true, false>", "k_partition_rows<512, 8, true, true>"):      # (rows out beyond 2^32 records; > 256 parts into columns)
         assert r[name]["lds"] <= 163840 and r[name]["vgpr"] <= 256, (name, r[name])
     for name in ("k_kmer_digit_hist<512, 8>", "k_kmer_digit_hist<256, 8>", "k_digit_hist<512, 8>"):
         assert r[name]["vgpr"] <= 64 and r[name]["lds"] <= 16384, (name, r[name])      # 8 waves per SIMD; the LDS leaves the thread limit (4 x 512) in charge
