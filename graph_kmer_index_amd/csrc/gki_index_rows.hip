@@ -10,14 +10,23 @@
 //                                   the first pass computes it again from the k-mer it carries anyway)
 //     k_digit_hist (later passes)   per-tile digit histogram                                  4 R
 //     scan                          bin-major exclusive scan -> first row of every (digit, tile) run
-//     k_partition_rows              the four input columns -> rows + keys (first)             24 R + 28 W
+//     k_partition_rows_staged       the four input columns -> rows + keys (first)             24 R + 28 W
 //                                   rows + keys -> rows + keys (later)                        28 R + 28 W
+//                                   (4096-row tile, ranked at once, staged through LDS in four parts: two workgroups per CU;
+//                                   k_partition_rows -- the tile sorted whole in LDS -- serves the bucket-range partition
+//                                   into columns and is the A/B partner, -DGKI_PT_NCH=1)
 //   k_group_bounds / k_group_scan   first row / row count of every group (= key >> L, L <= 10) 4 R
 //   k_group_finish                  one workgroup per group: counting sort on the low L (<= 10) bits in LDS, the directory of
 //                                   the group's 2^L buckets (streamed, no memset + scatter), frequencies, and the
 //                                   four output columns + frequency column, all coalesced      28 R + 26 W + 8 B/bucket
 //   k_group_large                   a group with more rows than LDS holds: one workgroup streams it (count, scan,
 //                                   ordered scatter); frequencies of its buckets by the kernels of the first form
+//
+//
+// Bucket-range partition (gki_partition_by_bucket_range*, gki_partition_rows_by_bucket_range): one pass of the same kernels
+// with the owning part (and optionally the top bits of the key inside the part: "grouped") as the digit; the grouped build
+// (gki_index_build_range_grouped / _from_rows) then sorts every group on its own in ONE segmented pass (TileDesc) and
+// finishes 4096-row groups (k_group_finish<.., 4096, 1024>).
 //
 // Stability: every pass keeps equal digits in input order and the in-LDS sort ranks equal buckets by row position, so
 // the result equals the first form's (and the oracle's stable build) element by element.
