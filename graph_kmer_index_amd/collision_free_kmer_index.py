@@ -305,7 +305,7 @@ class PartitionedDeviceIndex:
                 sl.free()
             if out is None:
                 part.free()
-            if not grouped or "domain" not in str(e):
+            if not grouped or e.code != 8:                # GKI_ERR_OUT_OF_DOMAIN
                 raise
             return cls.build(dflat, modulo, n_parts, skip_frequencies, grouped=False)
         if out is None:

@@ -737,7 +737,7 @@ int gki_index_build_range_from_rows(const void *d_rows, const void *d_keys, int6
                                  h_group_start, d_rows, d_keys, d_hashes_to_index, d_n_kmers, d_out_kmers, d_out_nodes,
                                  d_out_ref_offsets, d_out_af32, d_out_frequencies, nullptr, &done));
     if (!done)
-        return gki_set_error(GKI_ERR_BAD_ARG, "the records are outside the row-carrying build's domain (a group of neighbouring buckets with "
+        return gki_set_error(GKI_ERR_OUT_OF_DOMAIN, "the records are outside the row-carrying build's domain (a group of neighbouring buckets with "
                              "more than 2^22 records): build this slice from its columns (gki_index_build_range)");
     return GKI_OK;
 }

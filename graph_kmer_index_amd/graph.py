@@ -199,6 +199,9 @@ class GraphArrays:
             if bad is None:
                 return fast
             logging.warning("from_obgraph: the graph's whole arrays disagree with its accessors (%s): reading node by node" % bad)
+        else:
+            logging.info("from_obgraph: the graph object offers no whole arrays this adapter knows (ragged `edges` and "
+                         "`numeric_node_sequences`): reading it node by node through its accessor methods")
         return cls._from_obgraph_accessors(graph)
 
     @classmethod

@@ -35,6 +35,9 @@ extern "C" {
 #define GKI_ERR_OVERFLOW 6       /* a count does not fit the reference's dtype (e.g. int32 directory) */
 #define GKI_ERR_NOT_ONE_REF_SUCC 7 /* the reference's AssertionError kmer_finder.py:402: a reachable window at the
                                      variant limit ends a node that does not have exactly one linear-ref successor */
+#define GKI_ERR_OUT_OF_DOMAIN 8  /* gki_index_build_range_from_rows: the records lie outside the row-carrying build's domain (a
+                                     group of neighbouring buckets with more than 2^22 records); build that slice from its
+                                     columns (gki_index_build_range hands it to the pair-sorting form) */
 
 #define GKI_MAX_WINDOW_NODES 48        /* stacks of the product kernels (scratch) */
 #define GKI_MAX_DEEP_WINDOW_NODES 12288 /* stacks of the slow path (a global-memory arena, grown 192, 384, ... levels): beyond
@@ -340,7 +343,7 @@ int gki_index_build_range_grouped(const void *d_kmers, const void *d_nodes, cons
  *   << 32), d_keys uint32[n] (the bucket's offset in its part), both device buffers of the caller; h_start as above.
  * gki_index_build_range_from_rows: the slice build from one part's rows and keys (pointers into those buffers at the
  *   part's first record, n = its records, h_group_start relative to it).  No permutation output.  A key outside
- *   [0, n_buckets) is GKI_ERR_BAD_ARG. */
+ *   [0, n_buckets) is GKI_ERR_BAD_ARG; GKI_ERR_OUT_OF_DOMAIN when the records need the pair-sorting form. */
 int gki_partition_rows_by_bucket_range(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets,
                                        const void *d_af32, int64_t n, uint64_t modulo, int n_parts, int group_bits,
                                        int64_t max_rows_per_pass, void *d_rows, void *d_keys, int64_t *h_start);
