@@ -17,7 +17,8 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
                          uint64_t modulo, uint64_t bucket_begin, uint64_t n_buckets, int skip_frequencies,
                          int group_bits, const int64_t *h_group_start, const void *d_rows_in, const void *d_keys_in,
                          void *d_hashes_to_index, void *d_n_kmers, void *d_out_kmers, void *d_out_nodes,
-                         void *d_out_ref_offsets, void *d_out_af32, void *d_out_frequencies, void *d_out_permutation, int *done);
+                         void *d_out_ref_offsets, void *d_out_af32, void *d_out_frequencies, void *d_out_permutation, int *done,
+                         int by_node);
 int gki_partition_columns_by_part(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
                                   uint64_t modulo, int n_parts, int sub_bits, int64_t max_rows_per_pass, void *d_out_kmers,
                                   void *d_out_nodes, void *d_out_ref_offsets, void *d_out_af32, void *d_out_rows, void *d_out_keys,
@@ -414,6 +415,12 @@ __global__ __launch_bounds__(256) void k_flag_repeats(const uint32_t *__restrict
 // ReverseKmerIndex.from_flat_kmers (reverse_kmer_index.py:47-60): records stably sorted by node,
 // nodes_to_index_positions[node] = first record (uint32), nodes_to_n_hashes[node] = run length (uint16, wraps
 // like the NumPy assignment at :56).
+// n_hashes of the reverse index is uint16 (the NumPy assignment at reverse_kmer_index.py:56 stores the count modulo 2^16)
+__global__ __launch_bounds__(256) void k_narrow_counts(const uint32_t *__restrict__ in, int64_t n, uint16_t *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (uint16_t)in[i];
+}
+
 __global__ __launch_bounds__(256) void k_node_keys(const uint32_t *__restrict__ nodes, int64_t n, uint32_t *__restrict__ keys,
                                                    uint32_t *__restrict__ idx) {
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -658,7 +665,7 @@ int gki_index_build_range_grouped(const void *d_kmers, const void *d_nodes, cons
         int done = 0;
         GKI_TRY(gki_index_build_rows(d_kmers, d_nodes, d_ref_offsets, d_af32, n, modulo, bucket_begin, n_buckets, skip_frequencies,
                                      group_bits, h_group_start, nullptr, nullptr, d_hashes_to_index, d_n_kmers, d_out_kmers, d_out_nodes,
-                                     d_out_ref_offsets, d_out_af32, d_out_frequencies, d_out_permutation, &done));
+                                     d_out_ref_offsets, d_out_af32, d_out_frequencies, d_out_permutation, &done, 0));
         if (done) return GKI_OK;
     }
     return gki_index_build_pairs(d_kmers, d_nodes, d_ref_offsets, d_af32, n, modulo, bucket_begin, n_buckets, skip_frequencies,
@@ -735,7 +742,7 @@ int gki_index_build_range_from_rows(const void *d_rows, const void *d_keys, int6
     int done = 0;
     GKI_TRY(gki_index_build_rows(nullptr, nullptr, nullptr, nullptr, n, modulo, bucket_begin, n_buckets, skip_frequencies, group_bits,
                                  h_group_start, d_rows, d_keys, d_hashes_to_index, d_n_kmers, d_out_kmers, d_out_nodes,
-                                 d_out_ref_offsets, d_out_af32, d_out_frequencies, nullptr, &done));
+                                 d_out_ref_offsets, d_out_af32, d_out_frequencies, nullptr, &done, 0));
     if (!done)
         return gki_set_error(GKI_ERR_OUT_OF_DOMAIN, "the records are outside the row-carrying build's domain (a group of neighbouring buckets with "
                              "more than 2^22 records): build this slice from its columns (gki_index_build_range)");
@@ -806,6 +813,26 @@ int gki_reverse_index_build(const void *d_nodes, const void *d_kmers, const void
     if (n_nodes <= 0 || n_nodes > (1ll << 32)) return gki_set_error(GKI_ERR_BAD_ARG, "n_nodes must be in 1..2^32");
     if (n >= (1ll << 32)) return gki_set_error(GKI_ERR_OVERFLOW, "%lld records do not fit the uint32 directory", (long long)n);
     hipStream_t s = 0;
+    if (n > 0 && n < (1ll << 31) && n_nodes < (1ll << 32)) {
+        // the row-carrying form (gki_index_rows.hip) with the node id as the key: the payload travels with its key through the
+        // staged partition passes and the in-LDS finish leaves the node directory as it goes -- no gather, no separate
+        // directory passes (round 4; the pair-sorting form below stays for what lies outside its domain)
+        uint32_t *nk32 = nullptr;
+        HIP_TRY(gki_dev_malloc((void **)&nk32, (size_t)n_nodes * 4));
+        int done = 0;
+        int rc = gki_index_build_rows(d_kmers, d_nodes, d_ref_offsets, nullptr, n, 1, 0, (uint64_t)n_nodes, 1, 0, nullptr, nullptr, nullptr,
+                                      d_index_positions, nk32, d_out_kmers, nullptr, d_out_ref_offsets, nullptr, nullptr, nullptr, &done, 1);
+        if (rc == GKI_OK && done) {
+            hipLaunchKernelGGL(k_narrow_counts, dim3(stream_grid(n_nodes, 256)), dim3(256), 0, s, nk32, n_nodes, (uint16_t *)d_n_hashes);
+            hipError_t e = hipGetLastError();
+            hipError_t e2 = hipStreamSynchronize(s);
+            (void)gki_dev_free(nk32);
+            HIP_TRY(e); HIP_TRY(e2);
+            return GKI_OK;
+        }
+        (void)gki_dev_free(nk32);
+        if (rc != GKI_OK) return rc;
+    }
     HIP_TRY(hipMemsetAsync(d_index_positions, 0, (size_t)n_nodes * 4, s));      // reverse_kmer_index.py:53
     HIP_TRY(hipMemsetAsync(d_n_hashes, 0, (size_t)n_nodes * 2, s));             // :54
     if (n <= 0) { HIP_TRY(hipStreamSynchronize(s)); return GKI_OK; }

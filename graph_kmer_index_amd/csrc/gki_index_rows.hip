@@ -76,6 +76,7 @@ struct KeyRule {
     int n_parts;                            // > 0: key = owning part; part_begin[n_parts + 1] on the device
     float parts_per_bucket;                 //   n_parts / modulo: the part of bucket b is b * this, give or take one
     int parts_log2;                         //   >= 0: n_parts = 2^this, and part_begin[p] = (modulo * p) >> this needs no table
+    int by_node;                            // the key is the record's node id (ReverseKmerIndex): no k-mer arithmetic at all
     int sub_bits;                           // > 0 (with parts): key = part << sub_bits | the top sub_bits bits of the bucket's
     const uint32_t *part_begin;             //   offset in its part, i.e. (bucket - part_begin[part]) >> sub_shift[part]
     const uint32_t *sub_shift;              //   [n_parts] on the device
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
             w0[r] = valid[r] ? a.c_kmers[tile_base + e] : 0ull;
             w1[r] = valid[r] ? a.c_refs[tile_base + e] : 0ull;
             w2[r] = valid[r] ? ((uint64_t)a.c_nodes[tile_base + e] |
-                                ((uint64_t)(a.carry_index ? (uint32_t)(tile_base + e) : a.c_af[tile_base + e]) << 32)) : 0ull;
+                                ((uint64_t)(a.carry_index ? (uint32_t)(tile_base + e) : a.c_af ? a.c_af[tile_base + e] : 0u) << 32)) : 0ull;
         }
         stage_parts(a.rule, s_pb);
         for (int d = threadIdx.x; d < bins; d += THREADS) s_dbase[d] = a.dbase ? a.dbase[d] : 0;
@@ -327,7 +328,9 @@ __global__ __launch_bounds__(THREADS) void k_partition_rows(PartArgs a) {
 #pragma unroll
         for (int r = 0; r < RI; r++) {
             key[r] = 0u;
-            const uint32_t sort_key = valid[r] ? key_of(a.rule, s_pb, w0[r], &bad, &key[r]) : 0u;
+            uint32_t sort_key = 0u;
+            if (a.rule.by_node) { key[r] = valid[r] ? (uint32_t)w2[r] : 0u; sort_key = key[r]; }
+            else if (valid[r]) sort_key = key_of(a.rule, s_pb, w0[r], &bad, &key[r]);
             dig[r] = (sort_key >> a.shift) & mask;
         }
     }
@@ -488,7 +491,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_partition_rows_staged(PartArgs a
             w0[r] = valid[r] ? a.c_kmers[tile_base + e] : 0ull;
             w1[r] = valid[r] ? a.c_refs[tile_base + e] : 0ull;
             w2[r] = valid[r] ? ((uint64_t)a.c_nodes[tile_base + e] |
-                                ((uint64_t)(a.carry_index ? (uint32_t)(tile_base + e) : a.c_af[tile_base + e]) << 32)) : 0ull;
+                                ((uint64_t)(a.carry_index ? (uint32_t)(tile_base + e) : a.c_af ? a.c_af[tile_base + e] : 0u) << 32)) : 0ull;
         }
         stage_parts(a.rule, s_pb);
     } else {
@@ -515,7 +518,9 @@ __global__ __launch_bounds__(THREADS, 4) void k_partition_rows_staged(PartArgs a
 #pragma unroll
         for (int r = 0; r < RI; r++) {
             key[r] = 0u;
-            const uint32_t sort_key = valid[r] ? key_of(a.rule, s_pb, w0[r], &bad, &key[r]) : 0u;
+            uint32_t sort_key = 0u;
+            if (a.rule.by_node) { key[r] = valid[r] ? (uint32_t)w2[r] : 0u; sort_key = key[r]; }
+            else if (valid[r]) sort_key = key_of(a.rule, s_pb, w0[r], &bad, &key[r]);
             dig[r] = (sort_key >> a.shift) & mask;
         }
     }
@@ -843,9 +848,10 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_finish(FinishArgs a) {
         if (p < m) {
             const uint64_t km = s_kmer[p], rf = s_ref[p];
             const int64_t o = (int64_t)s + p;
-            a.o_kmers[o] = km; a.o_refs[o] = rf; a.o_nodes[o] = s_node[p];
+            a.o_kmers[o] = km; a.o_refs[o] = rf;
+            if (a.o_nodes) a.o_nodes[o] = s_node[p];             // (NULL node / allele-frequency / frequency columns: the reverse index)
             if (a.o_perm) { const uint32_t idx = s_af[p]; a.o_perm[o] = idx; a.o_af[o] = a.af_in[idx]; }
-            else a.o_af[o] = s_af[p];
+            else if (a.o_af) a.o_af[o] = s_af[p];
             uint32_t f = 0;
             if (!a.skip_frequencies) {
                 const uint32_t b = s_lk[p], c = s_cnt[b], b0 = WRANK ? s_pos[b] : s_pos[b] - c;
@@ -874,7 +880,7 @@ __global__ __launch_bounds__(GROUP_THREADS) void k_group_finish(FinishArgs a) {
                     if (at < a.big_cap) a.big_buckets[at] = (uint32_t)(gb + b);
                 }
             }
-            a.o_freq[o] = (uint16_t)f;
+            if (a.o_freq) a.o_freq[o] = (uint16_t)f;
         }
     }
 }
@@ -934,10 +940,11 @@ __global__ __launch_bounds__(256) void k_group_large(FinishArgs a, const uint32_
                     __builtin_amdgcn_wave_barrier();
                     if (before == 0) s_start[b] = slot + (uint32_t)__popcll(same);
                     const int64_t o = (int64_t)s + slot;
-                    a.o_kmers[o] = w0; a.o_refs[o] = w1; a.o_nodes[o] = (uint32_t)w2;
+                    a.o_kmers[o] = w0; a.o_refs[o] = w1;
+                    if (a.o_nodes) a.o_nodes[o] = (uint32_t)w2;
                     if (a.o_perm) { const uint32_t idx = (uint32_t)(w2 >> 32); a.o_perm[o] = idx; a.o_af[o] = a.af_in[idx]; }
-                    else a.o_af[o] = (uint32_t)(w2 >> 32);
-                    a.o_freq[o] = 0;
+                    else if (a.o_af) a.o_af[o] = (uint32_t)(w2 >> 32);
+                    if (a.o_freq) a.o_freq[o] = 0;
                 }
                 __syncthreads();
             }
@@ -1057,7 +1064,11 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
                          uint64_t modulo, uint64_t bucket_begin, uint64_t n_buckets, int skip_frequencies,
                          int group_bits, const int64_t *h_group_start, const void *d_rows_in, const void *d_keys_in,
                          void *d_hashes_to_index, void *d_n_kmers, void *d_out_kmers, void *d_out_nodes,
-                         void *d_out_ref_offsets, void *d_out_af32, void *d_out_frequencies, void *d_out_permutation, int *done) {
+                         void *d_out_ref_offsets, void *d_out_af32, void *d_out_frequencies, void *d_out_permutation, int *done,
+                         int by_node) {
+    // by_node: the key of a record is its node id and the "buckets" are the nodes (ReverseKmerIndex.from_flat_kmers,
+    // reverse_kmer_index.py:47-60: records stably sorted by node): modulo is unused, n_buckets = the number of nodes, the
+    // allele-frequency, node and frequency output columns may be NULL
     constexpr int THREADS = GKI_PT_THREADS, RI = GKI_PT_RI, TILE = THREADS * RI;
     *done = 0;
     hipStream_t s = 0;
@@ -1115,7 +1126,7 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
     int64_t *d_seg = nullptr;
     KeyRule rule;
     rule.mod = gki_mod_of(modulo); rule.bucket_begin = bucket_begin; rule.n_buckets = n_buckets; rule.n_parts = 0; rule.sub_bits = 0;
-    rule.part_begin = nullptr; rule.sub_shift = nullptr; rule.parts_per_bucket = 0.f; rule.parts_log2 = -1;
+    rule.part_begin = nullptr; rule.sub_shift = nullptr; rule.parts_per_bucket = 0.f; rule.parts_log2 = -1; rule.by_node = by_node;
     int rc = GKI_OK;
 #define HIP_G(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = gki_set_error(GKI_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); goto done; } } while (0)
     {
@@ -1151,7 +1162,10 @@ int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d
             const int64_t bins_n = ((int64_t)1 << bits) * n_tiles;
             const int xcd_tiles = (int)ceil_div(n_tiles, 8);
             const unsigned xgrid = (unsigned)(xcd_tiles * 8);
-            if (p == 0 && !from_rows)
+            if (p == 0 && by_node)
+                hipLaunchKernelGGL((k_digit_hist<THREADS, RI>), dim3(xgrid), dim3(THREADS), 0, s, (const uint32_t *)d_nodes, n, shift, bits,
+                                   hist, n_tiles, xcd_tiles, d_tiles);
+            else if (p == 0 && !from_rows)
                 hipLaunchKernelGGL((k_kmer_digit_hist<THREADS, RI>), dim3(xgrid), dim3(THREADS), 0, s, (const uint64_t *)d_kmers,
                                    n, rule, shift, bits, hist, n_tiles, xcd_tiles, d_tiles, (int *)(stats + 3));
             else
@@ -1311,7 +1325,7 @@ static int partition_columns_by_part(const void *d_kmers, const void *d_nodes, c
     KeyRule rule;
     rule.mod = gki_mod_of(modulo); rule.bucket_begin = 0; rule.n_buckets = modulo; rule.n_parts = n_parts; rule.sub_bits = sub_bits;
     rule.parts_per_bucket = (float)((double)n_parts / (double)modulo);
-    rule.parts_log2 = -1;
+    rule.parts_log2 = -1; rule.by_node = 0;
     for (int l = 0; l <= 8; l++) if ((1 << l) == n_parts) rule.parts_log2 = l;
     int rc = GKI_OK;
 #define HIP_G(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = gki_set_error(GKI_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); goto done; } } while (0)
