@@ -11,6 +11,8 @@
 // Inside a bucket records keep their input order (stable sort), which is also what the oracle's
 // stable restatement produces, so the build is comparable element by element.
 #include "gki_common.h"
+#include <cstring>
+#include <cstdlib>
 #include <mutex>
 
 int gki_index_build_rows(const void *d_kmers, const void *d_nodes, const void *d_ref_offsets, const void *d_af32, int64_t n,
@@ -813,7 +815,10 @@ int gki_reverse_index_build(const void *d_nodes, const void *d_kmers, const void
     if (n_nodes <= 0 || n_nodes > (1ll << 32)) return gki_set_error(GKI_ERR_BAD_ARG, "n_nodes must be in 1..2^32");
     if (n >= (1ll << 32)) return gki_set_error(GKI_ERR_OVERFLOW, "%lld records do not fit the uint32 directory", (long long)n);
     hipStream_t s = 0;
-    if (n > 0 && n < (1ll << 31) && n_nodes < (1ll << 32)) {
+    // GKI_REVERSE_FORM=pairs (read per call): the pair-sorting form, for the parity tests of the path behind the row form
+    const char *form = getenv("GKI_REVERSE_FORM");
+    const bool pairs_only = form && strcmp(form, "pairs") == 0;
+    if (!pairs_only && n > 0 && n < (1ll << 31) && n_nodes < (1ll << 32)) {
         // the row-carrying form (gki_index_rows.hip) with the node id as the key: the payload travels with its key through the
         // staged partition passes and the in-LDS finish leaves the node directory as it goes -- no gather, no separate
         // directory passes (round 4; the pair-sorting form below stays for what lies outside its domain)

@@ -280,8 +280,13 @@ def test_reverse_index_reference_known_answer(tmp_path):
         r.get_node_kmers_and_ref_positions(9)
 
 
-@pytest.mark.parametrize("n,n_nodes,seed", [(1, 1, 0), (5000, 70, 1), (300000, 100000, 2), (200000, 3, 3)])
-def test_reverse_index_random_vs_numpy(n, n_nodes, seed):
+@pytest.mark.parametrize("form", ["rows", "pairs"])
+@pytest.mark.parametrize("n,n_nodes,seed", [(1, 1, 0), (5000, 70, 1), (300000, 100000, 2), (200000, 3, 3), (3000, 5000000, 4),
+                                            (2000000, 1500, 5)])
+def test_reverse_index_random_vs_numpy(n, n_nodes, seed, form, monkeypatch):
+    # form: the row-carrying build with key = node id (the default), and the pair-sorting form that stays behind it
+    # (GKI_REVERSE_FORM is read by the library per call)
+    monkeypatch.setenv("GKI_REVERSE_FORM", form)
     rng = np.random.default_rng(seed)
     nodes = rng.integers(0, n_nodes, size=n).astype(np.uint32)
     kmers = rng.integers(0, 4 ** 31, size=n, dtype=np.uint64)
