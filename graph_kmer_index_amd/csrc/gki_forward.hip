@@ -40,17 +40,36 @@ __device__ __forceinline__ void put_record(const FwdOut &out, int64_t idx, uint6
 // gki_graph::fwd_script between gki_forward_count and the gki_forward_emit call with the same arguments; any other emit
 // call, the slow path for deep windows, or no memory for the script (192 B per start position) mean the emit pass walks.
 // Measured, 1.14e7 start positions on the 1 Gbp graph, alternating on one box (profiles/r03_forward_script_ab.txt):
-// all-nodes mode 4.16 -> 3.73 ms, and 3.75 -> 3.21 ms with short_path_facts below; one node per k-mer 2.98 -> 3.06 ms,
-// so gki_forward_count writes a script in all-nodes mode only.
+// all-nodes mode 4.16 -> 3.73 ms, and 3.75 -> 3.21 ms with short_path_facts below; one node per k-mer 2.98 -> 3.06 ms
+// with round 3's layout of the script.  With round 4's (below) both modes take it: 3 Gbp graph, 3.43e7 start positions,
+// all nodes 8.1 -> 6.2 ms, one node per k-mer 6.7 -> 5.1 ms (profiles/r04_forward_script_layout_ab.txt).
 #ifndef GKI_FWD_SCRIPT
 #define GKI_FWD_SCRIPT 1
 #endif
+// Layout (GKI_FWD_SCRIPT_SOA, round 4): the three 16-byte pieces of slot c of start position i lie at
+// [(c * 3 + piece) * n_pos + i] -- the lanes of a wave (neighbouring start positions, mostly in step) write a piece of
+// their c-th k-mer into consecutive 16-byte cells, whole lines per store instruction, and slots nobody uses are lines nobody
+// touches.  (Rounds 3-4 had the four 48-byte entries of a start position side by side, 192 B apart from lane to lane: 64
+// partly written lines per store instruction, and the script's 100 written bytes per start position cost the count pass
+// 1.9 ms on top of a 2.9 ms walk.)  =0 rebuilds that layout.
+#ifndef GKI_FWD_SCRIPT_ONE
+#define GKI_FWD_SCRIPT_ONE 1
+#endif
+#ifndef GKI_FWD_SCRIPT_SOA
+#define GKI_FWD_SCRIPT_SOA 1
+#endif
 constexpr int FW_SLOTS = 4, FW_SN = 5, FW_ENTRY_U4 = 3;
-__device__ __forceinline__ void script_write(uint4 *e, uint64_t h, double maf, int32_t q, int off, int lw, uint32_t first, const int32_t *nodes) {
+// cell of (start position i, slot c, piece p) in units of uint4
+__device__ __forceinline__ size_t script_cell(int64_t i, int c, int p, int64_t n_pos) {
+    return GKI_FWD_SCRIPT_SOA ? (size_t)(c * FW_ENTRY_U4 + p) * (size_t)n_pos + (size_t)i
+                              : ((size_t)i * FW_SLOTS + (size_t)c) * FW_ENTRY_U4 + (size_t)p;
+}
+__device__ __forceinline__ void script_write(uint4 *script, int64_t i, int c, int64_t n_pos, uint64_t h, double maf, int32_t q, int off, int lw,
+                                             uint32_t first, const int32_t *nodes) {
     const uint64_t mb = (uint64_t)__double_as_longlong(maf);
-    e[0] = make_uint4((uint32_t)h, (uint32_t)(h >> 32), (uint32_t)mb, (uint32_t)(mb >> 32));
-    e[1] = make_uint4((uint32_t)q, ((uint32_t)off & 0xFFFFu) | ((uint32_t)lw << 16), first, (uint32_t)nodes[0]);
-    e[2] = make_uint4((uint32_t)nodes[1], (uint32_t)nodes[2], (uint32_t)nodes[3], (uint32_t)nodes[4]);
+    script[script_cell(i, c, 0, n_pos)] = make_uint4((uint32_t)h, (uint32_t)(h >> 32), (uint32_t)mb, (uint32_t)(mb >> 32));
+    script[script_cell(i, c, 1, n_pos)] = make_uint4((uint32_t)q, ((uint32_t)off & 0xFFFFu) | ((uint32_t)lw << 16), first, (uint32_t)nodes[0]);
+    if (lw > 1) script[script_cell(i, c, 2, n_pos)] = make_uint4((uint32_t)nodes[1], (uint32_t)nodes[2], (uint32_t)nodes[3], (uint32_t)nodes[4]);
 }
 
 // The nodes of a finished path over at most FW_SN nodes, their smallest id, their minimum allele frequency, and whether
@@ -112,7 +131,7 @@ constexpr int FW_BUDGET = 1 << 22, FW_BUDGET_FROM = 8;     // (every step of thi
 template <bool EMIT, bool DEEP, bool SCRIPT>
 __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, const uint8_t *__restrict__ follow,
                              int32_t n0, int32_t o0, int64_t idx, FwdOut out, uint32_t *count_out, int *err,
-                             const DeepArena &da, int64_t lane_global, uint4 *script, uint32_t *used_out) {
+                             const DeepArena &da, int64_t lane_global, uint4 *script, int64_t pos, int64_t n_pos, uint32_t *used_out) {
     static_assert(!SCRIPT || (!EMIT && !DEEP), "the script is written by the product count kernel");
     uint32_t used = 0;                        // SCRIPT: entries written, 0xFF = this start position does not fit
     // per level: the node, its successor range (cur .. end), the hash so far, and ONE word for the bases collected (8 bits),
@@ -163,7 +182,7 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
         }
         if (SCRIPT) {
             const int32_t one[FW_SN] = {n0, 0, 0, 0, 0};
-            script_write(script, h0, g.allele_freq[n0], n0, o0 + k - 1, 1, 0u, one);
+            script_write(script, pos, 0, n_pos, h0, g.allele_freq[n0], n0, o0 + k - 1, 1, 0u, one);
             *used_out = 1;
         }
         *count_out = 1;
@@ -254,7 +273,7 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
 #pragma unroll
                             for (int r = 0; r < FW_SN; r++) ns[r] = r < Lw ? v[r] : 0;
                         }
-                        script_write(script + (size_t)used * FW_ENTRY_U4, hL, maf, q, t - 1, one_node ? 1 : Lw, count, ns);
+                        script_write(script, pos, (int)used, n_pos, hL, maf, q, t - 1, one_node ? 1 : Lw, count, ns);
                         used++;
                     }
                 }
@@ -302,7 +321,7 @@ __global__ __launch_bounds__(64, DEEP ? 1 : 8) void k_forward(DevGraph g, int k,
         const int32_t n0 = nodes[i];
         if (n0 < 0 || n0 >= g.n_nodes) { if (!EMIT) cnt[i] = 0; if (SCRIPT) used[i] = 0; continue; }
         forward_walk<EMIT, DEEP, SCRIPT>(g, k, M, one_node != 0, follow, n0, offsets[i], EMIT ? rec_start[i] : 0, out, &c, err, da, lane_global,
-                                         SCRIPT ? script + (size_t)i * (FW_SLOTS * FW_ENTRY_U4) : nullptr, &u);
+                                         script, i, n_pos, &u);
         if (!EMIT) cnt[i] = c;
         if (SCRIPT) { used[i] = (uint8_t)u; if (u == 0xFFu) atomicAdd(err + 1, 1); }
     }
@@ -328,10 +347,11 @@ __global__ __launch_bounds__(256) void k_forward_expand(const uint4 *__restrict_
     if (i < n_pos) {
         const uint32_t n = used[i];
         if (n != 0xFFu && (uint32_t)c < n) {
-            const uint4 a = script[tid * FW_ENTRY_U4], b = script[tid * FW_ENTRY_U4 + 1], d = script[tid * FW_ENTRY_U4 + 2];
-            s_e[wave][lane][0] = a; s_e[wave][lane][1] = b; s_e[wave][lane][2] = d;
-            s_idx[wave][lane] = rec_start[i] + (int64_t)b.z;
+            const uint4 a = script[script_cell(i, c, 0, n_pos)], b = script[script_cell(i, c, 1, n_pos)];
             lw = (int)((b.y >> 16) & 0xFFu);
+            s_e[wave][lane][0] = a; s_e[wave][lane][1] = b;
+            if (lw > 1) s_e[wave][lane][2] = script[script_cell(i, c, 2, n_pos)];       // (a one-record entry has no third piece)
+            s_idx[wave][lane] = rec_start[i] + (int64_t)b.z;
         }
     }
     const int incl = gki_wave_incl_sum(lw);
@@ -405,7 +425,7 @@ int gki_forward_count(gki_graph *gr, int k, int max_variant_nodes, int one_node,
     // the script for the emit call (see FW_SLOTS above); without memory for it the emit call walks as it always did
     script_drop(gr);
     FwdScript &sc = gr->fwd_script;
-    if (GKI_FWD_SCRIPT && !one_node) {      // (one node per k-mer: 2.98 -> 3.06 ms with the script, it stays out of that mode)
+    if (GKI_FWD_SCRIPT && (!one_node || GKI_FWD_SCRIPT_ONE)) {
         if (gki_dev_malloc(&sc.entries, (size_t)n_pos * FW_SLOTS * FW_ENTRY_U4 * 16) != hipSuccess ||
             gki_dev_malloc((void **)&sc.ncomp, (size_t)n_pos) != hipSuccess) { (void)hipGetLastError(); script_drop(gr); }
     }
