@@ -77,6 +77,20 @@ struct alignas(32) NodeWalk { // everything the boundary walk needs about a node
 };
 static_assert(sizeof(NodeWalk) == 32, "NodeWalk is one 32-byte record");
 
+// The early-stop search's view of a node (csrc/gki_forward.hip): one aligned 32-byte record holds everything a forward step
+// onto the node needs -- its first bases, its allele frequency, and its successors when there are at most two -- so a
+// descent is ONE record instead of the walk record, two sequence words, two edge offsets and an edge.
+struct alignas(32) NodeFwd {
+    uint64_t head;           // the node's first min(size, 31) bases, 2 bits each, the first of them least significant
+    double af;               // allele frequency (float64, as the finder reports it)
+    int32_t size;
+    int32_t e0;              // cnt == 1, 2: the first successor itself; cnt > 2: the index of the first successor in edges
+    int32_t e1;              // cnt == 2: the second successor
+    uint16_t cnt;            // number of successors (0xFFFF: 65535 or more, see edge_start)
+    uint8_t is_ref, pad;
+};
+static_assert(sizeof(NodeFwd) == 32, "NodeFwd is one 32-byte record");
+
 struct DevGraph {
     int64_t n_nodes, n_bases, n_words64;     // n_words64 = ceil(n_bases / 64): one bitmap word per 64 bases
     const int32_t *node_size;
@@ -122,6 +136,7 @@ struct FwdScript {
     void *entries;                           // [n_pos][FW_SLOTS] 48-byte entries
     uint8_t *ncomp;                          // [n_pos] entries in use, 0xFF: the start position did not fit, walk it again
     int64_t n_pos, overflow;
+    int64_t *over_list; int64_t over_cap;    // the start positions that did not fit (the first over_cap of them), for the emit pass
     const void *nodes, *offsets, *follow, *rec_start;
     int k, M, one_node, valid;
 };
@@ -138,6 +153,7 @@ struct gki_graph {
     DeepArena fwd_deep;                      // early-stop search: arena of its slow path, cap > 0 after a count call that needed it
     int64_t fwd_deep_bytes;
     FwdScript fwd_script;                    // early-stop search: what the count call left for the emit call (csrc/gki_forward.hip)
+    NodeFwd *fwd_nodes;                      // early-stop search: its per-node records, built by the first search after a prepare
 };
 
 // GKI_ERR_BAD_ARG unless the device that is current is the one the graph was uploaded to (gki_finder.hip)

@@ -10,7 +10,10 @@
 #include <math.h>
 
 namespace {
-constexpr int FMAX = GKI_MAX_WINDOW_NODES;
+#ifndef GKI_FWD_LEVELS
+#define GKI_FWD_LEVELS GKI_MAX_WINDOW_NODES
+#endif
+constexpr int FMAX = GKI_FWD_LEVELS;
 
 struct FwdOut { int64_t *hash; int32_t *start_node; int16_t *start_offset; int32_t *node; double *af; };
 
@@ -72,34 +75,6 @@ __device__ __forceinline__ void script_write(uint4 *script, int64_t i, int c, in
     if (lw > 1) script[script_cell(i, c, 2, n_pos)] = make_uint4((uint32_t)nodes[1], (uint32_t)nodes[2], (uint32_t)nodes[3], (uint32_t)nodes[4]);
 }
 
-// The nodes of a finished path over at most FW_SN nodes, their smallest id, their minimum allele frequency, and whether
-// the ids ascend.  A loop over the path is a chain of 2 x Lw dependent round trips (the level's node from the stack, then
-// its allele frequency); here the FW_SN stack slots are read at fixed indices and the FW_SN allele frequencies loaded side
-// by side -- two round trips whatever Lw is.  Slots beyond the path hold stale levels: replaced by the first node before
-// anything is indexed with them.
-// (the levels below the finished one come from the stack -- the low word of its (node, meta) entries --, the finished level's
-// node q is still in a register: nothing is stored for a level that ends its path)
-template <class NS>
-__device__ __forceinline__ bool short_path_facts(const DevGraph &g, NS &nm, int Lw, int32_t q, int32_t (&v)[FW_SN], int32_t &mn, double &maf) {
-#pragma unroll
-    for (int r = 0; r < FW_SN; r++) v[r] = (int32_t)(uint32_t)nm[r];
-#pragma unroll
-    for (int r = 0; r < FW_SN; r++) if (r == Lw - 1) v[r] = q;
-#pragma unroll
-    for (int r = 1; r < FW_SN; r++) if (r >= Lw) v[r] = v[0];
-    double f[FW_SN];
-#pragma unroll
-    for (int r = 0; r < FW_SN; r++) f[r] = g.allele_freq[v[r]];
-    mn = v[0]; maf = fmin((double)INFINITY, f[0]);
-    bool asc = true;
-#pragma unroll
-    for (int r = 1; r < FW_SN; r++) {
-        mn = v[r] < mn ? v[r] : mn; maf = fmin(maf, f[r]);
-        if (r < Lw) asc = asc && v[r] > v[r - 1];
-    }
-    return asc;
-}
-
 // only_follow_nodes (kmer_finder.py:386-388): when a node has successors in the follow set, only those are taken
 // and the variant limit is waived for that step.
 __device__ __forceinline__ bool any_followed(const DevGraph &g, const uint8_t *__restrict__ follow, int32_t node) {
@@ -119,35 +94,86 @@ __device__ __forceinline__ void check_one_ref_successor(const DevGraph &g, int32
 }
 
 // byte offset of every per-level array of the walk inside one (level, lane) cell of the slow path's arena (DeepArena)
-enum { FW_NM = 0, FW_CE = 8, FW_HS = 16, FW_LAST = 24, FW_CELL = 28 };
+enum { FW_NM = 0, FW_CE = 8, FW_HS = 16, FW_MF = 24, FW_LAST = 32, FW_CELL = 36 };
 // A path that has not reached its first k-mer after this many descents below level FW_BUDGET_FROM belongs to an
 // exponential family (a run of insertion sites with no variant limit to cut it): the search from that position is wound
 // up and the call refused, as in the finder (csrc/gki_finder.hip, STEP_BUDGET).
 constexpr int FW_BUDGET = 1 << 22, FW_BUDGET_FROM = 8;     // (every step of this walk reads global memory: ~1 us each)
 
-// DEEP = false: the product kernel, FMAX levels per lane in scratch.  DEEP = true: the slow path for forward windows over
-// more nodes than that (sixteen or more empty nodes before the first k-mer is complete), the same walk with its levels
-// in a global-memory arena of da.cap levels per lane (gki_forward_count grows it until the walk fits).
+// The walk's levels: the first GKI_FWD_REG_LEVELS of them in registers (a read is a select over R values, a write R
+// predicated moves), the rest in the stack behind (scratch; the slow path's arena).  A forward path of the usual search --
+// the start node, an allele, the node that completes the k-mer, which is never stored -- lives in two levels, so the
+// product kernel touches no scratch at all for it (rounds 2-4 kept every level in scratch: three stores per descent and
+// two loads per turn of the loop, each a trip to L2 -- a wave's levels do not fit L1 beside its neighbours').
+#ifndef GKI_FWD_REG_LEVELS
+#define GKI_FWD_REG_LEVELS 2
+#endif
+// (the register levels are a variable of their own, apart from the stack behind them: one aggregate holding both is one
+// stack object to the compiler, and the dynamically indexed part keeps the whole of it in scratch)
+template <class T, int R> struct RegLevels { T r[R > 0 ? R : 1]; };
+template <class T, int R, class ST> __device__ __forceinline__ T lv_get(const RegLevels<T, R> &rg, ST &st, int j) {
+    if (R > 0 && j < R) {
+        T v = rg.r[0];
+#pragma unroll
+        for (int i = 1; i < R; i++) if (j == i) v = rg.r[i];
+        return v;
+    }
+    return st[j];
+}
+template <class T, int R, class ST> __device__ __forceinline__ void lv_set(RegLevels<T, R> &rg, ST &st, int j, T v) {
+    if (R > 0 && j < R) {
+#pragma unroll
+        for (int i = 0; i < R; i++) if (j == i) rg.r[i] = v;
+    } else st[j] = v;
+}
+
+// A node's record in two 16-byte loads (field by field the compiler asks for it in four)
+__device__ __forceinline__ NodeFwd fwd_node(const NodeFwd *__restrict__ fw, int32_t n) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(fw + n);
+    const uint4 a = p[0], b = p[1];
+    NodeFwd w;
+    w.head = (uint64_t)a.x | ((uint64_t)a.y << 32);
+    w.af = __longlong_as_double((long long)((uint64_t)a.z | ((uint64_t)a.w << 32)));
+    w.size = (int32_t)b.x; w.e0 = (int32_t)b.y; w.e1 = (int32_t)b.z;
+    w.cnt = (uint16_t)(b.w & 0xFFFFu); w.is_ref = (uint8_t)((b.w >> 16) & 0xFFu); w.pad = 0;
+    return w;
+}
+
+// Successors of a node as the level's (cur, end) pair.  end >= 0: cur .. end index g.edges.  end < 0: the successors are in
+// the pair itself (NodeFwd: at most two) -- cur is the next one, or -1 when there is none left, and ~end the one after it
+// (INT_MIN: none).
+#define FW_CE(cur_, end_) ((uint64_t)(uint32_t)(cur_) | ((uint64_t)(uint32_t)(end_) << 32))
+__device__ __forceinline__ uint64_t succ_begin(const DevGraph &g, const NodeFwd &w, int32_t n) {
+    if (w.cnt == 0) return FW_CE(-1, INT_MIN);
+    if (w.cnt == 1) return FW_CE(w.e0, INT_MIN);
+    if (w.cnt == 2) return FW_CE(w.e0, ~w.e1);
+    return FW_CE(w.e0, w.cnt == 0xFFFF ? (int32_t)g.edge_start[n + 1] : w.e0 + (int32_t)w.cnt);
+}
+
+// DEEP = false: the product kernel, its levels in registers and, beyond those, FMAX levels per lane in scratch.  DEEP = true:
+// the slow path for forward windows over more nodes than that (sixteen or more empty nodes before the first k-mer is
+// complete), the same walk with its levels in a global-memory arena of da.cap levels per lane (gki_forward_count grows it
+// until the walk fits).
 template <bool EMIT, bool DEEP, bool SCRIPT>
-__device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, const uint8_t *__restrict__ follow,
+__device__ void forward_walk(const DevGraph &g, const NodeFwd *__restrict__ fw, int k, int M, bool one_node, const uint8_t *__restrict__ follow,
                              int32_t n0, int32_t o0, int64_t idx, FwdOut out, uint32_t *count_out, int *err,
                              const DeepArena &da, int64_t lane_global, uint4 *script, int64_t pos, int64_t n_pos, uint32_t *used_out) {
     static_assert(!SCRIPT || (!EMIT && !DEEP), "the script is written by the product count kernel");
+    constexpr int R = DEEP ? 0 : GKI_FWD_REG_LEVELS;
     uint32_t used = 0;                        // SCRIPT: entries written, 0xFF = this start position does not fit
-    // per level: the node, its successor range (cur .. end), the hash so far, and ONE word for the bases collected (8 bits),
-    // "forced traversal" (8 bits) and the variant nodes on the path (16 bits) -- three separate arrays were three scratch
-    // stores per descent and three loads per turn; `last` (forced traversal only) is touched only when a follow set is given
-    // Three 64-bit words per level -- (node, meta), (cur, end), the hash so far -- where rounds 2-3 kept eight arrays: every
-    // descent was eight scratch stores and every turn of the loop five scratch loads; now three and two, and the level that
-    // completes a k-mer (every path's last) stores nothing at all.  3 Gbp graph, 3.43e7 start positions, same box:
-    // all-nodes 7.97 -> 7.39 ms with the meta word alone (profiles/r04_forward_packed_levels_ab.txt).
+    // Per level four 64-bit words: (node, meta) with meta = bases collected (8 bits) | "forced traversal" (8) | variant
+    // nodes on the path (16); the successors still to take (cur, end); the hash so far; the smallest allele frequency on the
+    // path so far (it comes with the node's record, so a finished k-mer asks for nothing).  The level that completes a k-mer
+    // (every path's last) is never stored.  `last` (forced traversal only) is touched only when a follow set is given.
     typename StackOf<int32_t, FMAX, DEEP>::type last;
-    typename StackOf<uint64_t, FMAX, DEEP>::type nm, ce, hs;
-    bind(nm, da, FW_NM, lane_global); bind(ce, da, FW_CE, lane_global); bind(hs, da, FW_HS, lane_global);
-    bind(last, da, FW_LAST, lane_global);
+    typename StackOf<uint64_t, FMAX, DEEP>::type nm_st, ce_st, hs_st;
+    typename StackOf<double, FMAX, DEEP>::type mf_st;
+    RegLevels<uint64_t, R> nm_r, ce_r, hs_r;
+    RegLevels<double, R> mf_r;
+    bind(nm_st, da, FW_NM, lane_global); bind(ce_st, da, FW_CE, lane_global); bind(hs_st, da, FW_HS, lane_global);
+    bind(mf_st, da, FW_MF, lane_global); bind(last, da, FW_LAST, lane_global);
 #define FW_NODE_OF(x_) ((int32_t)(uint32_t)(x_))
 #define FW_META_OF(x_) ((uint32_t)((x_) >> 32))
-#define FW_CE(cur_, end_) ((uint64_t)(uint32_t)(cur_) | ((uint64_t)(uint32_t)(end_) << 32))
 #define FW_MK(have_, forced_, vc_) ((uint32_t)(have_) | ((uint32_t)(forced_) << 8) | ((uint32_t)(vc_) << 16))
 #define FW_HAVE_OF(m_) ((int)((m_) & 0xFFu))
 #define FW_FORCED_OF(m_) ((int)(((m_) >> 8) & 0xFFu))
@@ -155,21 +181,24 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
     const int cap = DEEP ? da.cap : FMAX;
     int steps_left = FW_BUDGET;
     uint32_t count = 0;
-    const NodeWalk w0 = g.walk[n0];
+    const NodeFwd w0 = fwd_node(fw, n0);
     if (o0 < 0 || o0 > w0.size) { *count_out = 0; if (SCRIPT) *used_out = 0; return; }
     // level 0: the start node from offset o0 (an empty start node contributes no base)
     int L = 0, have0 = 0;
     uint64_t h0 = 0;
+    const double maf0 = fmin((double)INFINITY, w0.af);
     {
         const int avail = w0.size - o0;
         const int t = avail < k ? avail : k;
-        const int vc0 = w0.is_ref ? 0 : 1, forced0 = any_followed(g, follow, n0) ? 1 : 0;
-        h0 = t > 0 ? gki_extract(g.seq2, w0.seq_start + o0, t) : 0ull;
+        // (the start node's bases from o0: inside its first 31 they are in the record, else two words of the sequence)
+        if (t > 0) h0 = o0 + t <= 31 ? (w0.head >> (2 * o0)) & ((1ull << (2 * t)) - 1ull) : gki_extract(g.seq2, g.seq_start[n0] + o0, t);
         have0 = t;
         if (t < k) {                           // (t == k: window complete inside the start node, handled below)
-            nm[0] = (uint64_t)(uint32_t)n0 | ((uint64_t)FW_MK(t, forced0, vc0) << 32);
-            hs[0] = h0;
-            ce[0] = FW_CE((int32_t)g.edge_start[n0], (int32_t)g.edge_start[n0 + 1]);
+            const int vc0 = w0.is_ref ? 0 : 1, forced0 = any_followed(g, follow, n0) ? 1 : 0;
+            lv_set(nm_r, nm_st, 0, (uint64_t)(uint32_t)n0 | ((uint64_t)FW_MK(t, forced0, vc0) << 32));
+            lv_set(hs_r, hs_st, 0, h0);
+            lv_set(mf_r, mf_st, 0, maf0);
+            lv_set(ce_r, ce_st, 0, forced0 ? FW_CE((int32_t)g.edge_start[n0], (int32_t)g.edge_start[n0 + 1]) : succ_begin(g, w0, n0));
             if (follow) last[0] = INT_MIN;
             L = 1;
             if (!EMIT && !forced0 && vc0 >= M) check_one_ref_successor(g, n0, err);
@@ -178,11 +207,11 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
     // completion inside the start node
     if (have0 == k) {
         if (EMIT) {
-            put_record<false>(out, idx, h0, n0, o0 + k - 1, n0, g.allele_freq[n0]);
+            put_record<false>(out, idx, h0, n0, o0 + k - 1, n0, w0.af);
         }
         if (SCRIPT) {
             const int32_t one[FW_SN] = {n0, 0, 0, 0, 0};
-            script_write(script, pos, 0, n_pos, h0, g.allele_freq[n0], n0, o0 + k - 1, 1, 0u, one);
+            script_write(script, pos, 0, n_pos, h0, w0.af, n0, o0 + k - 1, 1, 0u, one);
             *used_out = 1;
         }
         *count_out = 1;
@@ -190,10 +219,10 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
     }
     while (L > 0) {
         const int j = L - 1;
-        const uint64_t cej = ce[j];
+        const uint64_t cej = lv_get(ce_r, ce_st, j);
         const int32_t curj = (int32_t)(uint32_t)cej, endj = (int32_t)(uint32_t)(cej >> 32);
-        if (curj >= endj) { L--; continue; }
-        const uint64_t nmj = nm[j];
+        if (endj >= 0 ? curj >= endj : curj < 0) { L--; continue; }
+        const uint64_t nmj = lv_get(nm_r, nm_st, j);
         const uint32_t mj = FW_META_OF(nmj);
         int32_t q;
         if (FW_FORCED_OF(mj)) {
@@ -202,51 +231,64 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
             // [8, 7]): among SEVERAL forced successors of one node the reference's order is an accident of the
             // interpreter and is not reproduced.  They are taken in ascending id here (deterministic); parity for
             // such nodes is on the multiset of records.  last[j] is the latest forced successor taken.
+            // (a forced level's (cur, end) always index g.edges)
             q = INT_MAX;
             for (int32_t e = (int32_t)g.edge_start[FW_NODE_OF(nmj)]; e < endj; e++) {
                 const int32_t c = g.edges[e];
                 if (follow[c] && c > last[j] && c < q) q = c;
             }
-            if (q == INT_MAX) { ce[j] = FW_CE(endj, endj); continue; }
+            if (q == INT_MAX) { lv_set(ce_r, ce_st, j, FW_CE(endj, endj)); continue; }
             last[j] = q;
+        } else if (endj < 0) {
+            q = curj;
+            lv_set(ce_r, ce_st, j, endj == INT_MIN ? FW_CE(-1, INT_MIN) : FW_CE(~endj, INT_MIN));
         } else {
             q = g.edges[curj];
-            ce[j] = FW_CE(curj + 1, endj);
+            lv_set(ce_r, ce_st, j, FW_CE(curj + 1, endj));
         }
-        const NodeWalk wq = g.walk[q];
+        const NodeFwd wq = fwd_node(fw, q);
         if (FW_FORCED_OF(mj)) {
         } else if (FW_VC_OF(mj) >= M && !wq.is_ref) {
             continue;                                                   // :397-403 only the linear-ref successor
         }
         if (L >= cap - 1) { gki_raise(err, GKI_ERR_WINDOW_TOO_DEEP); continue; }
         const int hv = FW_HAVE_OF(mj);
-        const int t = wq.size < k - hv ? wq.size : k - hv;
+        const int t = wq.size < k - hv ? wq.size : k - hv;              // (t <= 31 - hv: the record's head holds these bases)
         const int vcL = FW_VC_OF(mj) + (wq.is_ref ? 0 : 1);
-        const uint64_t hL = hs[j] | (t > 0 ? gki_extract(g.seq2, wq.seq_start, t) << (2 * hv) : 0ull);
-        auto node_at = [&](int i) -> int32_t { return i == L ? q : FW_NODE_OF(nm[i]); };      // (level L itself is not stored)
+        const uint64_t hL = lv_get(hs_r, hs_st, j) | (t > 0 ? (wq.head & ((1ull << (2 * t)) - 1ull)) << (2 * hv) : 0ull);
+        const double mafL = fmin(lv_get(mf_r, mf_st, j), wq.af);
+        auto node_at = [&](int i) -> int32_t { return i == L ? q : FW_NODE_OF(lv_get(nm_r, nm_st, i)); };      // (level L itself is not stored)
         if (hv + t == k) {                          // first k-mer of this path: emit and stop (early stop, :326-330)
             const int Lw = L + 1;
+            // the path's nodes when there are at most FW_SN of them (slots beyond the path: 0), whether their ids ascend, and
+            // the smallest of them
+            int32_t v[FW_SN] = {0, 0, 0, 0, 0}; int32_t mn = q;
+            bool asc = true;
+            const bool short_path = Lw <= FW_SN;
+            if (short_path) {
+#pragma unroll
+                for (int r = 0; r < FW_SN; r++) v[r] = r < L ? FW_NODE_OF(lv_get(nm_r, nm_st, r)) : r == L ? q : 0;
+#pragma unroll
+                for (int r = 0; r < FW_SN; r++) if (r < L) mn = v[r] < mn ? v[r] : mn;
+#pragma unroll
+                for (int r = 1; r < FW_SN; r++) if (r < Lw) asc = asc && v[r] > v[r - 1];
+            } else {
+                for (int i = 0; i < L; i++) { const int32_t ni = node_at(i); mn = ni < mn ? ni : mn; }
+                if (!one_node) for (int i = 1; i < Lw; i++) asc = asc && node_at(i) > node_at(i - 1);
+            }
             if (EMIT) {
-                int32_t v[FW_SN]; int32_t mn = INT_MAX; double maf = INFINITY;
-                bool asc = true;
-                const bool short_path = Lw <= FW_SN;
-                if (short_path) asc = short_path_facts(g, nm, Lw, q, v, mn, maf);
-                else {
-                    for (int i = 0; i < Lw; i++) { const int32_t ni = node_at(i); mn = ni < mn ? ni : mn; maf = fmin(maf, g.allele_freq[ni]); }
-                    if (!one_node) for (int i = 1; i < Lw; i++) asc = asc && node_at(i) > node_at(i - 1);
-                }
                 if (one_node) {
-                    put_record<true>(out, idx, hL, q, t - 1, mn, maf); idx++;
+                    put_record<true>(out, idx, hL, q, t - 1, mn, mafL); idx++;
                 } else if (asc) {
                     // one record per distinct node, ascending (np.unique, kmer_finder.py:134).  Node ids usually grow along
                     // a forward path: then the path is the order (one pass instead of a selection per record)
                     if (short_path) {
 #pragma unroll
                         for (int r = 0; r < FW_SN; r++)
-                            if (r < Lw) { put_record<false>(out, idx, hL, q, t - 1, v[r], maf); idx++; }
+                            if (r < Lw) { put_record<false>(out, idx, hL, q, t - 1, v[r], mafL); idx++; }
                     } else {
                         for (int r = 0; r < Lw; r++) {
-                            put_record<false>(out, idx, hL, q, t - 1, node_at(r), maf); idx++;
+                            put_record<false>(out, idx, hL, q, t - 1, node_at(r), mafL); idx++;
                         }
                     }
                 } else {
@@ -254,40 +296,27 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
                     for (int r = 0; r < Lw; r++) {
                         int32_t best = INT_MAX;
                         for (int i = 0; i < Lw; i++) { const int32_t ni = node_at(i); if (ni > last && ni < best) best = ni; }
-                        put_record<false>(out, idx, hL, q, t - 1, best, maf); idx++;
+                        put_record<false>(out, idx, hL, q, t - 1, best, mafL); idx++;
                         last = best;
                     }
                 }
             }
             if (SCRIPT && used != 0xFFu) {
-                bool fits = used < (uint32_t)FW_SLOTS && (one_node || Lw <= FW_SN);
+                const bool fits = used < (uint32_t)FW_SLOTS && (one_node || (short_path && asc));
                 if (fits) {
-                    int32_t v[FW_SN]; int32_t mn = INT_MAX; double maf = INFINITY;
-                    bool asc = true;
-                    if (Lw <= FW_SN) asc = short_path_facts(g, nm, Lw, q, v, mn, maf);
-                    else for (int i = 0; i < Lw; i++) { const int32_t ni = node_at(i); mn = ni < mn ? ni : mn; maf = fmin(maf, g.allele_freq[ni]); }   // (one node per k-mer)
-                    fits = one_node || asc;
-                    if (fits) {
-                        int32_t ns[FW_SN] = {mn, 0, 0, 0, 0};
-                        if (!one_node) {
-#pragma unroll
-                            for (int r = 0; r < FW_SN; r++) ns[r] = r < Lw ? v[r] : 0;
-                        }
-                        script_write(script, pos, (int)used, n_pos, hL, maf, q, t - 1, one_node ? 1 : Lw, count, ns);
-                        used++;
-                    }
-                }
-                if (!fits) used = 0xFFu;
+                    if (one_node) v[0] = mn;
+                    script_write(script, pos, (int)used, n_pos, hL, mafL, q, t - 1, one_node ? 1 : Lw, count, v);
+                    used++;
+                } else used = 0xFFu;
             }
             count += one_node ? 1u : (uint32_t)Lw;
             continue;
         }
-        // (q's successor range asked for together with its record, ahead of the "first k-mer finished?" branch -- three
-        // dependent round trips per descent instead of four -- measured no different: profiles/r04_forward_early_edges_ab.txt)
-        ce[L] = FW_CE((int32_t)g.edge_start[q], (int32_t)g.edge_start[q + 1]);
         const int forcedL = any_followed(g, follow, q) ? 1 : 0;
-        nm[L] = (uint64_t)(uint32_t)q | ((uint64_t)FW_MK(hv + t, forcedL, vcL) << 32);
-        hs[L] = hL;
+        lv_set(ce_r, ce_st, L, forcedL ? FW_CE((int32_t)g.edge_start[q], (int32_t)g.edge_start[q + 1]) : succ_begin(g, wq, q));
+        lv_set(nm_r, nm_st, L, (uint64_t)(uint32_t)q | ((uint64_t)FW_MK(hv + t, forcedL, vcL) << 32));
+        lv_set(hs_r, hs_st, L, hL);
+        lv_set(mf_r, mf_st, L, mafL);
         if (follow) last[L] = INT_MIN;
         if (!EMIT && !forcedL && vcL >= M) check_one_ref_successor(g, q, err);
         L++;
@@ -308,22 +337,30 @@ __device__ void forward_walk(const DevGraph &g, int k, int M, bool one_node, con
 // Round 3: the records of one-node mode leave with the non-temporal hint (2.98 -> 2.79 ms), all-nodes mode must not
 // (3.96 -> 7.3 ms): put_record above.
 template <bool EMIT, bool DEEP = false, bool SCRIPT = false>
-__global__ __launch_bounds__(64, DEEP ? 1 : 8) void k_forward(DevGraph g, int k, int M, int one_node, const uint8_t *__restrict__ follow,
+__global__ __launch_bounds__(64, DEEP ? 1 : 8) void k_forward(DevGraph g, const NodeFwd *__restrict__ fw, int k, int M, int one_node, const uint8_t *__restrict__ follow,
                                                 const int32_t *__restrict__ nodes,
                                                 const int32_t *__restrict__ offsets, int64_t n_pos,
                                                 uint32_t *__restrict__ cnt, const int64_t *__restrict__ rec_start, FwdOut out,
-                                                int *__restrict__ err, DeepArena da, uint4 *__restrict__ script, uint8_t *__restrict__ used) {
+                                                int *__restrict__ err, DeepArena da, uint4 *__restrict__ script, uint8_t *__restrict__ used,
+                                                int64_t *__restrict__ list, int64_t list_n) {
+    // list: SCRIPT -- the start positions that do not fit the script are appended to it (up to list_n of them); EMIT -- when
+    // given, only these list_n start positions are walked (what the script's expansion left out)
     const int64_t lane_global = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n_items = EMIT && list ? list_n : n_pos;
     // product kernel: one position per lane; slow path: the arena's lanes walk the positions grid-stride
-    for (int64_t i = lane_global; i < n_pos; i += DEEP ? da.lanes : n_pos) {
+    for (int64_t t = lane_global; t < n_items; t += DEEP ? da.lanes : n_items) {
+        const int64_t i = EMIT && list ? list[t] : t;
         uint32_t c = 0, u = 0;
-        if (EMIT && used && used[i] != 0xFF) continue;          // written by the expansion of the script
+        if (EMIT && used && !list && used[i] != 0xFF) continue;          // written by the expansion of the script
         const int32_t n0 = nodes[i];
         if (n0 < 0 || n0 >= g.n_nodes) { if (!EMIT) cnt[i] = 0; if (SCRIPT) used[i] = 0; continue; }
-        forward_walk<EMIT, DEEP, SCRIPT>(g, k, M, one_node != 0, follow, n0, offsets[i], EMIT ? rec_start[i] : 0, out, &c, err, da, lane_global,
+        forward_walk<EMIT, DEEP, SCRIPT>(g, fw, k, M, one_node != 0, follow, n0, offsets[i], EMIT ? rec_start[i] : 0, out, &c, err, da, lane_global,
                                          script, i, n_pos, &u);
         if (!EMIT) cnt[i] = c;
-        if (SCRIPT) { used[i] = (uint8_t)u; if (u == 0xFFu) atomicAdd(err + 1, 1); }
+        if (SCRIPT) {
+            used[i] = (uint8_t)u;
+            if (u == 0xFFu) { const int slot = atomicAdd(err + 1, 1); if (slot < list_n) list[slot] = i; }
+        }
     }
 }
 
@@ -374,9 +411,42 @@ __global__ __launch_bounds__(256) void k_forward_expand(const uint4 *__restrict_
         }
     }
 }
+// NodeFwd of every node (gki_common.h); the 2-bit sequence is in place (gki_graph_prepare ran)
+__global__ __launch_bounds__(256) void k_build_fwd(DevGraph g, NodeFwd *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < g.n_nodes; n += stride) {
+        NodeFwd w;
+        w.size = g.node_size[n];
+        const int t31 = w.size < 31 ? w.size : 31;
+        w.head = t31 > 0 ? gki_extract(g.seq2, g.seq_start[n], t31) : 0ull;
+        w.af = g.allele_freq[n];
+        const int64_t e0 = g.edge_start[n], cnt = g.edge_start[n + 1] - e0;
+        w.e0 = cnt == 1 || cnt == 2 ? g.edges[e0] : (int32_t)e0;
+        w.e1 = cnt == 2 ? g.edges[e0 + 1] : 0;
+        w.cnt = (uint16_t)(cnt < 0xFFFF ? cnt : 0xFFFF);
+        w.is_ref = g.is_ref[n] ? 1 : 0;
+        w.pad = 0;
+        out[n] = w;
+    }
+}
 }  // namespace
 
 namespace {
+// the search's per-node records: built by the first search on a graph (and again after gki_graph_prepare), 32 B per node
+int fwd_nodes_ready(gki_graph *gr) {
+    if (gr->fwd_nodes) return GKI_OK;
+    void *p = nullptr;
+    if (hipMalloc(&p, (size_t)gr->d.n_nodes * sizeof(NodeFwd)) != hipSuccess) {
+        (void)hipGetLastError();
+        return gki_set_error(GKI_ERR_HIP, "forward search: no memory for %lld node records", (long long)gr->d.n_nodes);
+    }
+    hipLaunchKernelGGL(k_build_fwd, dim3(stream_grid(gr->d.n_nodes, 256)), dim3(256), 0, 0, gr->d, (NodeFwd *)p);
+    const hipError_t e = hipGetLastError(), e2 = hipStreamSynchronize(0);
+    if (e != hipSuccess || e2 != hipSuccess) { (void)hipFree(p); HIP_TRY(e); HIP_TRY(e2); }
+    gr->fwd_nodes = (NodeFwd *)p;
+    return GKI_OK;
+}
+
 // the slow path's arena: grown by the call that needs it, returned to the pool when the search is over
 void deep_release(gki_graph *gr) {
     if (gr->fwd_deep.base) (void)gki_dev_free(gr->fwd_deep.base);
@@ -400,6 +470,7 @@ void script_drop(gki_graph *gr) {
     FwdScript &sc = gr->fwd_script;
     if (sc.entries) (void)gki_dev_free(sc.entries);
     if (sc.ncomp) (void)gki_dev_free(sc.ncomp);
+    if (sc.over_list) (void)gki_dev_free(sc.over_list);
     sc = FwdScript{};
 }
 }  // namespace
@@ -412,6 +483,7 @@ int gki_forward_count(gki_graph *gr, int k, int max_variant_nodes, int one_node,
     if (k < 1 || k > GKI_MAX_K) return gki_set_error(GKI_ERR_BAD_ARG, "k must be in 1..31");
     GKI_TRY(gki_check_graph_device(gr, "gki_forward_count"));
     if (n_pos <= 0) { HIP_TRY(hipMemset(d_rec_start, 0, 8)); return GKI_OK; }
+    GKI_TRY(fwd_nodes_ready(gr));
     deep_release(gr);                     // a slow-path arena of an earlier search goes back to the pool (up to 5.6 GB)
     uint32_t *cnt = nullptr; void *tmp = nullptr; int *d_err = nullptr;
     int64_t tmp_bytes = gki_scan_tmp_bytes(n_pos);
@@ -428,6 +500,10 @@ int gki_forward_count(gki_graph *gr, int k, int max_variant_nodes, int one_node,
     if (GKI_FWD_SCRIPT && (!one_node || GKI_FWD_SCRIPT_ONE)) {
         if (gki_dev_malloc(&sc.entries, (size_t)n_pos * FW_SLOTS * FW_ENTRY_U4 * 16) != hipSuccess ||
             gki_dev_malloc((void **)&sc.ncomp, (size_t)n_pos) != hipSuccess) { (void)hipGetLastError(); script_drop(gr); }
+        else {
+            sc.over_cap = n_pos < (1 << 20) ? n_pos : (1 << 20);
+            if (gki_dev_malloc((void **)&sc.over_list, (size_t)sc.over_cap * 8) != hipSuccess) { (void)hipGetLastError(); sc.over_list = nullptr; sc.over_cap = 0; }
+        }
     }
     int64_t total = 0; int word[2] = {0, 0};
     int rc = GKI_OK;
@@ -437,17 +513,17 @@ int gki_forward_count(gki_graph *gr, int k, int max_variant_nodes, int one_node,
         e3 = hipMemset(d_err, 0, 8);
         if (da.cap > 0) {
             script_drop(gr);                // the slow path writes no script
-            hipLaunchKernelGGL((k_forward<false, true>), dim3((unsigned)(da.lanes / 64)), dim3(64), 0, 0, gr->d, k, M, one_node, (const uint8_t *)d_follow,
+            hipLaunchKernelGGL((k_forward<false, true>), dim3((unsigned)(da.lanes / 64)), dim3(64), 0, 0, gr->d, gr->fwd_nodes, k, M, one_node, (const uint8_t *)d_follow,
                                (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, cnt, (const int64_t *)nullptr, none, d_err, da,
-                               (uint4 *)nullptr, (uint8_t *)nullptr);
+                               (uint4 *)nullptr, (uint8_t *)nullptr, (int64_t *)nullptr, (int64_t)0);
         } else if (sc.entries)
-            hipLaunchKernelGGL((k_forward<false, false, true>), dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, k, M, one_node, (const uint8_t *)d_follow,
+            hipLaunchKernelGGL((k_forward<false, false, true>), dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, gr->fwd_nodes, k, M, one_node, (const uint8_t *)d_follow,
                                (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, cnt, (const int64_t *)nullptr, none, d_err, da,
-                               (uint4 *)sc.entries, sc.ncomp);
+                               (uint4 *)sc.entries, sc.ncomp, sc.over_list, sc.over_cap);
         else
-            hipLaunchKernelGGL((k_forward<false, false>), dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, k, M, one_node, (const uint8_t *)d_follow,
+            hipLaunchKernelGGL((k_forward<false, false>), dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, gr->fwd_nodes, k, M, one_node, (const uint8_t *)d_follow,
                                (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, cnt, (const int64_t *)nullptr, none, d_err, da,
-                               (uint4 *)nullptr, (uint8_t *)nullptr);
+                               (uint4 *)nullptr, (uint8_t *)nullptr, (int64_t *)nullptr, (int64_t)0);
         rc = hipGetLastError() == hipSuccess ? GKI_OK : gki_set_error(GKI_ERR_HIP, "k_forward launch failed");
         if (rc == GKI_OK) rc = gki_scan_u32_to_i64(cnt, n_pos, (int64_t *)d_rec_start, tmp, tmp_bytes, 0);
         e1 = hipMemcpy(&total, (const int64_t *)d_rec_start + n_pos, 8, hipMemcpyDeviceToHost);
@@ -482,6 +558,7 @@ int gki_forward_emit(gki_graph *gr, int k, int max_variant_nodes, int one_node, 
                      void *d_nodes_out, void *d_af64) {
     if (n_pos <= 0) return GKI_OK;
     GKI_TRY(gki_check_graph_device(gr, "gki_forward_emit"));
+    GKI_TRY(fwd_nodes_ready(gr));
     int *d_err = nullptr;
     HIP_TRY(gki_dev_malloc((void **)&d_err, 4));
     FwdOut out{(int64_t *)d_hashes, (int32_t *)d_start_nodes, (int16_t *)d_start_offsets, (int32_t *)d_nodes_out, (double *)d_af64};
@@ -500,20 +577,26 @@ int gki_forward_emit(gki_graph *gr, int k, int max_variant_nodes, int one_node, 
         const bool scripted = sc.valid && da.cap == 0 && sc.n_pos == n_pos && sc.nodes == d_nodes && sc.offsets == d_offsets && sc.follow == d_follow &&
                               sc.rec_start == d_rec_start && sc.k == k && sc.M == M && sc.one_node == (one_node ? 1 : 0);
         if (da.cap > 0)
-            hipLaunchKernelGGL((k_forward<true, true>), dim3((unsigned)(da.lanes / 64)), dim3(64), 0, 0, gr->d, k, M, one_node, (const uint8_t *)d_follow,
+            hipLaunchKernelGGL((k_forward<true, true>), dim3((unsigned)(da.lanes / 64)), dim3(64), 0, 0, gr->d, gr->fwd_nodes, k, M, one_node, (const uint8_t *)d_follow,
                                (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, (uint32_t *)nullptr, (const int64_t *)d_rec_start, out, d_err, da,
-                               (uint4 *)nullptr, (uint8_t *)nullptr);
+                               (uint4 *)nullptr, (uint8_t *)nullptr, (int64_t *)nullptr, (int64_t)0);
         else if (scripted) {
             hipLaunchKernelGGL(k_forward_expand, dim3((unsigned)ceil_div(n_pos * FW_SLOTS, 256)), dim3(256), 0, 0, (const uint4 *)sc.entries, sc.ncomp,
                                (const int64_t *)d_rec_start, n_pos, out);
-            if (sc.overflow > 0)                // the start positions the script could not hold: walked as before
-                hipLaunchKernelGGL((k_forward<true, false>), dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, k, M, one_node, (const uint8_t *)d_follow,
+            // the start positions the script could not hold are walked as before: those on the count pass's list, or -- when
+            // there were more than the list holds -- whichever the script marks, one lane per start position of the call
+            if (sc.overflow > 0 && sc.overflow <= sc.over_cap)
+                hipLaunchKernelGGL((k_forward<true, false>), dim3((unsigned)ceil_div(sc.overflow, 64)), dim3(64), 0, 0, gr->d, gr->fwd_nodes, k, M, one_node, (const uint8_t *)d_follow,
                                    (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, (uint32_t *)nullptr, (const int64_t *)d_rec_start, out, d_err, da,
-                                   (uint4 *)nullptr, sc.ncomp);
+                                   (uint4 *)nullptr, sc.ncomp, sc.over_list, sc.overflow);
+            else if (sc.overflow > 0)
+                hipLaunchKernelGGL((k_forward<true, false>), dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, gr->fwd_nodes, k, M, one_node, (const uint8_t *)d_follow,
+                                   (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, (uint32_t *)nullptr, (const int64_t *)d_rec_start, out, d_err, da,
+                                   (uint4 *)nullptr, sc.ncomp, (int64_t *)nullptr, (int64_t)0);
         } else
-            hipLaunchKernelGGL((k_forward<true, false>), dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, k, M, one_node, (const uint8_t *)d_follow,
+            hipLaunchKernelGGL((k_forward<true, false>), dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, gr->fwd_nodes, k, M, one_node, (const uint8_t *)d_follow,
                                (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, (uint32_t *)nullptr, (const int64_t *)d_rec_start, out, d_err, da,
-                               (uint4 *)nullptr, (uint8_t *)nullptr);
+                               (uint4 *)nullptr, (uint8_t *)nullptr, (int64_t *)nullptr, (int64_t)0);
         e = hipGetLastError();
         e2 = hipMemcpy(&word, d_err, 4, hipMemcpyDeviceToHost);          // (synchronises)
         if (e != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) break;

@@ -155,6 +155,7 @@ int gki_graph_prepare(gki_graph *g) {
     DevGraph &d = g->d;
     hipStream_t s = g->stream;
     int64_t n_u64 = ceil_div(d.n_bases, 32) + 2;
+    if (g->fwd_nodes) { (void)hipFree(g->fwd_nodes); g->fwd_nodes = nullptr; }     // of the sequence before: the next search builds them
     HIP_TRY(hipEventRecord(g->ev_prep0, s));
     HIP_TRY(hipMemsetAsync((void *)d.seq2, 0, (size_t)n_u64 * 8, s));
     GKI_TRY(gki_launch_pack(d.seq, d.n_bases, (uint32_t *)d.seq2, s));
@@ -212,6 +213,8 @@ int gki_graph_destroy(gki_graph *g) {
     if (g->fwd_deep.base) (void)gki_dev_free(g->fwd_deep.base);
     if (g->fwd_script.entries) (void)gki_dev_free(g->fwd_script.entries);
     if (g->fwd_script.ncomp) (void)gki_dev_free(g->fwd_script.ncomp);
+    if (g->fwd_script.over_list) (void)gki_dev_free(g->fwd_script.over_list);
+    if (g->fwd_nodes) (void)hipFree(g->fwd_nodes);
     (void)hipEventDestroy(g->ev_prep0);
     (void)hipEventDestroy(g->ev_prep1);
     (void)hipStreamDestroy(g->stream);
