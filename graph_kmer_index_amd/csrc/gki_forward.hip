@@ -105,6 +105,9 @@ constexpr int FW_BUDGET = 1 << 22, FW_BUDGET_FROM = 8;     // (every step of thi
 // the start node, an allele, the node that completes the k-mer, which is never stored -- lives in two levels, so the
 // product kernel touches no scratch at all for it (rounds 2-4 kept every level in scratch: three stores per descent and
 // two loads per turn of the loop, each a trip to L2 -- a wave's levels do not fit L1 beside its neighbours').
+#ifndef GKI_FWD_BLOCK
+#define GKI_FWD_BLOCK 64                  // threads per workgroup of the product kernels (one start position per lane)
+#endif
 #ifndef GKI_FWD_REG_LEVELS
 #define GKI_FWD_REG_LEVELS 2
 #endif
@@ -327,17 +330,22 @@ __device__ void forward_walk(const DevGraph &g, const NodeFwd *__restrict__ fw, 
     if (SCRIPT) *used_out = used;
 }
 
-// One lane per start position, every read from global memory: latency-bound, so resident waves are what counts.  Without
-// the occupancy request the compiler expands the per-level stacks into register select chains (178 VGPRs = 2 waves per
-// SIMD, 2 200 instructions); with it 25-32 VGPRs, 700 instructions, 8 waves.  tools/bench_forward.py, 1.14e7 starts on the
-// 1 Gbp graph, same box: 8.29 -> 5.15 ms per batch (all nodes), 6.81 -> 3.0 ms (one node per k-mer).
-// Then, all-nodes mode: an ascending path is written straight through instead of a selection per record: 5.0 -> 4.05 ms.
-// Tried and dropped: carrying the path's smallest node and minimum allele frequency down the walk instead of looping
-// over the path at every finished k-mer -- two more scratch stores per step cost more than the loops (5.0 -> 5.2 ms).
-// Round 3: the records of one-node mode leave with the non-temporal hint (2.98 -> 2.79 ms), all-nodes mode must not
-// (3.96 -> 7.3 ms): put_record above.
+// One lane per start position, every read from global memory.  What the counters show (profiles/r04_forward_node_records_ab.txt):
+// the wave slots are full and the waves wait nine cycles in ten; a wave lasts as long as its slowest lane and pays a memory
+// round trip per memory instruction of every turn of the loop, so the kernel's time is (turns of the slowest lane) x (memory
+// instructions per turn) x latency / (resident waves).  Hence, in the order they were found:
+//  - resident waves: without the occupancy request the compiler expands the per-level stacks into register select chains
+//    (178 VGPRs = 2 waves per SIMD); with it 8 waves.  1.14e7 starts on the 1 Gbp graph: 8.29 -> 5.15 ms (round 2);
+//  - an ascending path is written straight through instead of by a selection per record: 5.0 -> 4.05 ms (round 2);
+//  - the records of one-node mode leave with the non-temporal hint (2.98 -> 2.79 ms); all-nodes mode must not (round 3);
+//  - the script (the emit pass stops walking; round 3) and its piece-major layout (round 4: 8.1 -> 6.2 ms, 3.43e7 starts);
+//  - memory instructions per turn: one NodeFwd record per descent, the first levels in registers, the minimum allele
+//    frequency carried down (round 4: 6.4 -> 4.7 ms; round 2 had tried carrying it in scratch: slower);
+//  - 64-thread workgroups: with 256 a slot waits for the slowest of four waves (4.6 -> 4.8 ms).
+// Still there: the slowest lane -- a start position whose window crosses a second variant takes twice the turns of its
+// neighbours, and they wait for it.
 template <bool EMIT, bool DEEP = false, bool SCRIPT = false>
-__global__ __launch_bounds__(64, DEEP ? 1 : 8) void k_forward(DevGraph g, const NodeFwd *__restrict__ fw, int k, int M, int one_node, const uint8_t *__restrict__ follow,
+__global__ __launch_bounds__(DEEP ? 64 : GKI_FWD_BLOCK, DEEP ? 1 : 8) void k_forward(DevGraph g, const NodeFwd *__restrict__ fw, int k, int M, int one_node, const uint8_t *__restrict__ follow,
                                                 const int32_t *__restrict__ nodes,
                                                 const int32_t *__restrict__ offsets, int64_t n_pos,
                                                 uint32_t *__restrict__ cnt, const int64_t *__restrict__ rec_start, FwdOut out,
@@ -517,11 +525,11 @@ int gki_forward_count(gki_graph *gr, int k, int max_variant_nodes, int one_node,
                                (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, cnt, (const int64_t *)nullptr, none, d_err, da,
                                (uint4 *)nullptr, (uint8_t *)nullptr, (int64_t *)nullptr, (int64_t)0);
         } else if (sc.entries)
-            hipLaunchKernelGGL((k_forward<false, false, true>), dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, gr->fwd_nodes, k, M, one_node, (const uint8_t *)d_follow,
+            hipLaunchKernelGGL((k_forward<false, false, true>), dim3((unsigned)ceil_div(n_pos, GKI_FWD_BLOCK)), dim3(GKI_FWD_BLOCK), 0, 0, gr->d, gr->fwd_nodes, k, M, one_node, (const uint8_t *)d_follow,
                                (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, cnt, (const int64_t *)nullptr, none, d_err, da,
                                (uint4 *)sc.entries, sc.ncomp, sc.over_list, sc.over_cap);
         else
-            hipLaunchKernelGGL((k_forward<false, false>), dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, gr->fwd_nodes, k, M, one_node, (const uint8_t *)d_follow,
+            hipLaunchKernelGGL((k_forward<false, false>), dim3((unsigned)ceil_div(n_pos, GKI_FWD_BLOCK)), dim3(GKI_FWD_BLOCK), 0, 0, gr->d, gr->fwd_nodes, k, M, one_node, (const uint8_t *)d_follow,
                                (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, cnt, (const int64_t *)nullptr, none, d_err, da,
                                (uint4 *)nullptr, (uint8_t *)nullptr, (int64_t *)nullptr, (int64_t)0);
         rc = hipGetLastError() == hipSuccess ? GKI_OK : gki_set_error(GKI_ERR_HIP, "k_forward launch failed");
@@ -586,15 +594,15 @@ int gki_forward_emit(gki_graph *gr, int k, int max_variant_nodes, int one_node, 
             // the start positions the script could not hold are walked as before: those on the count pass's list, or -- when
             // there were more than the list holds -- whichever the script marks, one lane per start position of the call
             if (sc.overflow > 0 && sc.overflow <= sc.over_cap)
-                hipLaunchKernelGGL((k_forward<true, false>), dim3((unsigned)ceil_div(sc.overflow, 64)), dim3(64), 0, 0, gr->d, gr->fwd_nodes, k, M, one_node, (const uint8_t *)d_follow,
+                hipLaunchKernelGGL((k_forward<true, false>), dim3((unsigned)ceil_div(sc.overflow, GKI_FWD_BLOCK)), dim3(GKI_FWD_BLOCK), 0, 0, gr->d, gr->fwd_nodes, k, M, one_node, (const uint8_t *)d_follow,
                                    (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, (uint32_t *)nullptr, (const int64_t *)d_rec_start, out, d_err, da,
                                    (uint4 *)nullptr, sc.ncomp, sc.over_list, sc.overflow);
             else if (sc.overflow > 0)
-                hipLaunchKernelGGL((k_forward<true, false>), dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, gr->fwd_nodes, k, M, one_node, (const uint8_t *)d_follow,
+                hipLaunchKernelGGL((k_forward<true, false>), dim3((unsigned)ceil_div(n_pos, GKI_FWD_BLOCK)), dim3(GKI_FWD_BLOCK), 0, 0, gr->d, gr->fwd_nodes, k, M, one_node, (const uint8_t *)d_follow,
                                    (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, (uint32_t *)nullptr, (const int64_t *)d_rec_start, out, d_err, da,
                                    (uint4 *)nullptr, sc.ncomp, (int64_t *)nullptr, (int64_t)0);
         } else
-            hipLaunchKernelGGL((k_forward<true, false>), dim3((unsigned)ceil_div(n_pos, 64)), dim3(64), 0, 0, gr->d, gr->fwd_nodes, k, M, one_node, (const uint8_t *)d_follow,
+            hipLaunchKernelGGL((k_forward<true, false>), dim3((unsigned)ceil_div(n_pos, GKI_FWD_BLOCK)), dim3(GKI_FWD_BLOCK), 0, 0, gr->d, gr->fwd_nodes, k, M, one_node, (const uint8_t *)d_follow,
                                (const int32_t *)d_nodes, (const int32_t *)d_offsets, n_pos, (uint32_t *)nullptr, (const int64_t *)d_rec_start, out, d_err, da,
                                (uint4 *)nullptr, (uint8_t *)nullptr, (int64_t *)nullptr, (int64_t)0);
         e = hipGetLastError();
