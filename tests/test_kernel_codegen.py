@@ -113,6 +113,12 @@ def test_forward_search_kernel_runs_at_full_occupancy(forward_asm):
         if name.split("(")[0].startswith("k_forward<") and name.split("(")[0].split(",")[1].strip() == "true":
             continue                  # the slow path
         assert not re.findall(r"\n\s*flat_(load|store|atomic)", body), name
+        # the first levels of the walk are registers: what is left in scratch are the levels behind them, addressed by a
+        # level index in a VGPR.  (Held in one aggregate with that stack they were 25 scratch stores, most of them at fixed
+        # offsets, and the search 1.3x slower: profiles/r04_forward_node_records_ab.txt.)
+        if name.split("(")[0].startswith("k_forward<"):
+            assert len(re.findall(r"\n\s*scratch_store", body)) <= 12, (name, len(re.findall(r"\n\s*scratch_store", body)))
+            assert len(re.findall(r"\n\s*scratch_store_\w+ off,", body)) <= 2, name
 
 
 @pytest.fixture(scope="module")
