@@ -423,10 +423,14 @@ __global__ __launch_bounds__(256) void k_narrow_counts(const uint32_t *__restric
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (uint16_t)in[i];
 }
 
-__global__ __launch_bounds__(256) void k_node_keys(const uint32_t *__restrict__ nodes, int64_t n, uint32_t *__restrict__ keys,
-                                                   uint32_t *__restrict__ idx) {
+__global__ __launch_bounds__(256) void k_node_keys(const uint32_t *__restrict__ nodes, int64_t n, uint64_t n_nodes, uint32_t *__restrict__ keys,
+                                                   uint32_t *__restrict__ idx, int *__restrict__ bad) {
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { keys[i] = nodes[i]; idx[i] = (uint32_t)i; }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint32_t v = nodes[i];
+        if ((uint64_t)v >= n_nodes) { *bad = 1; v = (uint32_t)(n_nodes - 1); }      // (the directory is never indexed out of range)
+        keys[i] = v; idx[i] = (uint32_t)i;
+    }
 }
 
 // Node directory of the reverse index, two streaming passes and no search: PASS 0 -- the head of a run records where the
@@ -846,6 +850,7 @@ int gki_reverse_index_build(const void *d_nodes, const void *d_kmers, const void
     uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *hist = nullptr, *offs = nullptr;
     uint4 *rows = nullptr;
     void *tmp = nullptr;
+    int *bad = nullptr;
     int rc = GKI_OK;
 #define HIP_G(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = gki_set_error(GKI_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); goto done; } } while (0)
     {
@@ -857,7 +862,9 @@ int gki_reverse_index_build(const void *d_nodes, const void *d_kmers, const void
         HIP_G(gki_dev_malloc((void **)&offs, (size_t)(hist_n + 1) * 4));
         HIP_G(gki_dev_malloc(&tmp, (size_t)tmp_bytes));
         HIP_G(gki_dev_malloc((void **)&rows, (size_t)n * 16));
-        hipLaunchKernelGGL(k_node_keys, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const uint32_t *)d_nodes, n, keys[0], vals[0]);
+        HIP_G(gki_dev_malloc((void **)&bad, 4));
+        HIP_G(hipMemsetAsync(bad, 0, 4, s));
+        hipLaunchKernelGGL(k_node_keys, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const uint32_t *)d_nodes, n, (uint64_t)n_nodes, keys[0], vals[0], bad);
         HIP_G(hipGetLastError());
         int cur = 0;
         rc = radix_sort_pairs(keys, vals, n, key_bits((uint64_t)n_nodes - 1), hist, offs, tmp, tmp_bytes, s, &cur);
@@ -874,11 +881,14 @@ int gki_reverse_index_build(const void *d_nodes, const void *d_kmers, const void
         hipLaunchKernelGGL(k_node_directory<1>, dim3(stream_grid(n, 256)), dim3(256), 0, s, keys[cur], n,
                            (uint32_t *)d_index_positions, (uint16_t *)d_n_hashes);
         HIP_G(hipGetLastError());
+        int h_bad = 0;
+        HIP_G(hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, s));
         HIP_G(hipStreamSynchronize(s));
+        if (h_bad) rc = gki_set_error(GKI_ERR_BAD_ARG, "a record's node id is not below n_nodes = %lld", (long long)n_nodes);
     }
 done:
     for (int i = 0; i < 2; i++) { (void)gki_dev_free(keys[i]); (void)gki_dev_free(vals[i]); }
-    (void)gki_dev_free(hist); (void)gki_dev_free(offs); (void)gki_dev_free(tmp); (void)gki_dev_free(rows);
+    (void)gki_dev_free(hist); (void)gki_dev_free(offs); (void)gki_dev_free(tmp); (void)gki_dev_free(rows); (void)gki_dev_free(bad);
 #undef HIP_G
     return rc;
 }

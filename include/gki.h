@@ -267,8 +267,10 @@ int64_t gki_finder_interior_records(const gki_finder *f);
  * start position i are [rec_start[i], rec_start[i+1]) in depth-first successor order (the reference's order).
  * d_nodes int32[n_pos], d_offsets int32[n_pos], d_rec_start int64[n_pos+1]; output = the v2 columns.
  * d_follow: uint8[n_nodes] membership of only_follow_nodes (:386-388) or NULL.
- * gki_forward_count may leave the finished k-mers in a buffer owned by the graph (192 bytes per start position, all-nodes
- * mode); the next gki_forward_emit with the SAME arguments expands them instead of walking again and releases the buffer.
+ * The first search on a graph (and the first after gki_graph_prepare) builds the search's per-node records: 32 bytes per
+ * node, owned by the graph and freed with it.
+ * gki_forward_count may leave the finished k-mers in a buffer owned by the graph (193 bytes per start position, both
+ * modes); the next gki_forward_emit with the SAME arguments expands them instead of walking again and releases the buffer.
  * Any other sequence of calls (count(A), count(B), emit(A); a second emit) is answered by walking, and the emit pass
  * settles by itself whether it needs the slow path's deeper stacks: the results are the same.  The slow path's arena
  * (up to 5.6 GB) goes back to the library's pool when the emit call returns.  Calls on one graph handle must not overlap
@@ -368,7 +370,10 @@ int gki_index_build_pairs(const void *d_kmers, const void *d_nodes, const void *
  * node.  Inputs: device columns nodes uint32[n], kmers uint64[n], ref_offsets uint64[n]; n_nodes =
  * max node id + 1.  Outputs (device, sized by the caller): index_positions uint32[n_nodes] (first
  * record of the node, 0 if none), n_hashes uint16[n_nodes] (records of the node, modulo 2^16 as the
- * NumPy assignment at :56 stores it), and the permuted kmers / ref_offsets uint64[n]. */
+ * NumPy assignment at :56 stores it), and the permuted kmers / ref_offsets uint64[n].
+ * Built by the row-carrying form of the index build with the node id as the key; the pair-sorting form it replaced
+ * answers what that form declines, and every call when the environment holds GKI_REVERSE_FORM=pairs (read per call;
+ * for the parity tests of that path).  A node id >= n_nodes is GKI_ERR_BAD_ARG. */
 int gki_reverse_index_build(const void *d_nodes, const void *d_kmers, const void *d_ref_offsets, int64_t n,
                             int64_t n_nodes, void *d_index_positions, void *d_n_hashes, void *d_out_kmers,
                             void *d_out_ref_offsets);

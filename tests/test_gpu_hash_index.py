@@ -298,6 +298,28 @@ def test_reverse_index_random_vs_numpy(n, n_nodes, seed, form, monkeypatch):
     assert np.array_equal(r.hashes, skm) and np.array_equal(r.ref_positions, srf)
 
 
+@pytest.mark.parametrize("form", ["rows", "pairs"])
+def test_reverse_index_refuses_a_node_id_beyond_n_nodes(form, monkeypatch):
+    # include/gki.h: GKI_ERR_BAD_ARG in both forms, and nothing written outside the caller's n_nodes-sized outputs
+    monkeypatch.setenv("GKI_REVERSE_FORM", form)
+    rng = np.random.default_rng(9)
+    n, n_nodes = 50000, 1000
+    nodes = rng.integers(0, n_nodes, size=n).astype(np.uint32)
+    nodes[12345] = n_nodes + 7
+    d_nodes = _lib.DeviceArray.from_host(nodes)
+    d_kmers = _lib.DeviceArray.from_host(rng.integers(0, 4 ** 31, size=n, dtype=np.uint64))
+    d_refs = _lib.DeviceArray.from_host(rng.integers(0, 2 ** 40, size=n, dtype=np.uint64))
+    guard = 4096                                              # elements behind the directory that must stay as they are
+    index_pos = _lib.DeviceArray.from_host(np.full(n_nodes + guard, 0xABCDABCD, np.uint32))
+    n_hashes = _lib.DeviceArray.from_host(np.full(n_nodes + guard, 0xABCD, np.uint16))
+    out_kmers, out_refs = _lib.DeviceArray(n, np.uint64), _lib.DeviceArray(n, np.uint64)
+    with pytest.raises(_lib.GkiError) as e:
+        _lib.check(_lib.load().gki_reverse_index_build(d_nodes.ptr, d_kmers.ptr, d_refs.ptr, n, n_nodes, index_pos.ptr, n_hashes.ptr,
+                                                       out_kmers.ptr, out_refs.ptr))
+    assert e.value.code == 2
+    assert (index_pos.to_host()[n_nodes:] == 0xABCDABCD).all() and (n_hashes.to_host()[n_nodes:] == 0xABCD).all()
+
+
 def test_reverse_index_from_device_flat_kmers():
     from graph_kmer_index_amd import DeviceFlatKmers
     rng = np.random.default_rng(5)

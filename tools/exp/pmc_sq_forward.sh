@@ -1,15 +1,16 @@
 #!/bin/bash
 # usage (GPU box, repo root): tools/exp/pmc_sq_forward.sh <tag> "<bench_forward args>" -> SQ / L2 counters of the early-stop search's kernels
-# (separate rocprofv3 --pmc passes, no trace domains)
+# (separate rocprofv3 --pmc passes, no trace domains; SQ counters only: a pass asking for TCC_* / TCP_* names hung for its whole
+# timeout on this pool)
 tag="$1"; args="$2"
 R="$(pwd)"; export TMPDIR=/tmp
 cd /tmp
 A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE"
 B="SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD"
-C="TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_REQ_sum"
-D="TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum"
+
+
 i=0
-for grp in "$A" "$B" "$C" "$D"; do
+for grp in "$A" "$B"; do
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d "$R/gpurun_out/sqf_${tag}_$i" -- python3 "$R/tools/bench_forward.py" $args > "$R/gpurun_out/sqf_${tag}_$i.json" 2> "$R/gpurun_out/sqf_${tag}_$i.err" || { echo "pass $i failed"; tail -3 "$R/gpurun_out/sqf_${tag}_$i.err"; }
 done
