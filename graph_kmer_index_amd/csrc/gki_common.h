@@ -133,7 +133,7 @@ struct DeepArena { char *base; int64_t lanes; int32_t cap; int32_t pad; };
 // early-stop search: the finished k-mers the count pass wrote down for the emit pass (csrc/gki_forward.hip, "script"), and
 // the call they belong to -- the emit call uses them only when it is given the same arguments
 struct FwdScript {
-    void *entries;                           // [n_pos][FW_SLOTS] 48-byte entries
+    void *entries;                           // FW_SLOTS entries of up to three 16-byte pieces per start position, piece-major
     uint8_t *ncomp;                          // [n_pos] entries in use, 0xFF: the start position did not fit, walk it again
     int64_t n_pos, overflow;
     int64_t *over_list; int64_t over_cap;    // the start positions that did not fit (the first over_cap of them), for the emit pass

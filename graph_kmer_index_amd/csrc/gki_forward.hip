@@ -67,12 +67,19 @@ __device__ __forceinline__ size_t script_cell(int64_t i, int c, int p, int64_t n
     return GKI_FWD_SCRIPT_SOA ? (size_t)(c * FW_ENTRY_U4 + p) * (size_t)n_pos + (size_t)i
                               : ((size_t)i * FW_SLOTS + (size_t)c) * FW_ENTRY_U4 + (size_t)p;
 }
+// An entry: piece 0 = (hash, minimum allele frequency); piece 1 = (end node q, end offset | records << 16 | flags << 24, first two
+// nodes of the list); piece 2 = (the list's third and fourth node), written and read only when the list is that long.  The
+// list: in all-nodes mode the path's nodes but the last, which is q (a path over three nodes -- start node, allele, the node
+// that completes the k-mer -- is two pieces); in one-node mode (flag bit 0) the one node the record reports.  The number of
+// the entry's first record among its start position's is not stored: it is the sum of the records of the slots before it.
 __device__ __forceinline__ void script_write(uint4 *script, int64_t i, int c, int64_t n_pos, uint64_t h, double maf, int32_t q, int off, int lw,
-                                             uint32_t first, const int32_t *nodes) {
+                                             bool one_node, const int32_t *nodes) {
     const uint64_t mb = (uint64_t)__double_as_longlong(maf);
+    const int listed = one_node ? 1 : lw - 1;
     script[script_cell(i, c, 0, n_pos)] = make_uint4((uint32_t)h, (uint32_t)(h >> 32), (uint32_t)mb, (uint32_t)(mb >> 32));
-    script[script_cell(i, c, 1, n_pos)] = make_uint4((uint32_t)q, ((uint32_t)off & 0xFFFFu) | ((uint32_t)lw << 16), first, (uint32_t)nodes[0]);
-    if (lw > 1) script[script_cell(i, c, 2, n_pos)] = make_uint4((uint32_t)nodes[1], (uint32_t)nodes[2], (uint32_t)nodes[3], (uint32_t)nodes[4]);
+    script[script_cell(i, c, 1, n_pos)] = make_uint4((uint32_t)q, ((uint32_t)off & 0xFFFFu) | ((uint32_t)lw << 16) | (one_node ? 1u << 24 : 0u),
+                                                     (uint32_t)nodes[0], (uint32_t)nodes[1]);
+    if (listed > 2) script[script_cell(i, c, 2, n_pos)] = make_uint4((uint32_t)nodes[2], (uint32_t)nodes[3], 0u, 0u);
 }
 
 // only_follow_nodes (kmer_finder.py:386-388): when a node has successors in the follow set, only those are taken
@@ -214,7 +221,7 @@ __device__ void forward_walk(const DevGraph &g, const NodeFwd *__restrict__ fw, 
         }
         if (SCRIPT) {
             const int32_t one[FW_SN] = {n0, 0, 0, 0, 0};
-            script_write(script, pos, 0, n_pos, h0, w0.af, n0, o0 + k - 1, 1, 0u, one);
+            script_write(script, pos, 0, n_pos, h0, w0.af, n0, o0 + k - 1, 1, true, one);
             *used_out = 1;
         }
         *count_out = 1;
@@ -308,7 +315,7 @@ __device__ void forward_walk(const DevGraph &g, const NodeFwd *__restrict__ fw, 
                 const bool fits = used < (uint32_t)FW_SLOTS && (one_node || (short_path && asc));
                 if (fits) {
                     if (one_node) v[0] = mn;
-                    script_write(script, pos, (int)used, n_pos, hL, mafL, q, t - 1, one_node ? 1 : Lw, count, v);
+                    script_write(script, pos, (int)used, n_pos, hL, mafL, q, t - 1, one_node ? 1 : Lw, one_node, v);
                     used++;
                 } else used = 0xFFu;
             }
@@ -389,19 +396,25 @@ __global__ __launch_bounds__(256) void k_forward_expand(const uint4 *__restrict_
     const int64_t i = tid / FW_SLOTS;
     const int c = (int)(tid % FW_SLOTS);
     int lw = 0;
+    int64_t base = 0;
     if (i < n_pos) {
         const uint32_t n = used[i];
         if (n != 0xFFu && (uint32_t)c < n) {
             const uint4 a = script[script_cell(i, c, 0, n_pos)], b = script[script_cell(i, c, 1, n_pos)];
             lw = (int)((b.y >> 16) & 0xFFu);
             s_e[wave][lane][0] = a; s_e[wave][lane][1] = b;
-            if (lw > 1) s_e[wave][lane][2] = script[script_cell(i, c, 2, n_pos)];       // (a one-record entry has no third piece)
-            s_idx[wave][lane] = rec_start[i] + (int64_t)b.z;
+            if (!(b.y >> 24 & 1u) && lw > 3) s_e[wave][lane][2] = script[script_cell(i, c, 2, n_pos)];       // (lists of three and four nodes)
+            base = rec_start[i];
         }
     }
     const int incl = gki_wave_incl_sum(lw);
     const int R = gki_lane_value(incl, 63);
-    s_ex[wave][lane] = (uint16_t)(incl - lw);
+    const int excl = incl - lw;
+    // an entry's first record among its start position's = the records of the slots before it: the four slots of a start
+    // position are four neighbouring lanes, and the prefix sum at the first of them is what lies before the start position
+    const int excl_slot0 = __shfl(excl, lane & ~3, 64);
+    s_idx[wave][lane] = base + (int64_t)(excl - excl_slot0);
+    s_ex[wave][lane] = (uint16_t)excl;
     __builtin_amdgcn_wave_barrier();
     for (int rr0 = 0; rr0 < R; rr0 += 64) {
         const int rr = rr0 + lane;
@@ -412,10 +425,12 @@ __global__ __launch_bounds__(256) void k_forward_expand(const uint4 *__restrict_
                 if (o + step < 64 && (int)s_ex[wave][o + step] <= rr) o += step;
             const int t = rr - (int)s_ex[wave][o];
             const uint4 a = s_e[wave][o][0], b = s_e[wave][o][1];
-            const uint32_t *nodes5 = reinterpret_cast<const uint32_t *>(&s_e[wave][o][1]) + 3;      // b.w, d.x, d.y, d.z, d.w
+            const uint32_t *listed = reinterpret_cast<const uint32_t *>(&s_e[wave][o][1]) + 2;      // b.z, b.w, d.x, d.y
+            const int lw_o = (int)((b.y >> 16) & 0xFFu);
+            const bool from_list = (b.y >> 24 & 1u) || t < lw_o - 1;                                // (else: the path's last node, q)
             const uint64_t h = (uint64_t)a.x | ((uint64_t)a.y << 32);
             const double maf = __longlong_as_double((long long)((uint64_t)a.z | ((uint64_t)a.w << 32)));
-            put_record<false>(out, s_idx[wave][o] + t, h, (int32_t)b.x, (int)(int16_t)(b.y & 0xFFFFu), (int32_t)nodes5[t], maf);
+            put_record<false>(out, s_idx[wave][o] + t, h, (int32_t)b.x, (int)(int16_t)(b.y & 0xFFFFu), from_list ? (int32_t)listed[t] : (int32_t)b.x, maf);
         }
     }
 }
