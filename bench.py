@@ -595,7 +595,7 @@ def early_stop_record(lib, _lib, g, k, finder, max_variant_nodes=4):
            "every_start_has_a_record": bool(first_counts.min() >= 1),
            "workload": "seven early-stop searches per SNP site (unique_variant_kmers.py:119-140), one batch",
            "form": "all-nodes mode: the count pass walks on 32-byte node records and writes every finished k-mer down (<= 4 entries "
-                   "of 48 B per start position, piece-major), the emit pass expands them one lane per record; start positions "
+                   "of 32-48 B per start position, piece-major), the emit pass expands them one lane per record; start positions "
                    "that do not fit are listed and walked again",
            "timed": "wall clock around gki_forward_count + gki_forward_emit, graph / start arrays / output columns in HBM"}
     log("early-stop search: %d start positions, %d records in %.2f ms" % (n_pos, n_rec, 1e3 * dt))

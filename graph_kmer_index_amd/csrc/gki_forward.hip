@@ -115,6 +115,9 @@ constexpr int FW_BUDGET = 1 << 22, FW_BUDGET_FROM = 8;     // (every step of thi
 #ifndef GKI_FWD_BLOCK
 #define GKI_FWD_BLOCK 64                  // threads per workgroup of the product kernels (one start position per lane)
 #endif
+#ifndef GKI_FWD_WAVES
+#define GKI_FWD_WAVES 8                   // waves per SIMD the product kernels are held to
+#endif
 #ifndef GKI_FWD_REG_LEVELS
 #define GKI_FWD_REG_LEVELS 2
 #endif
@@ -352,7 +355,7 @@ __device__ void forward_walk(const DevGraph &g, const NodeFwd *__restrict__ fw, 
 // Still there: the slowest lane -- a start position whose window crosses a second variant takes twice the turns of its
 // neighbours, and they wait for it.
 template <bool EMIT, bool DEEP = false, bool SCRIPT = false>
-__global__ __launch_bounds__(DEEP ? 64 : GKI_FWD_BLOCK, DEEP ? 1 : 8) void k_forward(DevGraph g, const NodeFwd *__restrict__ fw, int k, int M, int one_node, const uint8_t *__restrict__ follow,
+__global__ __launch_bounds__(DEEP ? 64 : GKI_FWD_BLOCK, DEEP ? 1 : GKI_FWD_WAVES) void k_forward(DevGraph g, const NodeFwd *__restrict__ fw, int k, int M, int one_node, const uint8_t *__restrict__ follow,
                                                 const int32_t *__restrict__ nodes,
                                                 const int32_t *__restrict__ offsets, int64_t n_pos,
                                                 uint32_t *__restrict__ cnt, const int64_t *__restrict__ rec_start, FwdOut out,
