@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstddef>
 #include <stdio.h>
 #include <string.h>
 #include "../../include/gki.h"
@@ -76,6 +77,7 @@ struct alignas(32) NodeWalk { // everything the boundary walk needs about a node
     uint8_t is_ref, pad;
 };
 static_assert(sizeof(NodeWalk) == 32, "NodeWalk is one 32-byte record");
+static_assert(offsetof(NodeWalk, seq_start) == 0 && offsetof(NodeWalk, tail) == 8, "csrc/gki_forward.hip reads (seq_start, tail) as the record's first 16 bytes");
 
 // The early-stop search's view of a node (csrc/gki_forward.hip): one aligned 32-byte record holds everything a forward step
 // onto the node needs -- its first bases, its allele frequency, and its successors when there are at most two -- so a

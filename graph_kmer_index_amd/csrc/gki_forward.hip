@@ -195,6 +195,7 @@ __device__ void forward_walk(const DevGraph &g, const NodeFwd *__restrict__ fw, 
     int steps_left = FW_BUDGET;
     uint32_t count = 0;
     const NodeFwd w0 = fwd_node(fw, n0);
+    const uint4 st = reinterpret_cast<const uint4 *>(g.walk + n0)[0];        // NodeWalk: (seq_start, tail)
     if (o0 < 0 || o0 > w0.size) { *count_out = 0; if (SCRIPT) *used_out = 0; return; }
     // level 0: the start node from offset o0 (an empty start node contributes no base)
     int L = 0, have0 = 0;
@@ -203,8 +204,17 @@ __device__ void forward_walk(const DevGraph &g, const NodeFwd *__restrict__ fw, 
     {
         const int avail = w0.size - o0;
         const int t = avail < k ? avail : k;
-        // (the start node's bases from o0: inside its first 31 they are in the record, else two words of the sequence)
-        if (t > 0) h0 = o0 + t <= 31 ? (w0.head >> (2 * o0)) & ((1ull << (2 * t)) - 1ull) : gki_extract(g.seq2, g.seq_start[n0] + o0, t);
+        // The start node's bases from o0.  A window that goes on into a successor takes the node's LAST t bases: they are in
+        // the boundary walk's record of the node (NodeWalk::tail, its first 16 bytes asked for together with the search's own
+        // record) -- no trip to the sequence, which was the third dependent round trip of every start position.  A window
+        // complete inside the start node: inside the node's first 31 bases from the record's head, else from the sequence.
+        if (t > 0 && t < k) {
+            const int t31 = w0.size < 31 ? w0.size : 31;
+            h0 = (((uint64_t)st.z | ((uint64_t)st.w << 32)) >> (2 * (t31 - t))) & ((1ull << (2 * t)) - 1ull);
+        } else if (t > 0) {
+            h0 = o0 + t <= 31 ? (w0.head >> (2 * o0)) & ((1ull << (2 * t)) - 1ull)
+                              : gki_extract(g.seq2, (int64_t)((uint64_t)st.x | ((uint64_t)st.y << 32)) + o0, t);
+        }
         have0 = t;
         if (t < k) {                           // (t == k: window complete inside the start node, handled below)
             const int vc0 = w0.is_ref ? 0 : 1, forced0 = any_followed(g, follow, n0) ? 1 : 0;
