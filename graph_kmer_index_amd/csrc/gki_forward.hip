@@ -362,8 +362,14 @@ __device__ void forward_walk(const DevGraph &g, const NodeFwd *__restrict__ fw, 
 //  - memory instructions per turn: one NodeFwd record per descent, the first levels in registers, the minimum allele
 //    frequency carried down (round 4: 6.4 -> 4.7 ms; round 2 had tried carrying it in scratch: slower);
 //  - 64-thread workgroups: with 256 a slot waits for the slowest of four waves (4.6 -> 4.8 ms).
+//  - bytes of script: a three-node path's entry in two pieces instead of three (4.75 -> 4.3 ms).
+// What did NOT move it: a dependent round trip fewer per descent (round 4's early-edges switch) or per start position
+// (the start node's bases from NodeWalk::tail instead of the sequence: 1 %), fewer scratch levels, a third register level,
+// 6 instead of 8 waves per SIMD.  So the bound is the memory instructions the waves issue -- each a request per distinct
+// line among 64 lanes that share little -- not the length of a lane's dependent chain.
 // Still there: the slowest lane -- a start position whose window crosses a second variant takes twice the turns of its
-// neighbours, and they wait for it.
+// neighbours, and they wait for it (a refilling state-machine form of the walk was tried against that and was slower:
+// profiles/r04_forward_node_records_ab.txt).
 template <bool EMIT, bool DEEP = false, bool SCRIPT = false>
 __global__ __launch_bounds__(DEEP ? 64 : GKI_FWD_BLOCK, DEEP ? 1 : GKI_FWD_WAVES) void k_forward(DevGraph g, const NodeFwd *__restrict__ fw, int k, int M, int one_node, const uint8_t *__restrict__ follow,
                                                 const int32_t *__restrict__ nodes,
