@@ -426,6 +426,38 @@ def test_kmers_from_positions_when_node_ids_do_not_grow_along_the_path():
     assert out_of_order >= 5
 
 
+def test_early_stop_search_after_the_sequence_on_the_device_was_replaced():
+    # gki_graph_prepare (include/gki.h) after the caller rewrote its device sequence: the search's per-node records (first
+    # bases of every node, built by the first search on the graph) belong to the old sequence and have to be built again --
+    # and so do the finder's walk records, whose tails the search reads for its start nodes
+    from graph_kmer_index_amd import _lib
+    from graph_kmer_index_amd.device_graph import DeviceGraph
+    rng = np.random.default_rng(77)
+    for it in range(6):
+        k = int(rng.integers(4, 14))
+        seqs, edges, lin, af = overlapping_bubble_graph(rng, n_var=int(rng.integers(3, 10)), min_ref=1, max_ref=k)
+        g = GraphArrays.from_dicts(seqs, edges, lin, af)
+        d_seq = _lib.DeviceArray.from_host(np.ascontiguousarray(g.seq, dtype=np.uint8))
+        g._device = DeviceGraph(g, d_seq=d_seq)
+        nodes = rng.integers(0, g.n_nodes, size=24)
+        offs = [int(rng.integers(0, max(1, g.node_size[n]))) for n in nodes]
+        for round_ in range(2):
+            try:
+                exp = [oracle.find_from_position(g, k, int(n), int(o), False, 4) for n, o in zip(nodes, offs)]
+            except oracle.OracleError:
+                break
+            f = DenseKmerFinder(g, k, only_save_one_node_per_kmer=False, max_variant_nodes=4)
+            f.find_kmers_starting_at_positions(nodes, offs)
+            assert_same_records(finder_cols(f), {key: np.concatenate([e[key] for e in exp]) for key in exp[0]}, exact_order=True)
+            f.close()
+            # other bases in the same nodes, written over the caller's device buffer
+            g.seq[:] = rng.integers(0, 4, size=len(g.seq)).astype(g.seq.dtype)
+            _lib.check(_lib.load().gki_memcpy_h2d(d_seq.ptr, _lib.hptr(np.ascontiguousarray(g.seq, dtype=np.uint8)), len(g.seq)))
+            g._device.prepare()
+        g._device.close()
+        g._device = None
+
+
 def test_early_stop_emit_from_the_script_equals_the_walking_emit():
     # csrc/gki_forward.hip: in all-nodes mode gki_forward_count leaves the finished k-mers in a script and the
     # gki_forward_emit call with the same arguments expands it (start positions with more than four finished k-mers or a
