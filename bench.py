@@ -765,7 +765,7 @@ def main():
                     help="full_index: the partition also groups every slice by this many top key bits (8 slices x 2^7 = the pass's 1024 "
                          "digits) and the slice builds start from there with one pass less; 0: plain bucket-range partition")
     ap.add_argument("--no-sharded-build", action="store_true", help="skip the sharded_build record (N>1)")
-    ap.add_argument("--sharded-build-budget", type=float, default=600.0, help="seconds the sharded_build record may take before "
+    ap.add_argument("--sharded-build-budget", type=float, default=300.0, help="seconds the sharded_build record may take before "
                     "rank 0 prints the line without it")
     ap.add_argument("--modulo", type=int, default=452930477)
     args = ap.parse_args()
