@@ -72,14 +72,29 @@ __device__ __forceinline__ size_t script_cell(int64_t i, int c, int p, int64_t n
 // list: in all-nodes mode the path's nodes but the last, which is q (a path over three nodes -- start node, allele, the node
 // that completes the k-mer -- is two pieces); in one-node mode (flag bit 0) the one node the record reports.  The number of
 // the entry's first record among its start position's is not stored: it is the sum of the records of the slots before it.
+// The script's cells leave with the non-temporal hint: they are read once, by another kernel, and the lines of the graph the
+// walk reads stay in L2 -- all nodes 4.27 -> 3.97 ms, same box, alternating (profiles/r04_forward_script_layout_ab.txt;
+// -DGKI_FWD_SCRIPT_NT=0 rebuilds the plain stores).
+#ifndef GKI_FWD_SCRIPT_NT
+#define GKI_FWD_SCRIPT_NT 1
+#endif
+__device__ __forceinline__ void script_store(uint4 *p, const uint4 &v) {
+    if (GKI_FWD_SCRIPT_NT) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+        __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(p));
+    } else *p = v;
+}
 __device__ __forceinline__ void script_write(uint4 *script, int64_t i, int c, int64_t n_pos, uint64_t h, double maf, int32_t q, int off, int lw,
                                              bool one_node, const int32_t *nodes) {
     const uint64_t mb = (uint64_t)__double_as_longlong(maf);
     const int listed = one_node ? 1 : lw - 1;
-    script[script_cell(i, c, 0, n_pos)] = make_uint4((uint32_t)h, (uint32_t)(h >> 32), (uint32_t)mb, (uint32_t)(mb >> 32));
-    script[script_cell(i, c, 1, n_pos)] = make_uint4((uint32_t)q, ((uint32_t)off & 0xFFFFu) | ((uint32_t)lw << 16) | (one_node ? 1u << 24 : 0u),
-                                                     (uint32_t)nodes[0], (uint32_t)nodes[1]);
-    if (listed > 2) script[script_cell(i, c, 2, n_pos)] = make_uint4((uint32_t)nodes[2], (uint32_t)nodes[3], 0u, 0u);
+    const uint4 p0 = make_uint4((uint32_t)h, (uint32_t)(h >> 32), (uint32_t)mb, (uint32_t)(mb >> 32));
+    const uint4 p1 = make_uint4((uint32_t)q, ((uint32_t)off & 0xFFFFu) | ((uint32_t)lw << 16) | (one_node ? 1u << 24 : 0u),
+                                (uint32_t)nodes[0], (uint32_t)nodes[1]);
+    script_store(&script[script_cell(i, c, 0, n_pos)], p0);
+    script_store(&script[script_cell(i, c, 1, n_pos)], p1);
+    if (listed > 2) script_store(&script[script_cell(i, c, 2, n_pos)], make_uint4((uint32_t)nodes[2], (uint32_t)nodes[3], 0u, 0u));
 }
 
 // only_follow_nodes (kmer_finder.py:386-388): when a node has successors in the follow set, only those are taken
